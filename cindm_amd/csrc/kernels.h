@@ -1,0 +1,638 @@
+// Device kernels of libcindm_hip.so (gfx950 / CDNA4 only).
+//
+// Data layout: every activation is channel-last fp32 [rows = sample*L + position, C] with an
+// explicit row stride, which is the reference's API layout [B, horizon, F]
+// (model/diffusion_1d.py:610-614) -- the reference's two `b h t -> b t h` transposes disappear.
+//
+// conv_gemm_kernel<T>: implicit-GEMM 1-D convolution / linear layer on fp32 MFMA
+// (v_mfma_f32_16x16x4_f32, exact fp32 == an fmaf chain in k order).
+//   out[b, lo, n] = bias[n] + sum_{tap<T} sum_{c<Cin} W[tap][c][n] * act(in)[b, li(lo,tap), c]
+// One workgroup (4 waves) owns a 48-row x 32-column output tile; since C*L = 1536 for every
+// tensor of the U-Net this is exactly one tile per sample-equivalent, i.e. B' workgroups per layer.
+// The 4 waves split K (each wave owns 8 of every 32 input channels, all taps) and are reduced
+// through LDS at the end, so nothing is shared between waves inside the K loop:
+//   * A (activations) is staged per 32-channel chunk into LDS ONCE per workgroup, with the
+//     producer's GroupNorm+Mish(+time bias) / LayerNorm applied on the way in ("normalise on
+//     load"), and read as MFMA fragments with one ds_read_b32 per 16x4 fragment; conv taps are
+//     pure LDS row offsets, out-of-range taps point at a zero row.
+//   * B (weights, repacked [tap][Cin][Cout]) goes straight from L2 to VGPRs in MFMA fragment
+//     order (each weight is used by exactly one wave), prefetched one chunk ahead.
+// Epilogue: cross-wave reduce, bias, optional "+ Mish(GroupNorm(y))" and "+ residual" terms,
+// store, and per-(sample, group) GroupNorm statistics / per-row LayerNorm statistics of the
+// OUTPUT as (mean, M2) partials (two-pass in LDS, merged by the consumer with Chan's formula)
+// so that no separate normalisation pass over HBM exists.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cindm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 48;        // tile rows
+constexpr int TN = 32;        // tile cols
+constexpr int KC = 32;        // channels per staged chunk
+constexpr int LDA = 34;       // LDS row pitch (floats): 2*row + k spreads 16 rows x 2 k over 32 banks
+constexpr int MAXR = 96;      // max input rows per tile (stride-2 conv: 2 * 48)
+constexpr int ZROW = MAXR;    // index of the all-zero LDS row
+constexpr int LDR = 33;       // reduce / output tile pitch
+
+enum SrcMode { SRC_PLAIN = 0, SRC_GN_MISH = 1, SRC_LN = 2, SRC_MISH = 3 };
+
+struct Src {
+    const float* p;       // [rows, ld]
+    int ld;
+    int C;                // valid channels of this source (multiple of 4)
+    int mode;             // SrcMode
+    const float* stats;   // GN: [Bp][8][P][2] (mean, M2);  LN: [rows][P][2]
+    int P;                // partials per statistic
+    int gw;               // GN group width (channels per group)
+    float cnt;            // elements per partial (GN: L*min(gw,32); LN: 32)
+    const float* gamma;   // [C] (GN weight / LN g)
+    const float* beta;    // [C] (GN bias) or null
+    const float* tb;      // per-timestep bias table base (already offset to this layer) or null
+    int tb_ld;            // table row pitch
+};
+
+struct GemmArgs {
+    Src src[2];
+    int nsrc;
+    const float* W;       // [T][CinP][Npad]
+    const float* bias;    // [Npad] or null
+    int CinP, Npad, N;
+    int Bp, Lin, Lout, stride, pad, transposed, spt;
+    float* out; int ldo;
+    const float* res; int ldres;                         // + res
+    const float* e_y; int e_ld; const float* e_stats;    // + Mish(GN(e_y))
+    int e_P; int e_gw; float e_cnt; const float* e_gamma; const float* e_beta;
+    float* stats_out; int so_gw;                         // GN (mean,M2) partials of the output
+    float* ln_out;                                       // LN (mean,M2) partials per row & 32-col tile
+    const int* t_ptr; int t_imm;                         // timestep (device pointer wins)
+};
+
+__device__ __forceinline__ float mish_f(float x) {
+    // Mish(x) = x * tanh(softplus(x)), PyTorch softplus threshold 20.
+    // tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2),  n = e*(e+2)   (no cancellation)
+    if (x > 20.0f) return x;
+    float e = expf(x);
+    float n = e * (e + 2.0f);
+    return x * (n / (n + 2.0f));
+}
+
+__device__ __forceinline__ float wave_sum_seg(float v, int seg) {
+    // deterministic butterfly sum over aligned lane segments of size seg (power of two <= 64)
+    for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Merge P equal-count (mean, M2) partials -> (mean, rstd) with eps.
+__device__ __forceinline__ void merge_stats(const float* st, int P, float cnt, float eps, float& mean, float& rstd) {
+    float m = 0.f;
+    for (int p = 0; p < P; ++p) m += st[2 * p];
+    m /= (float)P;
+    float M2 = 0.f;
+    for (int p = 0; p < P; ++p) {
+        float d = st[2 * p] - m;
+        M2 += st[2 * p + 1] + cnt * d * d;
+    }
+    mean = m;
+    rstd = 1.0f / sqrtf(M2 / (cnt * (float)P) + eps);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][(MAXR + 1) * LDA];
+    __shared__ __attribute__((aligned(16))) float Red[4][TM * LDR];
+    __shared__ float tabA[TM * 8 * 2];      // GN prologue: [spt][8](mean, rstd), spt <= 48;  LN: [rows_in <= 96](mean, rstd)
+    __shared__ float tabE[TM * 8 * 2];      // epilogue GN table [spt][8](mean, rstd)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int b0 = mt * a.spt;
+    const int ns = min(a.spt, a.Bp - b0);
+    const int rows_out = ns * a.Lout;
+    const int rows_in = ns * a.Lin;
+    const int n0 = nt * TN;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+
+    // ---- zero rows + normalisation tables -------------------------------------------------
+    for (int i = tid; i < 2 * LDA; i += 256) As[i / LDA][ZROW * LDA + (i % LDA)] = 0.f;
+    {
+        const Src& s = a.src[0];
+        if (s.mode == SRC_GN_MISH) {
+            for (int i = tid; i < ns * 8; i += 256) {
+                float m, r;
+                merge_stats(s.stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
+                tabA[2 * i] = m; tabA[2 * i + 1] = r;
+            }
+        } else if (s.mode == SRC_LN) {
+            for (int i = tid; i < rows_in; i += 256) {
+                float m, r;
+                merge_stats(s.stats + (size_t)(b0 * a.Lin + i) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
+                tabA[2 * i] = m; tabA[2 * i + 1] = r;
+            }
+        }
+    }
+    if (a.e_y) {
+        for (int i = tid; i < ns * 8; i += 256) {
+            float m, r;
+            merge_stats(a.e_stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * a.e_P * 2, a.e_P, a.e_cnt, 1e-5f, m, r);
+            tabE[2 * i] = m; tabE[2 * i + 1] = r;
+        }
+    }
+
+    // ---- per-lane A fragment addresses (float index into one As buffer) --------------------
+    int aaddr[3][T > 0 ? T : 1];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        const int r = mb * 16 + (lane & 15);
+        const int s = r / a.Lout, lo = r - s * a.Lout;
+#pragma unroll
+        for (int tap = 0; tap < (T > 0 ? T : 1); ++tap) {
+            int row = ZROW;
+            if (r < rows_out) {
+                int li; bool ok;
+                if (!a.transposed) { li = lo * a.stride + tap - a.pad; ok = (li >= 0) && (li < a.Lin); }
+                else { int q = lo + a.pad - tap; li = q >> 1; ok = (q >= 0) && !(q & 1) && (li < a.Lin); }
+                if (ok) row = s * a.Lin + li;
+            }
+            aaddr[mb][tap] = row * LDA + w * 8 + (lane >> 4);
+        }
+    }
+
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    if constexpr (T > 0) {
+        const int nch0 = (a.src[0].C + KC - 1) / KC;
+        const int nch = nch0 + (a.nsrc > 1 ? (a.src[1].C + KC - 1) / KC : 0);
+        // staging role: thread -> (row r0 + 32p, channels c4*4..c4*4+3)
+        const int c4 = tid & 7, r0 = tid >> 3;
+        int srow[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) srow[p] = (r0 + 32 * p) / a.Lin;
+
+        float4 stg[3];
+        auto stage_load = [&](int ch) {
+            const Src& s = (ch < nch0) ? a.src[0] : a.src[1];
+            const int cl = ((ch < nch0) ? ch : ch - nch0) * KC + c4 * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int r = r0 + 32 * p;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < rows_in && cl < s.C)
+                    v = *reinterpret_cast<const float4*>(s.p + (size_t)(b0 * a.Lin + r) * s.ld + cl);
+                stg[p] = v;
+            }
+        };
+        auto stage_store = [&](int ch) {
+            const Src& s = (ch < nch0) ? a.src[0] : a.src[1];
+            const int cl = ((ch < nch0) ? ch : ch - nch0) * KC + c4 * 4;
+            float* dst = As[ch & 1];
+            const bool cok = cl < s.C;
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f), tb = bt;
+            if (cok && (s.mode == SRC_GN_MISH || s.mode == SRC_LN)) {
+                g = *reinterpret_cast<const float4*>(s.gamma + cl);
+                if (s.beta) bt = *reinterpret_cast<const float4*>(s.beta + cl);
+            }
+            if (cok && s.tb) tb = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + cl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int r = r0 + 32 * p;
+                if (r >= MAXR) continue;
+                float4 v = stg[p];
+                if (r < rows_in && cok) {
+                    if (s.mode == SRC_GN_MISH) {
+                        const int ti = (srow[p] * 8 + cl / s.gw) * 2;
+                        const float m = tabA[ti], rs = tabA[ti + 1];
+                        v.x = mish_f((v.x - m) * rs * g.x + bt.x) + tb.x;
+                        v.y = mish_f((v.y - m) * rs * g.y + bt.y) + tb.y;
+                        v.z = mish_f((v.z - m) * rs * g.z + bt.z) + tb.z;
+                        v.w = mish_f((v.w - m) * rs * g.w + bt.w) + tb.w;
+                    } else if (s.mode == SRC_LN) {
+                        const float m = tabA[2 * r], rs = tabA[2 * r + 1];
+                        v.x = (v.x - m) * rs * g.x; v.y = (v.y - m) * rs * g.y;
+                        v.z = (v.z - m) * rs * g.z; v.w = (v.w - m) * rs * g.w;
+                    } else if (s.mode == SRC_MISH) {
+                        v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w);
+                    }
+                }
+                float2* d2 = reinterpret_cast<float2*>(dst + r * LDA + c4 * 4);
+                d2[0] = make_float2(v.x, v.y);
+                d2[1] = make_float2(v.z, v.w);
+            }
+        };
+
+        float bcur[2 * T][2], bnxt[2 * T][2];
+        auto load_b = [&](int ch, float (&b)[2 * T][2]) {
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+                for (int cs = 0; cs < 2; ++cs) {
+                    const size_t krow = (size_t)tap * a.CinP + ch * KC + w * 8 + cs * 4 + (lane >> 4);
+                    const float* wp = a.W + krow * a.Npad + n0 + (lane & 15);
+                    b[tap * 2 + cs][0] = wp[0];
+                    b[tap * 2 + cs][1] = wp[16];
+                }
+        };
+
+        __syncthreads();          // tables + zero rows visible
+        load_b(0, bcur);
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool more = ch + 1 < nch;
+            if (more) { load_b(ch + 1, bnxt); stage_load(ch + 1); }
+            const float* Ab = As[ch & 1];
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+                for (int cs = 0; cs < 2; ++cs) {
+                    const float a0 = Ab[aaddr[0][tap] + cs * 4];
+                    const float a1 = Ab[aaddr[1][tap] + cs * 4];
+                    const float a2 = Ab[aaddr[2][tap] + cs * 4];
+                    const float b0v = bcur[tap * 2 + cs][0], b1v = bcur[tap * 2 + cs][1];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0v, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1v, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0v, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc[1][1], 0, 0, 0);
+                    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0v, acc[2][0], 0, 0, 0);
+                    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1v, acc[2][1], 0, 0, 0);
+                }
+            if (more) {
+                stage_store(ch + 1);
+#pragma unroll
+                for (int i = 0; i < 2 * T; ++i) { bcur[i][0] = bnxt[i][0]; bcur[i][1] = bnxt[i][1]; }
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+
+    // ---- cross-wave K reduction through LDS --------------------------------------------------
+    // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
+    __syncthreads();
+
+    const int n = tid & 31, rq = tid >> 5;
+    const int gn = n0 + n;
+    const bool nok = gn < a.N;
+    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+    float eg = 1.f, eb = 0.f;
+    if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        float v = 0.f;
+        if (T > 0) v = (Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n]);
+        v += bias;
+        if (r < rows_out && nok) {
+            const size_t grow = (size_t)b0 * a.Lout + r;
+            if (a.e_y) {
+                const int s = r / a.Lout;
+                const int ti = (s * 8 + gn / a.e_gw) * 2;
+                const float y = a.e_y[grow * a.e_ld + gn];
+                v += mish_f((y - tabE[ti]) * tabE[ti + 1] * eg + eb);
+            }
+            if (a.res) v += a.res[grow * a.ldres + gn];
+            a.out[grow * a.ldo + gn] = v;
+        } else {
+            v = 0.f;
+        }
+        Red[0][r * LDR + n] = v;     // finished tile kept for the statistics passes (own slot only)
+    }
+
+    if (a.stats_out || a.ln_out) __syncthreads();
+
+    if (a.stats_out) {
+        // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group part).
+        const int gwt = min(a.so_gw, TN);             // group columns inside this tile
+        const int ngt = TN / gwt;                     // groups (or one part of a group) per tile
+        const int P = max(1, a.so_gw / TN);           // partials per statistic
+        const int S = a.spt * ngt;
+        const int ne = a.Lout * gwt;
+        int tps = 1;
+        while (tps * 2 * S <= 256 && tps < 64) tps <<= 1;
+        const int si = tid / tps, u = tid - si * tps;
+        const bool act = si < S;
+        const int s = act ? si / ngt : 0, gl = act ? si - (si / ngt) * ngt : 0;
+        float sum = 0.f;
+        if (act)
+            for (int e = u; e < ne; e += tps) { const int l = e / gwt, c = e - l * gwt; sum += Red[0][(s * a.Lout + l) * LDR + gl * gwt + c]; }
+        sum = wave_sum_seg(sum, tps);
+        const float mean = sum / (float)ne;
+        float m2 = 0.f;
+        if (act)
+            for (int e = u; e < ne; e += tps) { const int l = e / gwt, c = e - l * gwt; const float d = Red[0][(s * a.Lout + l) * LDR + gl * gwt + c] - mean; m2 += d * d; }
+        m2 = wave_sum_seg(m2, tps);
+        if (act && u == 0 && s < ns) {
+            const int g = (n0 + gl * gwt) / a.so_gw;
+            const int p = (n0 / TN) % P;
+            float* o = a.stats_out + (((size_t)(b0 + s) * 8 + g) * P + p) * 2;
+            o[0] = mean; o[1] = m2;
+        }
+    }
+    if (a.ln_out) {
+        // LayerNorm partial statistics per output row over this tile's 32 columns.
+        const int r = tid >> 2, sub = tid & 3;
+        float sum = 0.f;
+        if (r < TM)
+            for (int c = sub * 8; c < sub * 8 + 8; ++c) sum += Red[0][r * LDR + c];
+        sum = wave_sum_seg(sum, 4);
+        const float mean = sum * (1.0f / 32.0f);
+        float m2 = 0.f;
+        if (r < TM)
+            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - mean; m2 += d * d; }
+        m2 = wave_sum_seg(m2, 4);
+        if (sub == 0 && r < rows_out) {
+            float* o = a.ln_out + (((size_t)b0 * a.Lout + r) * (a.Npad / TN) + nt) * 2;
+            o[0] = mean; o[1] = m2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear attention core (LinearAttentionTemporal.forward, model/diffusion_1d.py:281-291) for one
+// (sample, head) per wave: q *= 32^-0.5; k = softmax over positions; ctx[d][e] = sum_n k[d][n] v[e][n];
+// out[e][n] = sum_d ctx[d][e] q[d][n].   qkv: [rows, 384] (q | k | v, each heads*32 channels, head-major);
+// att: [rows, 128].  grid = Bp, block = 256 (4 heads).
+constexpr int ATT_MAXL = 48;
+__global__ __launch_bounds__(256) void linattn_core_kernel(const float* __restrict__ qkv, float* __restrict__ att, int L) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    float* q = sm + (size_t)h * (3 * L * 32 + 32 * 33);
+    float* k = q + L * 32;
+    float* v = k + L * 32;
+    float* ctx = v + L * 32;                       // [32][33]
+    const size_t row0 = (size_t)blockIdx.x * L;
+    const int d = lane & 31, half = lane >> 5;
+    const float scale = 0.17677669529663687f;      // 32 ** -0.5
+    for (int n = half; n < L; n += 2) {
+        const float* p = qkv + (row0 + n) * 384 + h * 32 + d;
+        q[n * 32 + d] = p[0] * scale;
+        k[n * 32 + d] = p[128];
+        v[n * 32 + d] = p[256];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    // softmax over positions n for channel d (both halves compute redundantly -> no cross-lane traffic)
+    float mx = -INFINITY;
+    for (int n = 0; n < L; ++n) mx = fmaxf(mx, k[n * 32 + d]);
+    float sum = 0.f;
+    for (int n = 0; n < L; ++n) sum += expf(k[n * 32 + d] - mx);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    for (int n = half; n < L; n += 2) k[n * 32 + d] = expf(k[n * 32 + d] - mx) * inv;
+    __syncthreads();
+    // ctx[d][e], e in [half*16, half*16+16)
+    float c[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = 0.f;
+    for (int n = 0; n < L; ++n) {
+        const float kk = k[n * 32 + d];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[j] += kk * v[n * 32 + half * 16 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ctx[d * 33 + half * 16 + j] = c[j];
+    __syncthreads();
+    // out[e][n] for e = lane&31, n = half, half+2, ...
+    const int e = d;
+    for (int n = half; n < L; n += 2) {
+        float o = 0.f;
+#pragma unroll 8
+        for (int dd = 0; dd < 32; ++dd) o += ctx[dd * 33 + e] * q[n * 32 + dd];
+        att[(row0 + n) * 128 + h * 32 + e] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based Gaussian noise: Philox4x32-10 keyed by seed, counter = (element/4, sample, step, 0),
+// Box-Muller on the four 32-bit outputs.  Pure function of (seed, global sample, step, element):
+// results do not depend on the number of GPUs / batch partition.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float counter_normal(uint64_t seed, uint64_t sample, uint32_t step, uint32_t elem) {
+    uint32_t r[4];
+    philox4x32_10(elem >> 2, (uint32_t)sample, step, (uint32_t)(sample >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int j = elem & 3;
+    const uint32_t ra = r[j & 2], rb = r[(j & 2) + 1];
+    const float u1 = ((float)(ra >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(rb >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    return (j & 1) ? rad * sn : rad * cs;
+}
+
+__global__ void fill_normal_kernel(float* out, int64_t B, int64_t per, uint64_t seed, int64_t off, uint32_t step) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * per) return;
+    const int64_t b = i / per, e = i - b * per;
+    out[i] = counter_normal(seed, (uint64_t)(off + b), step, (uint32_t)e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Composition: gather U-Net input rows, and scatter-aggregate + DDPM posterior update.
+struct ComposeArgs {
+    int mode, W, cs, T, nb, cond_steps, objective, clip;
+    float uncond_coef;
+    int64_t B;
+    int Ltot;            // rows of the state x per sample (excludes cond rows)
+    int F;               // 4 * nb
+    const float* x;      // [B, Ltot, F]
+    const float* cond;   // [B, cond_steps, F] or null
+    float* pair_in;      // [(kk*P+p)*B + b, T, 8]
+    float* single_in;    // MULTIBODY: [i*B + b, T, 4]
+    const float* pair_eps;
+    const float* single_eps;
+    // schedule tables (device, [timesteps])
+    const float* sqrt_recip; const float* sqrt_recipm1; const float* sqrt_ac; const float* sqrt_1mac;
+    const float* coef1; const float* coef2; const float* logvar;
+    const int* t_ptr; int t_imm;
+    // outputs
+    float* mean_out; float* x0_out; float* eps_out;   // predict
+    float* x_out;                                      // step: x_{t-1} (may alias x)
+    const float* noise; int64_t noise_t_stride;        // explicit noise (+ t * stride), or null
+    uint64_t seed; int64_t sample_off; int add_noise;
+    const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
+};
+
+__device__ __forceinline__ int pair_index(int i, int j, int nb) {   // i < j, order (0,1),(0,2),..,(1,2),..
+    return i * nb - (i * (i + 1)) / 2 + (j - i - 1);
+}
+
+// state value at full-sequence row l (cond rows first when cond_steps > 0)
+__device__ __forceinline__ float full_x(const ComposeArgs& a, int64_t b, int l, int f) {
+    if (l < a.cond_steps) return a.cond[((size_t)b * a.cond_steps + l) * a.F + f];
+    return a.x[((size_t)b * a.Ltot + (l - a.cond_steps)) * a.F + f];
+}
+
+__global__ void compose_gather_kernel(const ComposeArgs a) {
+    // pair rows
+    const int P = a.nb * (a.nb - 1) / 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.mode == 0) {                       // plain model on cat(cond, x): [B, Lfull, F]
+        const int Lfull = a.Ltot + a.cond_steps;
+        if (i >= a.B * (int64_t)Lfull * a.F) return;
+        const int f = (int)(i % a.F);
+        const int l = (int)((i / a.F) % Lfull);
+        a.pair_in[i] = full_x(a, i / ((int64_t)a.F * Lfull), l, f);
+        return;
+    }
+    const int64_t npair = (int64_t)a.W * P * a.B * a.T * 8;
+    const int64_t nsingle = (a.mode == 5) ? (int64_t)a.nb * a.B * a.T * 4 : 0;
+    if (i < npair) {
+        const int c = (int)(i & 7);
+        int64_t r = i >> 3;
+        const int l = (int)(r % a.T); r /= a.T;
+        const int64_t b = r % a.B; r /= a.B;
+        const int p = (int)(r % P); const int kk = (int)(r / P);
+        // decode pair p -> (ii, jj)
+        int ii = 0, rem = p;
+        while (rem >= a.nb - 1 - ii) { rem -= a.nb - 1 - ii; ++ii; }
+        const int jj = ii + 1 + rem;
+        const int f = (c < 4) ? ii * 4 + c : jj * 4 + (c - 4);
+        a.pair_in[i] = full_x(a, b, kk * a.cs + l, f);
+    } else if (i < npair + nsingle) {
+        const int64_t k = i - npair;
+        const int c = (int)(k & 3);
+        int64_t r = k >> 2;
+        const int l = (int)(r % a.T); r /= a.T;
+        const int64_t b = r % a.B; const int body = (int)(r / a.B);
+        a.single_in[k] = full_x(a, b, l, body * 4 + c);
+    }
+}
+
+// One thread per state element (b, l, f) of the FULL sequence (cond rows skipped on output).
+__global__ void compose_update_kernel(const ComposeArgs a) {
+    const int Lfull = a.Ltot + a.cond_steps;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * (int64_t)a.Ltot * a.F) return;
+    const int f = (int)(i % a.F);
+    const int lx = (int)((i / a.F) % a.Ltot);
+    const int64_t b = i / ((int64_t)a.F * a.Ltot);
+    const int l = lx + a.cond_steps;             // row in the full sequence
+    const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int body = f >> 2, comp = f & 3;
+    const int P = a.nb * (a.nb - 1) / 2;
+    const float xv = a.x[i];
+    const float ra = a.sqrt_recip[t], rb = a.sqrt_recipm1[t], c1 = a.coef1[t], c2 = a.coef2[t];
+
+    auto pair_eps_at = [&](int kk, int other, int lw) -> float {
+        // eps of `body` from the pair {body, other} in window kk at window row lw
+        const int ii = min(body, other), jj = max(body, other);
+        const int p = pair_index(ii, jj, a.nb);
+        const int slot = (body == ii) ? 0 : 1;
+        const int64_t row = ((int64_t)kk * P + p) * a.B + b;
+        return a.pair_eps[(row * a.T + lw) * 8 + slot * 4 + comp];
+    };
+    auto x0_of = [&](float eps_or_out) -> float {
+        float x0;
+        if (a.objective == 0) x0 = ra * xv - rb * eps_or_out;
+        else if (a.objective == 1) x0 = eps_or_out;
+        else x0 = a.sqrt_ac[t] * xv - a.sqrt_1mac[t] * eps_or_out;
+        return x0;
+    };
+
+    float eps = 0.f, x0 = 0.f, mean = 0.f;
+    int cover = 0;
+    for (int kk = 0; kk < a.W; ++kk) { const int lw = l - kk * a.cs; if (lw >= 0 && lw < a.T) ++cover; }
+
+    if (a.mode == 0) {                       // plain: pair_eps is the model output on the full state
+        const float o = a.pair_eps[((size_t)b * Lfull + l) * a.F + f];
+        x0 = x0_of(o);
+        eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        mean = c1 * x0 + c2 * xv;
+    } else if (a.mode == 1 || a.mode == 2 || a.mode == 4) {
+        // eps aggregated over senders then windows (model/diffusion_1d.py:994-999, :1457-1458)
+        float tot = 0.f;
+        for (int kk = 0; kk < a.W; ++kk) {
+            const int lw = l - kk * a.cs;
+            if (lw < 0 || lw >= a.T) continue;
+            float s = 0.f;
+            for (int o = 0; o < a.nb; ++o) if (o != body) s += pair_eps_at(kk, o, lw);
+            if (a.mode == 1) s /= (float)(a.nb - 1);
+            tot += s;
+        }
+        const float o = (a.mode == 1) ? tot / (float)cover : tot / ((float)cover / (float)a.W);
+        x0 = x0_of(o);
+        eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        mean = c1 * x0 + c2 * xv;
+    } else if (a.mode == 3) {
+        // p_mean_variance per (window, pair), then average mean and x0 (:1436-1452)
+        float tm = 0.f, tx = 0.f, te = 0.f;
+        for (int kk = 0; kk < a.W; ++kk) {
+            const int lw = l - kk * a.cs;
+            if (lw < 0 || lw >= a.T) continue;
+            float sm = 0.f, sx = 0.f, se = 0.f;
+            for (int o = 0; o < a.nb; ++o) {
+                if (o == body) continue;
+                const float e = pair_eps_at(kk, o, lw);
+                float x0e = x0_of(e);
+                if (a.clip) x0e = fminf(fmaxf(x0e, -1.f), 1.f);
+                sm += c1 * x0e + c2 * xv; sx += x0e; se += e;
+            }
+            tm += sm / (float)(a.nb - 1); tx += sx / (float)(a.nb - 1); te += se / (float)(a.nb - 1);
+        }
+        mean = tm / (float)cover; x0 = tx / (float)cover; eps = te / (float)cover;
+    } else {                                 // mode 5: gradient() :1900-1922
+        float s = 0.f;
+        for (int o = 0; o < a.nb; ++o) if (o != body) s += pair_eps_at(0, o, l);
+        const float u = a.single_eps[(((int64_t)body * a.B + b) * a.T + l) * 4 + comp];
+        const float o = s - a.uncond_coef * u;
+        x0 = x0_of(o);
+        eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        mean = c1 * x0 + c2 * xv;
+    }
+
+    if (a.mean_out) a.mean_out[i] = mean;
+    if (a.x0_out) a.x0_out[i] = x0;
+    if (a.eps_out) a.eps_out[i] = eps;
+    if (a.x_out) {
+        float v = mean;
+        const uint32_t el = (uint32_t)(lx * a.F + f);
+        if (a.add_noise && t > 0) {
+            const float z = a.noise ? a.noise[(size_t)t * a.noise_t_stride + i]
+                                    : counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+            v += expf(0.5f * a.logvar[t]) * z;
+        }
+        if (a.inp_cond && lx < a.inp_steps) {      // inpainting overwrite (:1715-1718)
+            const size_t ci = ((size_t)b * a.inp_steps + lx) * a.F + f;
+            const float z = a.inp_noise ? a.inp_noise[(size_t)t * a.inp_noise_t_stride + ci]
+                                        : counter_normal(a.seed ^ 0x5bd1e995u, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+            v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z;
+        }
+        a.x_out[i] = v;
+    }
+}
+
+__global__ void dec_counter_kernel(int* t) { if (threadIdx.x == 0 && blockIdx.x == 0) *t -= 1; }
+
+}  // namespace cindm

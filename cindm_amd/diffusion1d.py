@@ -1,0 +1,434 @@
+"""GaussianDiffusion1D (sampling half) on MI355X: the reference's constructor / buffers / ``sample``
+surface (model/diffusion_1d.py:801-2406 of AI4Science-WestlakeU/cindm) over the HIP library.
+
+What runs where
+  * every U-Net evaluation, the window / body-pair gather, the score composition, x0 prediction,
+    clamp, posterior mean and the noise add run in ``libcindm_hip.so``;
+  * with ``design_fn=None`` (and no recurrence / overwrite) the whole reverse loop is ONE call
+    (``cindm_ddpm1d_sample``: one hipGraph-captured step replayed per timestep);
+  * ``design_fn`` guidance is a user Python callable: its gradient is taken by PyTorch autograd
+    between two library calls per step, exactly where the reference takes it.
+Training (``forward`` / ``p_losses``), DDIM and the unreachable ULA/UHMC samplers of the reference
+are out of this build's scope and raise NotImplementedError.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from . import _ffi
+from .schedule import make_schedule
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
+
+
+class NoiseTape:
+    """Explicit noise for parity runs, replacing the reference's ``torch.randn`` draws:
+    ``init`` [B,L,F] (x_T, :1673 / :1987); ``step`` [T,B,L,F] indexed by timestep (:1281 / :1118);
+    ``recur`` [T,R,B,L,F] relaxation draws (:1365); ``cond`` [T,B,Lc,F] inpainting draws (:1717)."""
+
+    def __init__(self, init, step, recur=None, cond=None):
+        self.init, self.step, self.recur, self.cond = init, step, recur, cond
+
+    def to(self, device):
+        f = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
+        return NoiseTape(f(self.init), f(self.step), f(self.recur), f(self.cond))
+
+
+def _exists(x):
+    return x is not None
+
+
+class GaussianDiffusion1D(nn.Module):
+    """Drop-in for the reference's ``GaussianDiffusion1D`` (constructor :802-822)."""
+
+    def __init__(self, model, model_unconditioned=None, betas_inference=None, *, image_size, conditioned_steps,
+                 timesteps=1000, sampling_timesteps=None, loss_type="l1", objective="pred_noise",
+                 beta_schedule="cosine", ddim_sampling_eta=0., auto_normalize=True, loss_weight_discount=0.95,
+                 num_time_steps_UHMC=100, is_diffusion_condition=None, backward_steps=5, backward_lr=1):
+        super().__init__()
+        self.model = model
+        self.model_unconditioned = model_unconditioned
+        self.betas_inference = betas_inference
+        self.channels = self.model.channels
+        self.is_diffusion_condition = is_diffusion_condition
+        self.self_condition = False
+        self.num_timesteps_UHMC = num_time_steps_UHMC
+        self.image_size = image_size
+        self.conditioned_steps = conditioned_steps
+        self.rollout_steps = image_size
+        self.objective = objective
+        self.backward_steps = backward_steps
+        self.backward_lr = backward_lr
+        assert objective in {"pred_noise", "pred_x0", "pred_v"}, "objective must be pred_noise, pred_x0 or pred_v"
+        tables = make_schedule(beta_schedule, timesteps, objective)
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.loss_weight_discount = loss_weight_discount
+        self.sampling_timesteps = sampling_timesteps if _exists(sampling_timesteps) else timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for name in _ffi.SCHED_NAMES:               # the 13 buffers, same names and order (:873-910)
+            self.register_buffer(name, tables[name])
+        self._h = None
+        self._tab_sig = None
+        self._ws = None
+
+    def __del__(self):
+        h = self.__dict__.get("_h")
+        if h is not None and h.value:
+            try:
+                _ffi.lib().cindm_ddpm1d_destroy(h)
+            except Exception:
+                pass
+            self.__dict__["_h"] = None
+
+    # ------------------------------------------------------------------ library handle
+    def _handle(self):
+        sig = tuple((getattr(self, n).data_ptr(), getattr(self, n)._version) for n in _ffi.SCHED_NAMES)
+        if self._h is not None and sig == self._tab_sig:
+            return self._h
+        L = _ffi.lib()
+        if self._h is not None:
+            L.cindm_ddpm1d_destroy(self._h)
+        d = _ffi.SchedDesc()
+        d.timesteps = self.num_timesteps
+        keep = []
+        for n in _ffi.SCHED_NAMES:
+            t = getattr(self, n).detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            setattr(d, n, t.data_ptr())
+        h = C.c_void_p()
+        dev = self.betas.device
+        if dev.type != "cuda":
+            raise _ffi.CindmError("GaussianDiffusion1D is on the CPU: move it to a ROCm device (.to('cuda')); "
+                                  "there is no CPU execution path")
+        with torch.cuda.device(dev):
+            _ffi.check(L.cindm_ddpm1d_create(C.byref(d), C.byref(h)))
+        self._h, self._tab_sig = h, sig
+        return h
+
+    def _compose_desc(self, mode, n_composed, compose_start_step, window, n_bodies, clip=True):
+        c = _ffi.ComposeDesc()
+        c.mode, c.n_windows, c.compose_start_step, c.window = mode, n_composed + 1, compose_start_step, window
+        c.n_bodies, c.cond_steps = n_bodies, self.conditioned_steps
+        c.objective, c.clip_denoised, c.uncond_coef = _ffi.OBJECTIVES[self.objective], int(clip), 1.4
+        return c
+
+    def _desc_for(self, x_shape, compose_mode=None, n_composed=0, compose_start_step=4, single_model_step=-1,
+                  compose_n_bodies=2, clip=True, outside=False):
+        """Maps the reference's keyword soup onto a compose descriptor."""
+        if outside:
+            if compose_mode == "mean":
+                mode = _ffi.COMPOSE_MEAN_OUTSIDE
+            elif compose_mode == "noise_sum":
+                mode = _ffi.COMPOSE_NOISESUM_OUTSIDE
+            else:
+                raise ValueError(f"unknown compose_mode {compose_mode!r}")
+            return self._compose_desc(mode, n_composed, compose_start_step, single_model_step, compose_n_bodies, clip)
+        if compose_mode is not None and "inside" in compose_mode:
+            if compose_mode == "mean-inside":
+                mode = _ffi.COMPOSE_MEAN_INSIDE
+            elif compose_mode == "sum-inside":
+                mode = _ffi.COMPOSE_SUM_INSIDE
+            else:
+                raise ValueError(f"unknown compose_mode {compose_mode!r}")
+            return self._compose_desc(mode, n_composed, compose_start_step, single_model_step, compose_n_bodies, clip)
+        nb = x_shape[-1] // 4
+        if self.model_unconditioned is not None:           # :1003-1004 -> gradient()
+            if nb != 4:
+                raise NotImplementedError("gradient(): only the 4-body branch is supported (the reference's 3-body "
+                                          "branch hard-codes batch 20, model/diffusion_1d.py:1958-1960)")
+            return self._compose_desc(_ffi.COMPOSE_MULTIBODY, 0, 0, self.model.horizon, nb, clip)
+        return self._compose_desc(_ffi.COMPOSE_PLAIN, 0, 0, self.model.horizon, nb, clip)
+
+    def _prepare(self, desc, B, device):
+        self.model.sync_weights()
+        if desc.mode == _ffi.COMPOSE_MULTIBODY:
+            self.model_unconditioned.sync_weights()
+        L = _ffi.lib()
+        h = self._handle()
+        un = self.model_unconditioned._h if desc.mode == _ffi.COMPOSE_MULTIBODY else None
+        nbytes = L.cindm_ddpm1d_workspace_bytes(h, self.model._h, un, C.byref(desc), B)
+        if nbytes == 0:
+            raise _ffi.CindmError(L.cindm_last_error().decode() or "invalid composition")
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return h, un, self._ws
+
+    @staticmethod
+    def _f32(t, device=None):
+        return None if t is None else t.detach().to(device=device or t.device, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ reference-named helpers
+    def predict_start_from_noise(self, x_t, t, noise):
+        return self.sqrt_recip_alphas_cumprod[t].view(-1, 1, 1) * x_t - self.sqrt_recipm1_alphas_cumprod[t].view(-1, 1, 1) * noise
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = self.posterior_mean_coef1[t].view(-1, 1, 1) * x_start + self.posterior_mean_coef2[t].view(-1, 1, 1) * x_t
+        return mean, self.posterior_variance[t].view(-1, 1, 1), self.posterior_log_variance_clipped[t].view(-1, 1, 1)
+
+    def q_sample(self, x_start, t, noise=None):
+        """:2399-2406 (a two-table elementwise expression on the state; plumbing, not on the hot loop)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return self.sqrt_alphas_cumprod[t].view(-1, 1, 1) * x_start + self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1) * noise
+
+    @staticmethod
+    def _t_int(t):
+        if torch.is_tensor(t):
+            return int(t.reshape(-1)[0])
+        return int(t)
+
+    @torch.no_grad()
+    def _predict(self, x, cond, t, desc):
+        """(model_mean, x_start, pred_noise) = p_mean_variance(x, cond, t, ...) (:1033-1044) on the device."""
+        if not x.is_cuda:
+            raise _ffi.CindmError("sampling needs ROCm device tensors; there is no CPU execution path")
+        x = self._f32(x)
+        cond_d = self._f32(cond, x.device) if (cond is not None and self.conditioned_steps != 0) else None
+        B = x.shape[0]
+        h, un, ws = self._prepare(desc, B, x.device)
+        mean, x0, eps = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().cindm_ddpm1d_predict(h, self.model._h, un, C.byref(desc), _ffi.ptr(x), _ffi.ptr(cond_d),
+                                                       int(t), None, B, _ffi.ptr(mean), _ffi.ptr(x0), _ffi.ptr(eps),
+                                                       _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+        return mean, x0, eps
+
+    def model_predictions(self, x, cond, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, **kwargs):
+        """:951-1031.  Returns ModelPrediction(pred_noise, pred_x_start) (x_start unclamped unless clip_x_start)."""
+        desc = self._desc_for(x.shape, kwargs.get("compose_mode"), kwargs.get("n_composed", 0),
+                              kwargs.get("compose_start_step", 4), kwargs.get("single_model_step", -1),
+                              kwargs.get("compose_n_bodies", 2), clip=clip_x_start)
+        _, x0, eps = self._predict(x, cond, self._t_int(t), desc)
+        return ModelPrediction(eps, x0)
+
+    def p_mean_variance(self, x, cond, t, x_self_cond=None, clip_denoised=True, **kwargs):
+        """:1033-1044.  Returns (model_mean, posterior_variance, posterior_log_variance, x_start, pred_noise)."""
+        ti = self._t_int(t)
+        desc = self._desc_for(x.shape, kwargs.get("compose_mode"), kwargs.get("n_composed", 0),
+                              kwargs.get("compose_start_step", 4), kwargs.get("single_model_step", -1),
+                              kwargs.get("compose_n_bodies", 2), clip=clip_denoised)
+        mean, x0, eps = self._predict(x, cond, ti, desc)
+        return mean, self.posterior_variance[ti].view(1, 1, 1), self.posterior_log_variance_clipped[ti].view(1, 1, 1), x0, eps
+
+    @torch.no_grad()
+    def gradient(self, x_t, t, n_bodies, scalar_for_gradient=None):
+        """:1857-1926 (4-body branch, t <= 400): pair + unconditioned composition of eps."""
+        if n_bodies != 4 or self.model_unconditioned is None:
+            raise NotImplementedError("gradient(): only n_bodies == 4 with model_unconditioned set is supported")
+        ti = self._t_int(t)
+        if ti > 400:
+            raise NotImplementedError("gradient(): t > 400 dereferences scalar_for_gradient (unreachable for N <= 401)")
+        desc = self._compose_desc(_ffi.COMPOSE_MULTIBODY, 0, 0, self.model.horizon, 4, clip=False)
+        desc.cond_steps = 0                             # x_t here already is cat(cond, x)
+        _, _, eps = self._predict(x_t, None, ti, desc)
+        return eps
+
+    # ------------------------------------------------------------------ one reverse step
+    def _design_shift(self, design_fn, design_guidance, x, x_start, t):
+        """Gradient term of the guided step (:1072-1106 / :1235-1269 / :1468-1512), PyTorch autograd on the
+        user's callable."""
+        eta = self.betas[t] / torch.sqrt(self.alphas_cumprod_prev)[t]
+        g = design_guidance
+
+        def grad_of(z):
+            with torch.enable_grad():
+                zc = z.clone().detach().requires_grad_()
+                return torch.autograd.grad(design_fn(zc), zc)[0]
+
+        if g.startswith("standard"):
+            gd = grad_of(x)
+            if g == "standard" or g.startswith("standard-recurrence"):
+                return gd
+            if g == "standard-alpha" or g.startswith("standard-alpha-recurrence"):
+                return eta * gd
+            raise ValueError(g)
+        if g.startswith("universal-forward"):
+            gd = grad_of(x_start)
+            return gd if "pure" in g else eta * gd
+        if g.startswith("universal-backward"):
+            xc, final = x_start.clone(), None
+            for kk in range(self.backward_steps):
+                gd = grad_of(xc)
+                if kk == 1:
+                    final = gd if "pure" in g else eta * gd
+                xc = xc - gd * self.backward_lr
+            coef = (self.sqrt_alphas_cumprod * self.betas / (torch.sqrt(1 - self.betas) * (1 - self.alphas_cumprod)))[t]
+            return final - coef * (xc - x_start)
+        raise ValueError(g)
+
+    @torch.no_grad()
+    def _guided_step(self, x, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise):
+        """Shared body of p_sample / p_sample_compose_inside / p_sample_compose_outside."""
+        R = int(design_guidance.split("-")[-1]) if "recurrence" in design_guidance else 0
+        x = self._f32(x)
+        logvar = self.posterior_log_variance_clipped[t]
+        x_start = None
+        for r in range(max(R, 1)):
+            mean, x_start, _ = self._predict(x, cond, t, desc)
+            pred = mean
+            if design_fn is not None:
+                pred = mean - self._design_shift(design_fn, design_guidance, x, x_start, t)
+            if initial_state_overwrite is not None:
+                k = initial_state_overwrite.shape[1]
+                pred = torch.cat([initial_state_overwrite.to(pred), pred[:, k:]], 1)
+            if R:
+                ratio = self.alphas_cumprod / self.alphas_cumprod_prev
+                z = recur_noise[r] if recur_noise is not None else torch.randn_like(pred)
+                x = torch.sqrt(ratio)[t] * pred + torch.sqrt(1 - ratio)[t] * z
+        if t > 0:
+            z = noise if noise is not None else torch.randn_like(x)
+            pred = pred + (0.5 * logvar).exp() * z
+        return pred, x_start
+
+    @torch.no_grad()
+    def p_sample(self, x, cond, t: int, x_self_cond=None, clip_denoised=True, design_fn=None,
+                 design_guidance="standard", initial_state_overwrite=None, *, noise=None, recur_noise=None):
+        """:1047-1186.  Returns (x_{t-1}, x_start)."""
+        desc = self._desc_for(x.shape, None, clip=clip_denoised)
+        return self._guided_step(x, cond, int(t), desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise)
+
+    @torch.no_grad()
+    def p_sample_compose_inside(self, x, cond, t: int, x_self_cond=None, clip_denoised=True, design_fn=None,
+                                design_guidance="standard", initial_state_overwrite=None, compose_mode="mean-inside",
+                                n_composed=0, compose_start_step=4, single_model_step=-1, compose_n_bodies=2,
+                                *, noise=None, recur_noise=None):
+        """:1190-1376."""
+        if self.sampling_timesteps != self.num_timesteps and "recurrence" in design_guidance:
+            raise NotImplementedError("DDIM return convention (:1372-1376) is out of scope")
+        assert "inside" not in compose_mode or single_model_step > 0
+        desc = self._desc_for(x.shape, compose_mode, n_composed, compose_start_step, single_model_step, compose_n_bodies,
+                              clip=clip_denoised)
+        return self._guided_step(x, cond, int(t), desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise)
+
+    @torch.no_grad()
+    def p_sample_compose_outside(self, x, cond, t: int, x_self_cond=None, clip_denoised=True, design_fn=None,
+                                 design_guidance="standard", compose_mode="mean", n_composed=0, compose_start_step=4,
+                                 single_model_step=-1, compose_n_bodies=2, initial_state_overwrite=None,
+                                 *, noise=None, recur_noise=None):
+        """:1380-1652."""
+        assert single_model_step > 0
+        desc = self._desc_for(x.shape, compose_mode, n_composed, compose_start_step, single_model_step, compose_n_bodies,
+                              clip=clip_denoised, outside=True)
+        return self._guided_step(x, cond, int(t), desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise)
+
+    # ------------------------------------------------------------------ loops
+    @torch.no_grad()
+    def _run_loop(self, img, cond, desc, t_start, t_end, *, noise_steps, seed, sample_offset, inpaint_cond,
+                  inpaint_noise_steps, use_graph=True):
+        """The unguided reverse loop as one library call (cindm_ddpm1d_sample)."""
+        B = img.shape[0]
+        h, un, ws = self._prepare(desc, B, img.device)
+        cond_d = self._f32(cond, img.device) if (cond is not None and self.conditioned_steps != 0) else None
+        inp = self._f32(inpaint_cond, img.device)
+        with torch.cuda.device(img.device):
+            _ffi.check(_ffi.lib().cindm_ddpm1d_sample(
+                h, self.model._h, un, C.byref(desc), _ffi.ptr(img), _ffi.ptr(cond_d), _ffi.ptr(noise_steps),
+                C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
+                _ffi.ptr(inpaint_noise_steps), t_start, t_end, B, _ffi.ptr(ws), ws.numel(),
+                _ffi.current_stream(img.device), int(use_graph)))
+        return img
+
+    def _init_state(self, shape, device, noise, seed, sample_offset, tag):
+        if noise is not None:
+            return self._f32(noise.init, device).clone()
+        img = torch.empty(shape, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _ffi.check(_ffi.lib().cindm_fill_normal(_ffi.ptr(img), shape[0], shape[1] * shape[2], C.c_uint64(seed),
+                                                    sample_offset, tag, _ffi.current_stream(device)))
+        return img
+
+    @staticmethod
+    def _draw_seed():
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, cond, n_composed=0, compose_start_step=4, compose_n_bodies=2, compose_mode="mean",
+                      design_fn=None, design_guidance="standard", initial_state_overwrite=None, initialization_mode=0,
+                      initialization_img=None, *, noise=None, seed=None, sample_offset=0, use_graph=True, t_stop=0):
+        """:1656-1720.  Build-only keywords: ``noise`` (NoiseTape, explicit draws), ``seed`` /
+        ``sample_offset`` (counter-based generator keyed by global sample index), ``t_stop`` (truncate)."""
+        device = self.betas.device
+        if device.type != "cuda":
+            raise _ffi.CindmError("GaussianDiffusion1D is on the CPU: move it to a ROCm device; there is no CPU execution path")
+        if seed is None and noise is None:
+            seed = self._draw_seed()
+        seed = 0 if seed is None else int(seed)
+        if noise is not None:
+            noise = noise.to(device)
+        B, T1 = shape[0], shape[1]
+        full = (B, T1 + n_composed * compose_start_step, compose_n_bodies * 4)
+        assert compose_start_step < T1
+        init = self._init_state(full, device, noise, seed, sample_offset, self.num_timesteps)
+        if initialization_mode == 0:
+            img = init
+        elif initialization_mode == 1:
+            img = self._f32(initialization_img, device).reshape(full).clone()
+        else:
+            img = self._f32(initialization_img, device).reshape(full) + init
+        inside = "inside" in compose_mode
+        desc = self._desc_for(full, compose_mode, n_composed, compose_start_step, T1, compose_n_bodies, outside=not inside)
+        inpaint = cond if (self.conditioned_steps == 0 and cond is not None) else None
+        fast = design_fn is None and "recurrence" not in design_guidance and initial_state_overwrite is None
+        if fast:
+            return self._run_loop(img, cond, desc, self.num_timesteps - 1, t_stop,
+                                  noise_steps=None if noise is None else noise.step, seed=seed, sample_offset=sample_offset,
+                                  inpaint_cond=inpaint, inpaint_noise_steps=None if noise is None else noise.cond,
+                                  use_graph=use_graph)
+        for t in reversed(range(t_stop, self.num_timesteps)):
+            nz = None if noise is None else noise.step[t]
+            rn = None if (noise is None or noise.recur is None) else noise.recur[t]
+            img, _ = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, nz, rn)
+            if inpaint is not None:
+                zc = noise.cond[t] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
+                img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
+        return img
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, cond=None, is_composing_time=False, n_composed=2, compose_start_step=4,
+               compose_n_bodies=2, compose_mode="mean", design_fn=None, design_guidance="standard",
+               initial_state_overwrite=None, initialization_mode=0, initialization_img=None, **build_kw):
+        """:2330-2376.  ``build_kw``: noise=, seed=, sample_offset=, use_graph=, t_stop= (see p_sample_loop)."""
+        self.is_ddim_sampling = self.sampling_timesteps < self.num_timesteps
+        if self.is_ddim_sampling:
+            raise NotImplementedError("ddim_sample (:1724) is out of this build's scope; set sampling_timesteps == timesteps")
+        return self.p_sample_loop((batch_size, self.image_size, self.channels), cond=cond, n_composed=n_composed,
+                                  compose_start_step=compose_start_step, compose_n_bodies=compose_n_bodies,
+                                  compose_mode=compose_mode, design_fn=design_fn, design_guidance=design_guidance,
+                                  initial_state_overwrite=initial_state_overwrite,
+                                  initialization_mode=initialization_mode, initialization_img=initialization_img,
+                                  **build_kw)
+
+    @torch.no_grad()
+    def sample_compose_multibodies(self, cond, N, L, n_bodies, *, noise=None, seed=None, sample_offset=0,
+                                   use_graph=True, t_stop=0):
+        """:1986-2042 for N <= 401 (ULA branch unreachable): x = cat(cond, noise);
+        for i = N-1..0: x[:, cs:] = p_sample(x[:, cs:], cond, i).  Returns [B, rollout_steps, 4*n_bodies]."""
+        if N > 401:
+            raise NotImplementedError("sample_step_ULA (:2048) is out of scope; use N <= 401")
+        if not cond.is_cuda:
+            raise _ffi.CindmError("sampling needs ROCm device tensors; there is no CPU execution path")
+        device = cond.device
+        if seed is None and noise is None:
+            seed = self._draw_seed()
+        seed = 0 if seed is None else int(seed)
+        if noise is not None:
+            noise = noise.to(device)
+        B = cond.shape[0]
+        shape = (B, self.rollout_steps, cond.shape[2])
+        img = self._init_state(shape, device, noise, seed, sample_offset, self.num_timesteps)
+        desc = self._desc_for(shape, None)
+        return self._run_loop(img, cond, desc, N - 1, t_stop, noise_steps=None if noise is None else noise.step,
+                              seed=seed, sample_offset=sample_offset, inpaint_cond=None, inpaint_noise_steps=None,
+                              use_graph=use_graph)
+
+    # ------------------------------------------------------------------ out of scope
+    def forward(self, *a, **k):
+        raise NotImplementedError("training loss (p_losses, :2438-2501) is out of this build's scope")
+
+    def ddim_sample(self, *a, **k):
+        raise NotImplementedError("ddim_sample (:1724) is out of this build's scope")

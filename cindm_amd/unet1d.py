@@ -1,0 +1,183 @@
+"""TemporalUnet1D on MI355X: the reference's constructor / state_dict / forward surface
+(model/diffusion_1d.py:517-646 of AI4Science-WestlakeU/cindm) over the HIP library.
+
+The module owns ordinary ``nn.Parameter`` tensors under the reference's state-dict key names
+(SURVEY.md Appendix A.3), so reference checkpoints load with ``load_state_dict(strict=True)``
+and ``.to(device)`` / ``.eval()`` / ``.parameters()`` behave as callers expect.  ``forward``
+hands raw device pointers to ``libcindm_hip.so``; there is no PyTorch compute path.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _ffi
+
+
+class _Node(nn.Module):
+    """Anonymous container used to rebuild the reference's dotted key hierarchy."""
+
+
+def _attach(root, dotted, param):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+def sinusoid_table(timesteps, dim):
+    """Row t = SinusoidalPosEmb(dim)(t) (model/diffusion_1d.py:151-158): fp32 frequencies
+    ``exp(arange(half) * -(ln 1e4 / (half-1)))``, fp32 product with the integer timestep, fp32
+    sin/cos -- evaluated once on the host for t = 0..timesteps-1."""
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half) * -emb)
+    arg = torch.arange(timesteps)[:, None] * freq[None, :]
+    return torch.cat((arg.sin(), arg.cos()), dim=-1).contiguous()
+
+
+class TemporalUnet1D(nn.Module):
+    """Drop-in for ``TemporalUnet1D(horizon, transition_dim, cond_dim, dim=64,
+    dim_mults=(1, 2, 4, 8), attention=False)`` (model/diffusion_1d.py:519-527).
+
+    Extra keyword ``timesteps`` (default 1000) sizes the per-timestep bias table that replaces
+    the time-embedding MLP at run time."""
+
+    def __init__(self, horizon, transition_dim, cond_dim, dim=64, dim_mults=(1, 2, 4, 8), attention=False,
+                 *, timesteps=1000):
+        super().__init__()
+        self.horizon = horizon
+        self.transition_dim = transition_dim
+        self.channels = transition_dim
+        self.cond_dim = cond_dim
+        self.dim = dim
+        self.dim_mults = tuple(dim_mults)
+        self.attention = bool(attention)
+        self.timesteps = int(timesteps)
+        L = _ffi.lib()
+        d = _ffi.UnetDesc()
+        d.horizon, d.transition_dim, d.dim, d.n_mults = horizon, transition_dim, dim, len(self.dim_mults)
+        for i, m in enumerate(self.dim_mults):
+            d.dim_mults[i] = m
+        d.attention, d.timesteps = int(self.attention), self.timesteps
+        h = C.c_void_p()
+        _ffi.check(L.cindm_unet1d_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._sig = None
+        self._ws = None
+        self._ws_rows = 0
+        # parameters under the reference's key names, PyTorch-default initialisation
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        manifest = []
+        for i in range(L.cindm_unet1d_num_params(h)):
+            _ffi.check(L.cindm_unet1d_param_info(h, i, name, 256, C.byref(shape), C.byref(nd)))
+            manifest.append((name.value.decode(), tuple(int(shape[j]) for j in range(nd.value))))
+        fan = {}
+        for k, s in manifest:
+            if k.endswith(".weight") and len(s) >= 2:
+                f = s[1] * (s[2] if len(s) > 2 else 1)
+                fan[k[:-7]] = f
+        for k, s in manifest:
+            base = k.rsplit(".", 1)[0]
+            t = torch.empty(s)
+            if k.endswith(".norm.g") or (".block.2." in k and k.endswith(".weight")):
+                t.fill_(1.0)
+            elif ".block.2." in k:
+                t.zero_()
+            else:
+                bound = 1.0 / math.sqrt(fan[base])
+                t.uniform_(-bound, bound)
+            _attach(self, k, nn.Parameter(t))
+        self._manifest = manifest
+
+    def __del__(self):
+        h = self.__dict__.get("_h")
+        if h is not None and h.value:
+            try:
+                _ffi.lib().cindm_unet1d_destroy(h)
+            except Exception:
+                pass
+            self.__dict__["_h"] = None
+
+    # ------------------------------------------------------------------ weights -> library
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def sync_weights(self, force=False):
+        """Copies the current parameter values into the library handle and re-runs its
+        finalisation (weight repack + per-timestep bias table) if anything changed."""
+        sig = self._signature()
+        if not force and sig == self._sig:
+            return
+        L = _ffi.lib()
+        dev = None
+        for k, p in self.named_parameters():
+            if p.dtype != torch.float32:
+                raise TypeError(f"{k}: fp32 parameters required, got {p.dtype}")
+            t = p.detach().contiguous()
+            if t.is_cuda:
+                dev = t.device
+            _ffi.check(L.cindm_unet1d_set_param(self._h, k.encode(), _ffi.ptr(t), t.numel(), int(t.is_cuda)))
+        if dev is None:
+            raise _ffi.CindmError("TemporalUnet1D parameters are on the CPU: move the module to a ROCm device "
+                                  "(.to('cuda')); there is no CPU execution path")
+        tab = sinusoid_table(self.timesteps, self.dim)
+        _ffi.check(L.cindm_unet1d_set_sinusoid_table(self._h, _ffi.ptr(tab), tab.numel()))
+        with torch.cuda.device(dev):
+            _ffi.check(L.cindm_unet1d_finalize(self._h, _ffi.current_stream(dev)))
+        self._sig = sig
+
+    def workspace(self, rows, device):
+        L = _ffi.lib()
+        if self._ws is None or self._ws_rows < rows or self._ws.device != device:
+            nbytes = L.cindm_unet1d_workspace_bytes(self._h, rows)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws_rows = rows
+        return self._ws
+
+    @property
+    def launches_per_forward(self):
+        return _ffi.lib().cindm_unet1d_launches_per_forward(self._h)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, time, cond=None):
+        """x [B, horizon, transition_dim] fp32 on a ROCm device, time [B] (all equal) -> eps [B, horizon, F]
+        (model/diffusion_1d.py:610-646).  ``cond`` is ignored, as in the reference."""
+        if not x.is_cuda:
+            raise _ffi.CindmError("TemporalUnet1D.forward needs a ROCm device tensor; there is no CPU execution path")
+        if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:
+            raise ValueError(f"expected x of shape [B, {self.horizon}, {self.transition_dim}], got {tuple(x.shape)}")
+        if torch.is_tensor(time):
+            lo, hi = torch.aminmax(time)
+            lo, hi = int(lo), int(hi)
+            if lo != hi:
+                raise NotImplementedError("per-row timesteps are not supported on the sampling path (all rows share t)")
+            t = lo
+        else:
+            t = int(time)
+        self.sync_weights()
+        x = x.contiguous().float()
+        out = torch.empty_like(x)
+        ws = self.workspace(x.shape[0], x.device)
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().cindm_unet1d_forward(self._h, _ffi.ptr(x), t, None, _ffi.ptr(out), x.shape[0],
+                                                       _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+        return out
+
+    def tap(self, name, rows):
+        """Intermediate activation of the last forward as [rows, C, L] (the reference's layout)."""
+        shape = (C.c_int64 * 3)()
+        ws = self._ws
+        dst = torch.empty(rows * 1536 * 8, dtype=torch.float32, device=ws.device)
+        with torch.cuda.device(ws.device):
+            _ffi.check(_ffi.lib().cindm_unet1d_tap(self._h, name.encode(), rows, _ffi.ptr(ws), _ffi.ptr(dst),
+                                                   dst.numel(), C.byref(shape), _ffi.current_stream(ws.device)))
+        n = shape[0] * shape[1] * shape[2]
+        return dst[:n].view(shape[0], shape[1], shape[2]).transpose(1, 2).contiguous()

@@ -1,0 +1,193 @@
+/*
+ * cindm_hip.h -- C ABI of libcindm_hip.so: MI355X (gfx950) implementation of CinDM's
+ * compositional diffusion SAMPLING hot path.
+ *
+ * The upstream reference (AI4Science-WestlakeU/cindm) has no native/FFI layer: its callers
+ * construct Python classes and call methods.  Each entry point below therefore cites the
+ * reference *Python* interface (file:line relative to the reference root) whose arithmetic
+ * it replaces; the Python face in cindm_amd/ keeps those class/method signatures and binds
+ * to this library through ctypes (see INTEGRATION.md for the binding stub).
+ *
+ * Conventions
+ *   - every function returns int: 0 = OK, <0 = error; text via cindm_last_error() (thread-local)
+ *   - no C++ types / exceptions cross the boundary; no torch types in any signature
+ *   - the CALLER owns every tensor buffer and the workspace and passes raw DEVICE pointers plus
+ *     explicit sizes; the library owns only opaque handles and its packed copies of the weights
+ *   - all launches are asynchronous on the hipStream_t passed in (as void*); nothing
+ *     synchronises the device except *_finalize
+ *   - a handle is bound to the device current at *_create and is not thread-safe
+ *   - all tensors are fp32, contiguous, layout [batch, time, feature] (the reference's API
+ *     layout, model/diffusion_1d.py:610-614), which is also the channel-last layout the kernels
+ *     use internally
+ */
+#ifndef CINDM_HIP_H
+#define CINDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CINDM_ABI_VERSION 1
+
+typedef struct cindm_unet1d cindm_unet1d;
+typedef struct cindm_ddpm1d cindm_ddpm1d;
+
+/* ------------------------------------------------------------------ misc */
+int cindm_abi_version(void);
+const char* cindm_last_error(void);
+
+/* ------------------------------------------------------------------ TemporalUnet1D
+ * Replaces TemporalUnet1D.__init__/forward, model/diffusion_1d.py:517-646, and the blocks it
+ * is built from: SinusoidalPosEmb :146, Conv1dBlock :197, ResidualTemporalBlock :483,
+ * Residual/PreNorm/LayerNorm/LinearAttentionTemporal :75/:134/:123/:272, Downsample1d :92,
+ * Upsample1d :100. */
+typedef struct {
+    int32_t horizon;          /* TemporalUnet1D(horizon=...)           :521 */
+    int32_t transition_dim;   /* n_bodies * 4 features                 :522 */
+    int32_t dim;              /* base width, 64                        :524 */
+    int32_t n_mults;          /* len(dim_mults), <= 8                  :525 */
+    int32_t dim_mults[8];
+    int32_t attention;        /* 0/1                                   :526 */
+    int32_t timesteps;        /* size of the per-timestep bias table (diffusion T, 1000) */
+} cindm_unet1d_desc;
+
+int  cindm_unet1d_create(const cindm_unet1d_desc* desc, cindm_unet1d** out);
+void cindm_unet1d_destroy(cindm_unet1d* h);
+
+/* State-dict manifest (the reference's nn.Module.state_dict() key names, registration order,
+ * SURVEY.md Appendix A.3): number of tensors; name/shape of tensor idx. */
+int  cindm_unet1d_num_params(const cindm_unet1d* h);
+int  cindm_unet1d_param_info(const cindm_unet1d* h, int idx, char* name, int name_cap,
+                             int64_t shape[4], int* ndim);
+/* Copy one state-dict tensor (PyTorch layout, fp32) into the handle; src may be a host
+ * (on_device=0) or device (on_device=1) pointer.  Replaces load_state_dict for this module. */
+int  cindm_unet1d_set_param(cindm_unet1d* h, const char* key, const float* src, int64_t numel,
+                            int on_device);
+/* Optional: sinusoidal embedding table [timesteps, dim] (host fp32), row t = SinusoidalPosEmb(t)
+ * (:151-158).  If never called, *_finalize computes it with libm expf/sinf/cosf. */
+int  cindm_unet1d_set_sinusoid_table(cindm_unet1d* h, const float* table_host, int64_t numel);
+/* Repack weights to the kernels' [tap][Cin][Cout] layout and precompute, for every timestep,
+ * the time path time_mlp -> per-block Mish->Linear biases (:537-542, :493-497, :509) with the
+ * GEMM kernels.  Synchronises `stream`. */
+int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
+
+size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t rows);
+/* eps[rows,horizon,F] = TemporalUnet1D.forward(x[rows,horizon,F], time=t)   (:610-646).
+ * All rows share timestep t (as every caller on the sampling path does).  If t_dev != NULL the
+ * timestep is read from that device int32 at kernel run time (graph-replayable) and t is ignored. */
+int  cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int32_t* t_dev,
+                          float* eps, int64_t rows, void* ws, size_t ws_bytes, void* stream);
+/* Debug/parity aid: copy a named intermediate activation of the LAST forward (same rows/ws)
+ * to dst (device, capacity dst_cap floats) in channel-last layout [rows, L, C].
+ * Names: reference module paths, e.g. "downs.0.0", "mid_attn", "ups.2.3", "final_conv.0". */
+int  cindm_unet1d_tap(cindm_unet1d* h, const char* name, int64_t rows, void* ws, float* dst,
+                      int64_t dst_cap, int64_t shape[3], void* stream);
+/* Number of kernel launches one forward issues (for DESIGN/bench bookkeeping). */
+int  cindm_unet1d_launches_per_forward(const cindm_unet1d* h);
+
+/* ------------------------------------------------------------------ GaussianDiffusion1D (sampling half)
+ * Replaces GaussianDiffusion1D.model_predictions :951, gradient :1857, p_mean_variance :1033,
+ * q_posterior :938, predict_start_from_noise :914, p_sample :1047, p_sample_compose_inside :1190,
+ * p_sample_compose_outside :1380, p_sample_loop :1656, sample_compose_multibodies :1986,
+ * q_sample :2399 of model/diffusion_1d.py. */
+typedef struct {
+    int32_t timesteps;
+    /* the 13 fp32 buffers registered at :873-910, host pointers, each [timesteps] */
+    const float* betas;
+    const float* alphas_cumprod;
+    const float* alphas_cumprod_prev;
+    const float* sqrt_alphas_cumprod;
+    const float* sqrt_one_minus_alphas_cumprod;
+    const float* log_one_minus_alphas_cumprod;
+    const float* sqrt_recip_alphas_cumprod;
+    const float* sqrt_recipm1_alphas_cumprod;
+    const float* posterior_variance;
+    const float* posterior_log_variance_clipped;
+    const float* posterior_mean_coef1;
+    const float* posterior_mean_coef2;
+    const float* loss_weight;
+} cindm_sched_desc;
+
+int  cindm_ddpm1d_create(const cindm_sched_desc* desc, cindm_ddpm1d** out);
+void cindm_ddpm1d_destroy(cindm_ddpm1d* h);
+
+enum {
+    CINDM_COMPOSE_PLAIN = 0,          /* self.model(x) on the whole state                  :1006 */
+    CINDM_COMPOSE_MEAN_INSIDE = 1,    /* compose_mode "mean-inside"                        :994-996 */
+    CINDM_COMPOSE_SUM_INSIDE = 2,     /* compose_mode "sum-inside"                         :997-999 */
+    CINDM_COMPOSE_MEAN_OUTSIDE = 3,   /* p_sample_compose_outside compose_mode "mean"      :1447-1452 */
+    CINDM_COMPOSE_NOISESUM_OUTSIDE = 4, /* compose_mode "noise_sum"                        :1453-1463 */
+    CINDM_COMPOSE_MULTIBODY = 5       /* gradient(): pair model + unconditioned model      :1865-1926 */
+};
+enum { CINDM_OBJ_PRED_NOISE = 0, CINDM_OBJ_PRED_X0 = 1, CINDM_OBJ_PRED_V = 2 };
+
+typedef struct {
+    int32_t mode;               /* CINDM_COMPOSE_* */
+    int32_t n_windows;          /* n_composed + 1                                          :977 */
+    int32_t compose_start_step; /* window stride                                           :978 */
+    int32_t window;             /* single_model_step = image_size                          :963 */
+    int32_t n_bodies;           /* compose_n_bodies (state feature dim = 4*n_bodies)       :964 */
+    int32_t cond_steps;         /* conditioned_steps: rows of `cond` prepended to x        :956-957 */
+    int32_t objective;          /* CINDM_OBJ_*                                             :1010-1027 */
+    int32_t clip_denoised;      /* x_start.clamp_(-1,1)                                    :1038-1039 */
+    float   uncond_coef;        /* coefficient_unconditioned_grad = 1.4 (MULTIBODY)        :1900 */
+} cindm_compose_desc;
+
+size_t cindm_ddpm1d_workspace_bytes(const cindm_ddpm1d* h, const cindm_unet1d* pair,
+                                    const cindm_unet1d* uncond, const cindm_compose_desc* c, int64_t B);
+
+/* p_mean_variance (:1033-1044) for one timestep: evaluate the composed U-Nets on x
+ * [B, L_tot, 4*n_bodies] (with cond [B, cond_steps, F] prepended when cond_steps > 0), aggregate
+ * eps over windows / body pairs, x0 = predict_start_from_noise, clamp, posterior mean.
+ * Writes mean_out, x0_out, eps_out (each [B, L_tot, F], any may be NULL). */
+int  cindm_ddpm1d_predict(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond,
+                          const cindm_compose_desc* c, const float* x, const float* cond,
+                          int32_t t, const int32_t* t_dev, int64_t B,
+                          float* mean_out, float* x0_out, float* eps_out,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* One full reverse step without design guidance (p_sample :1061-1120 / p_sample_compose_inside
+ * :1209-1283 / p_sample_compose_outside :1406-1523 with design_fn=None):
+ *   x <- mean + exp(0.5*logvar_t) * z   (z = 0 at t == 0), in place.
+ * z = noise[B,L_tot,F] if noise != NULL, else the library's counter-based Gaussian
+ * keyed by (seed, sample_offset + b, t, element).
+ * Inpainting (:1715-1718): if inpaint_cond != NULL, afterwards
+ *   x[:, :inpaint_steps] = q_sample(inpaint_cond, t, inpaint_noise or counter-based noise). */
+int  cindm_ddpm1d_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond,
+                       const cindm_compose_desc* c, float* x, const float* cond,
+                       const float* noise, uint64_t seed, int64_t sample_offset,
+                       const float* inpaint_cond, int32_t inpaint_steps, const float* inpaint_noise,
+                       int32_t t, const int32_t* t_dev, int64_t B, float* x0_out,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* The reverse loop (p_sample_loop :1682-1720 / sample_compose_multibodies :2000-2033 without
+ * design guidance): for t = t_start, t_start-1, ..., t_end: cindm_ddpm1d_step.  One step is
+ * captured into a hipGraph (timestep held in a device counter) and replayed.
+ * noise_steps: NULL (counter-based noise) or device tensor [timesteps, B, L_tot, F] indexed by t;
+ * inpaint_noise_steps likewise [timesteps, B, inpaint_steps, F]. */
+int  cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond,
+                         const cindm_compose_desc* c, float* x, const float* cond,
+                         const float* noise_steps, uint64_t seed, int64_t sample_offset,
+                         const float* inpaint_cond, int32_t inpaint_steps,
+                         const float* inpaint_noise_steps,
+                         int32_t t_start, int32_t t_end, int64_t B,
+                         void* ws, size_t ws_bytes, void* stream, int32_t use_graph);
+
+/* out[n] ~ N(0,1): the library's counter-based Gaussian (Philox4x32-10 + Box-Muller) for the
+ * initial state x_T (:1673), keyed by (seed, sample_offset + b, step_tag, element);
+ * out is [B, per_sample]. */
+int  cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed,
+                       int64_t sample_offset, int32_t step_tag, void* stream);
+
+/* Timing aid for bench.py: elapsed ms of `n_replays` steps measured with HIP events on `stream`
+ * is done by the caller; this returns the number of kernel launches in one step. */
+int  cindm_ddpm1d_launches_per_step(const cindm_ddpm1d* h, const cindm_unet1d* pair,
+                                    const cindm_unet1d* uncond, const cindm_compose_desc* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CINDM_HIP_H */

@@ -1,0 +1,305 @@
+"""GPU (MI355X): the HIP path, called through the C ABI via the Python face, against (1) the committed
+golden vectors captured from the reference and (2) the CPU oracle on seeded inputs, plus
+size-independent properties at BASELINE's full batch sizes.
+
+Tolerances (max-abs error / max-abs value, fp32): north_star allows 1e-4 on whole trajectories.
+We hold single U-Net forwards and single reverse steps to 2e-5 and free-running 1000-step chains
+to 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cindm_amd
+import cindm_oracle as O
+from test_oracle_golden import STEP_CASES, point_objective
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = 2e-5
+TOL_STEP = 2e-5
+TOL_CHAIN = 1e-4
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().float(), torch.as_tensor(b).detach().cpu().float()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def build_unet(device, hz=24, F=8, attention=True, seed=None):
+    seed = (1 if F == 4 else 0) if seed is None else seed
+    sd = O.synth_state_dict(O.unet1d_param_shapes(hz, F, attention=attention), seed=seed)
+    m = cindm_amd.TemporalUnet1D(hz, F, False, attention=attention)
+    m.load_state_dict(sd, strict=True)
+    return m.to(device), sd
+
+
+@pytest.fixture(scope="module")
+def unet8(device):
+    return build_unet(device)
+
+
+@pytest.fixture(scope="module")
+def unet4(device):
+    return build_unet(device, F=4)
+
+
+@pytest.fixture(scope="module")
+def diff8(device, unet8):
+    return cindm_amd.GaussianDiffusion1D(unet8[0], image_size=24, conditioned_steps=0, timesteps=1000,
+                                         sampling_timesteps=1000, loss_type="l1").to(device)
+
+
+@pytest.fixture(scope="module")
+def diff_mb(device, unet8, unet4):
+    d = cindm_amd.GaussianDiffusion1D(unet8[0], image_size=20, conditioned_steps=4, timesteps=1000,
+                                      sampling_timesteps=1000, loss_type="l1").to(device)
+    d.model_unconditioned = unet4[0]
+    return d
+
+
+def test_native_library_is_loaded():
+    import ctypes
+    L = cindm_amd._ffi.lib()
+    assert isinstance(L, ctypes.CDLL) and "libcindm_hip.so" in L._name
+    maps = open("/proc/self/maps").read()
+    assert "libcindm_hip.so" in maps
+
+
+# ------------------------------------------------------------------ U-Net forward
+def test_unet_forward_golden(gold_dir, device, unet8):
+    g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
+    m, _ = unet8
+    x = torch.from_numpy(g["x"]).to(device)
+    for t in (0, 1, 10, 500, 999):
+        out = m(x, torch.full((4,), t, device=device))
+        assert rel(out, g[f"eps_t{t}"]) < TOL_FWD, t
+
+
+def test_unet_blocks_golden(gold_dir, device, unet8):
+    """Per-block parity: every tapped module output of the reference (B=2, t=500)."""
+    g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
+    m, _ = unet8
+    x = torch.from_numpy(g["x"][:2]).to(device)
+    m(x, torch.full((2,), 500, device=device))
+    for k in ("downs.0.0", "downs.0.1", "downs.0.2", "downs.0.3", "downs.1.0", "downs.2.1", "downs.3.2", "mid_block1",
+              "mid_attn", "mid_block2", "ups.0.0", "ups.0.3", "ups.1.1", "ups.2.2", "ups.2.3"):
+        assert rel(m.tap(k, 2), g["tap." + k]) < TOL_FWD, k
+
+
+@pytest.mark.parametrize("hz,F,att,key,xkey", [(24, 4, True, "eps_f4_t321", "x_f4"), (24, 16, True, "eps_f16_t321", "x_f16"),
+                                                 (24, 8, False, "eps_noattn_t500", None), (44, 8, True, "eps_h44_t500", "x_h44"),
+                                                 (8, 8, True, "eps_h8_t500", "x_h8")])
+def test_unet_variants_golden(gold_dir, device, hz, F, att, key, xkey):
+    g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
+    m, _ = build_unet(device, hz, F, att)
+    x = torch.from_numpy(g[xkey] if xkey else g["x"][:2]).to(device)
+    t = int(key.rsplit("_t", 1)[1])
+    out = m(x, torch.full((x.shape[0],), t, device=device))
+    assert rel(out, g[key]) < TOL_FWD
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 47, 50])
+def test_unet_ragged_batches_vs_oracle(device, unet8, B):
+    """Batches that do not fill the last tile, against the oracle on the same seeded input."""
+    m, sd = unet8
+    x = torch.randn((B, 24, 8), generator=torch.Generator().manual_seed(100 + B))
+    ref = O.unet1d_forward(sd, x, torch.full((B,), 77, dtype=torch.long))
+    out = m(x.to(device), torch.full((B,), 77, device=device))
+    assert rel(out, ref) < TOL_FWD
+
+
+def test_unet_rows_are_independent(device, unet8):
+    """A sample's result does not depend on its batch mates (per-sample ops only; SURVEY 8c identity 5)."""
+    m, _ = unet8
+    x = torch.randn((256, 24, 8), generator=torch.Generator().manual_seed(5)).to(device)
+    tt = torch.full((256,), 400, device=device)
+    full = m(x, tt)
+    part = m(x[37:40].contiguous(), tt[:3])
+    assert torch.equal(full[37:40], part)
+    assert torch.equal(full, m(x, tt))            # and launches are deterministic
+
+
+def test_time_tensor_contract(device, unet8):
+    m, _ = unet8
+    x = torch.zeros((2, 24, 8), device=device)
+    with pytest.raises(NotImplementedError):
+        m(x, torch.tensor([1, 2], device=device))
+    with pytest.raises(ValueError):
+        m(torch.zeros((2, 23, 8), device=device), torch.zeros(2, device=device, dtype=torch.long))
+    with pytest.raises(cindm_amd.CindmError):
+        m(x, torch.full((2,), 1000, device=device))
+
+
+# ------------------------------------------------------------------ single reverse steps
+@pytest.mark.parametrize("tag", sorted(STEP_CASES))
+def test_single_steps_golden(gold_dir, device, diff8, tag):
+    g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
+    kind, kw, ts = STEP_CASES[tag]
+    fn = diff8.p_sample_compose_inside if kind == "inside" else diff8.p_sample_compose_outside
+    for t in ts:
+        x = torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device)
+        nz = torch.from_numpy(g[f"{tag}.t{t}.noise"]).to(device)
+        out, x0 = fn(x, None, t, noise=nz, **kw)
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (tag, t)
+
+
+def test_guided_steps_golden(gold_dir, device, diff8):
+    g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
+    kwi = dict(compose_mode="mean-inside", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    for guid in ("standard", "standard-alpha", "standard-recurrence-3", "universal-forward", "universal-backward"):
+        for t in (500, 0):
+            tag = "design_" + guid
+            x = torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device)
+            nz = torch.from_numpy(g[f"{tag}.t{t}.noise"]).to(device)
+            rn = torch.from_numpy(g[f"{tag}.t{t}.recur"]).to(device) if f"{tag}.t{t}.recur" in g else None
+            out, x0 = diff8.p_sample_compose_inside(x, None, t, design_fn=point_objective, design_guidance=guid,
+                                                    noise=nz, recur_noise=rn, **kwi)
+            assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (guid, t)
+    kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    tag, t = "recur2_outside_iso", 500
+    out, _ = diff8.p_sample_compose_outside(torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device), None, t,
+                                            design_guidance="standard-recurrence-2",
+                                            initial_state_overwrite=torch.from_numpy(g["iso"]).to(device),
+                                            noise=torch.from_numpy(g[f"{tag}.t{t}.noise"]).to(device),
+                                            recur_noise=torch.from_numpy(g[f"{tag}.t{t}.recur"]).to(device), **kw)
+    assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP
+
+
+def test_multibody_steps_golden(gold_dir, device, diff_mb):
+    g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
+    cond = torch.from_numpy(g["cfg4_script.cond"]).to(device)
+    for t in (399, 200, 1, 0):
+        out, x0 = diff_mb.p_sample(torch.from_numpy(g[f"cfg4_script.t{t}.x"]).to(device), cond, t,
+                                   noise=torch.from_numpy(g[f"cfg4_script.t{t}.noise"]).to(device))
+        assert rel(out, g[f"cfg4_script.t{t}.out"]) < TOL_STEP and rel(x0, g[f"cfg4_script.t{t}.x0"]) < TOL_STEP, t
+    # gradient() alone against the oracle
+    x = torch.randn((3, 24, 16), generator=torch.Generator().manual_seed(9))
+    od = O.Diffusion1D(O.synth_state_dict(O.unet1d_param_shapes(24, 8), 0), image_size=20, conditioned_steps=4,
+                       sd_uncond=O.synth_state_dict(O.unet1d_param_shapes(24, 4), 1))
+    assert rel(diff_mb.gradient(x.to(device), 123, 4), O.gradient_4body(od, x, 123)) < TOL_STEP
+
+
+def test_step_identities(device, diff8):
+    """outside(mean, n_composed=0, nb=2) == inside(mean-inside, n_composed=0) == plain p_sample, bitwise."""
+    g = torch.Generator().manual_seed(3)
+    x, nz = torch.randn((6, 24, 8), generator=g).to(device), torch.randn((6, 24, 8), generator=g).to(device)
+    kw = dict(n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    a, _ = diff8.p_sample_compose_outside(x, None, 700, compose_mode="mean", noise=nz, **kw)
+    b, _ = diff8.p_sample_compose_inside(x, None, 700, compose_mode="mean-inside", noise=nz, **kw)
+    c, _ = diff8.p_sample(x, None, 700, noise=nz)
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+# ------------------------------------------------------------------ chains
+def _tape(seed, shape, T, cond_shape=None):
+    t = O.NoiseTape.make(seed, shape, T, cond_shape=cond_shape)
+    return cindm_amd.NoiseTape(t.init, t.step, None, t.cond)
+
+
+def test_chain_cfg1(gold_dir, device, diff8):
+    """BASELINE config 1: nbody-2, single model, batch 4, 1000 DDPM steps; graph replay == eager launches."""
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    tape = _tape(1234, (4, 24, 8), 1000)
+    a = diff8.sample(batch_size=4, cond=None, n_composed=0, compose_n_bodies=2, noise=tape, use_graph=True)
+    b = diff8.sample(batch_size=4, cond=None, n_composed=0, compose_n_bodies=2, noise=tape, use_graph=False)
+    assert torch.equal(a, b)
+    assert rel(a, g["cfg1.final"]) < TOL_CHAIN
+    # time-localised: stop at the stored checkpoints
+    ts = list(g["cfg1.ckpt_t"])
+    for t in (900, 500, 100):
+        part = diff8.sample(batch_size=4, n_composed=0, compose_n_bodies=2, noise=tape, t_stop=t)
+        assert rel(part, g["cfg1.ckpt"][ts.index(t)]) < TOL_CHAIN, t
+
+
+def test_chain_cfg3_time_composition(gold_dir, device, diff8):
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    out = diff8.sample(batch_size=2, n_composed=2, compose_start_step=16, compose_mode="mean-inside",
+                       noise=_tape(1235, (2, 56, 8), 1000))
+    assert tuple(out.shape) == (2, 56, 8) and rel(out, g["cfg3.final"]) < TOL_CHAIN
+
+
+def test_chain_default_sample(gold_dir, device, diff8):
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    out = diff8.sample(batch_size=2, noise=_tape(1236, (2, 32, 8), 1000))     # n_composed=2, cs=4, "mean"
+    assert tuple(out.shape) == (2, 32, 8) and rel(out, g["default.final"]) < TOL_CHAIN
+
+
+def test_chain_inpainting(gold_dir, device, diff8):
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    cond = torch.from_numpy(g["inpaint.cond"]).to(device)
+    out = diff8.sample(batch_size=2, cond=cond, n_composed=0, noise=_tape(1237, (2, 24, 8), 1000, cond_shape=(2, 4, 8)))
+    assert rel(out, g["inpaint.final"]) < TOL_CHAIN
+
+
+def test_chain_cfg4_script_multibodies(gold_dir, device, diff_mb):
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    cond = torch.from_numpy(np.load(os.path.join(gold_dir, "steps_1d.npz"))["cfg4_script.cond"]).to(device)
+    out = diff_mb.sample_compose_multibodies(cond, 400, 0, 4, noise=_tape(1238, (2, 20, 16), 400))
+    assert tuple(out.shape) == (2, 20, 16) and rel(out, g["cfg4_script.final"]) < TOL_CHAIN
+
+
+def test_chain_cfg4_paper_four_bodies(gold_dir, device, diff8):
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    out = diff8.sample(batch_size=1, n_composed=0, compose_n_bodies=4, compose_mode="mean-inside",
+                       noise=_tape(1239, (1, 24, 16), 1000))
+    assert tuple(out.shape) == (1, 24, 16) and rel(out, g["cfg4_paper.final"]) < TOL_CHAIN
+
+
+def test_guided_loop_matches_oracle(device, diff8, unet8):
+    """design_fn path of p_sample_loop (standard-recurrence-2), last 12 steps, against the oracle."""
+    _, sd = unet8
+    od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+    T0 = 988
+    gen = torch.Generator().manual_seed(44)
+    tape = O.NoiseTape(torch.randn((2, 24, 8), generator=gen) * 0.5, torch.randn((1000, 2, 24, 8), generator=gen),
+                       torch.randn((1000, 2, 2, 24, 8), generator=gen))
+    ref = O.sample(od, 2, tape, n_composed=0, compose_mode="mean-inside", design_fn=point_objective,
+                   design_guidance="standard-recurrence-2", t_stop=T0)
+    nt = cindm_amd.NoiseTape(tape.init, tape.step, tape.recur)
+    out = diff8.sample(batch_size=2, n_composed=0, compose_mode="mean-inside", design_fn=point_objective,
+                       design_guidance="standard-recurrence-2", noise=nt, t_stop=T0)
+    assert rel(out, ref) < TOL_CHAIN
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_batch256_properties(device, diff8):
+    """BASELINE config 2 (batch 256): determinism, independence from the batch partition (the property the
+    multi-GPU sharding relies on), boundedness."""
+    a = diff8.sample(batch_size=256, n_composed=0, compose_n_bodies=2, seed=77)
+    b = diff8.sample(batch_size=256, n_composed=0, compose_n_bodies=2, seed=77)
+    assert torch.equal(a, b)
+    part = diff8.sample(batch_size=64, n_composed=0, compose_n_bodies=2, seed=77, sample_offset=64)
+    assert torch.equal(a[64:128], part)
+    assert bool(torch.isfinite(a).all()) and float(a.abs().max()) <= 1.0 + 1e-5     # last step: clamp(x0), sigma_0 * 0
+    c = diff8.sample(batch_size=256, n_composed=0, compose_n_bodies=2, seed=78)
+    assert not torch.equal(a, c)
+
+
+def test_full_size_cfg3_window_consistency(device, diff8):
+    """Config 3 shape at batch 256 for a short tail of the chain: finite, right shape, and the composed step
+    equals the plain step where only one window covers a position and nb == 2."""
+    x = torch.randn((256, 56, 8), generator=torch.Generator().manual_seed(8)).to(device)
+    kw3 = dict(compose_mode="mean-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2)
+    _, x0 = diff8.p_sample_compose_inside(x, None, 300, noise=torch.zeros_like(x), **kw3)
+    _, x0_first = diff8.p_sample(x[:, :24].contiguous(), None, 300, noise=torch.zeros((256, 24, 8), device=device))
+    assert torch.equal(x0[:, :16], x0_first[:, :16])      # positions 0..15 are covered by window 0 only
+    assert bool(torch.isfinite(x0).all())
+
+
+def test_counter_noise(device):
+    """The in-kernel generator is a pure function of (seed, global sample, step, element) and looks N(0,1)."""
+    import ctypes as C
+    L = cindm_amd._ffi.lib()
+    a = torch.empty((1024, 192), device=device)
+    b = torch.empty((512, 192), device=device)
+    s = cindm_amd._ffi.current_stream(device)
+    cindm_amd._ffi.check(L.cindm_fill_normal(cindm_amd._ffi.ptr(a), 1024, 192, C.c_uint64(5), 0, 1000, s))
+    cindm_amd._ffi.check(L.cindm_fill_normal(cindm_amd._ffi.ptr(b), 512, 192, C.c_uint64(5), 512, 1000, s))
+    assert torch.equal(a[512:], b)
+    assert abs(float(a.mean())) < 0.01 and abs(float(a.var()) - 1.0) < 0.02
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.15
+    assert float(a.abs().max()) < 7.0
+    flat = a.flatten()
+    assert abs(float((flat[:-1] * flat[1:]).mean())) < 0.01

@@ -1,0 +1,148 @@
+"""CPU: host-side logic of the product -- the C-ABI library loads and exports every symbol the header
+declares, the state-dict contract, schedule tables, error behaviour without a device, sharding math.
+No kernel is launched here (there is no GPU in the build container)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cindm_amd
+from cindm_amd import _ffi, dist as cdist
+import cindm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cindm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cindm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = _ffi.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/cindm_hip.h but not exported"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    assert L.cindm_abi_version() == 1
+
+
+def test_descriptor_structs_match_header_layout():
+    assert C.sizeof(_ffi.UnetDesc) == 4 * (4 + 8 + 2)
+    assert C.sizeof(_ffi.ComposeDesc) == 9 * 4
+    assert C.sizeof(_ffi.SchedDesc) == 8 + 13 * 8
+
+
+@pytest.mark.parametrize("hz,F,att", [(24, 8, True), (24, 4, True), (24, 16, True), (44, 8, True), (8, 8, True), (6, 8, True), (24, 8, False)])
+def test_state_dict_contract(gold_dir, hz, F, att):
+    man = json.load(open(os.path.join(gold_dir, "manifest_1d.json")))
+    key = f"unet1d_h{hz}_f{F}" + ("" if att else "_noattn")
+    m = cindm_amd.TemporalUnet1D(hz, F, False, attention=att)
+    got = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+    assert got == [(k, v) for k, v in man[key].items()]
+    # strict load of generator-defined weights, and round trip
+    sd = O.synth_state_dict(O.unet1d_param_shapes(hz, F, attention=att))
+    m.load_state_dict(sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+    assert m.horizon == hz and m.transition_dim == F and m.channels == F
+    assert next(iter(m.parameters())).dtype == torch.float32
+
+
+def test_state_dict_rejects_foreign_keys():
+    m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
+    sd = dict(m.state_dict())
+    sd["bogus.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd, strict=True)
+    L = _ffi.lib()
+    z = torch.zeros(4)
+    assert L.cindm_unet1d_set_param(m._h, b"bogus.weight", _ffi.ptr(z), 4, 0) != 0
+    assert b"unexpected key" in L.cindm_last_error()
+    assert L.cindm_unet1d_set_param(m._h, b"time_mlp.1.bias", _ffi.ptr(z), 4, 0) != 0
+    assert b"size mismatch" in L.cindm_last_error()
+
+
+def test_constructor_validation():
+    L = _ffi.lib()
+    for kw in (dict(horizon=25), dict(horizon=64), dict(transition_dim=6), dict(dim=48)):
+        args = dict(horizon=24, transition_dim=8, dim=64)
+        args.update(kw)
+        with pytest.raises(_ffi.CindmError):
+            cindm_amd.TemporalUnet1D(args["horizon"], args["transition_dim"], False, dim=args["dim"], attention=True)
+    assert L.cindm_last_error()
+
+
+def test_diffusion_buffers_and_schedule(gold_dir):
+    g = np.load(os.path.join(gold_dir, "schedule.npz"))
+    m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
+    for kind in ("cosine", "linear"):
+        d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000,
+                                          loss_type="l1", beta_schedule=kind)
+        names = [k for k in d.state_dict() if not k.startswith("model.")]
+        assert names == list(O.SCHEDULE_BUFFERS)
+        for k in names:
+            assert np.array_equal(getattr(d, k).numpy(), g[f"{kind}.{k}"]), (kind, k)
+    tab = cindm_amd.make_schedule("sigmoid", 1000)
+    for k in O.SCHEDULE_BUFFERS:
+        assert np.array_equal(tab[k].numpy(), g[f"sigmoid.{k}"]), k
+    assert [k for k in d.state_dict() if k.startswith("model.")] == ["model." + k for k in m.state_dict()]
+    assert d.channels == 8 and d.image_size == 24 and d.rollout_steps == 24 and d.num_timesteps == 1000
+    assert d.sampling_timesteps == 1000 and not d.is_ddim_sampling
+
+
+def test_no_cpu_fallback():
+    m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
+    with pytest.raises(_ffi.CindmError, match="no CPU execution path"):
+        m(torch.zeros(2, 24, 8), torch.zeros(2, dtype=torch.long))
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0)
+    with pytest.raises(_ffi.CindmError, match="no CPU execution path"):
+        d.sample(batch_size=2, n_composed=0)
+    with pytest.raises(_ffi.CindmError, match="no CPU execution path"):
+        d.p_sample_compose_inside(torch.zeros(2, 24, 8), None, 5, single_model_step=24)
+    with pytest.raises(NotImplementedError):
+        d(torch.zeros(2, 24, 8))
+    d.sampling_timesteps = 250
+    with pytest.raises(NotImplementedError):
+        d.sample(batch_size=2)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "cindm_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no CPU", ""), fn
+    for fn in os.listdir(os.path.join(pkg, "csrc")):
+        assert "oracle" not in open(os.path.join(pkg, "csrc", fn)).read()
+
+
+def test_compose_descriptors():
+    m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0)
+    c = d._desc_for((4, 56, 8), "mean-inside", 2, 16, 24, 2)
+    assert (c.mode, c.n_windows, c.compose_start_step, c.window, c.n_bodies) == (1, 3, 16, 24, 2)
+    c = d._desc_for((4, 32, 8), "mean", 2, 4, 24, 2, outside=True)
+    assert (c.mode, c.n_windows) == (3, 3)
+    c = d._desc_for((4, 24, 8), "mean-inside", 0, 4, 24, 2)
+    assert c.n_windows == 1
+    c = d._desc_for((4, 24, 8), None)
+    assert c.mode == 0 and c.n_bodies == 2
+    with pytest.raises(ValueError):
+        d._desc_for((4, 24, 8), "median-inside", 0, 4, 24, 2)
+    d.model_unconditioned = cindm_amd.TemporalUnet1D(24, 4, False, attention=True)
+    c = d._desc_for((4, 20, 16), None)
+    assert c.mode == 5 and c.n_bodies == 4 and abs(c.uncond_coef - 1.4) < 1e-7
+
+
+def test_shard_bounds():
+    for total in (1, 7, 256, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [cdist.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a, b), (c, d) in zip(spans[:-1], spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

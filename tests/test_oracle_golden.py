@@ -1,0 +1,173 @@
+"""CPU: the oracle (oracle/cindm_oracle.py) against the committed golden vectors that were captured
+from the reference itself (oracle/make_golden.py).  This is what keeps the oracle pinned when the
+reference tree is not present (GPU box, CI)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cindm_oracle as O
+
+TOL = 2e-6     # oracle vs reference-captured outputs: same torch ops, same order -> ~bitwise
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def sd8():
+    return O.synth_state_dict(O.unet1d_param_shapes(24, 8), seed=0)
+
+
+@pytest.fixture(scope="module")
+def sd4():
+    return O.synth_state_dict(O.unet1d_param_shapes(24, 4), seed=1)
+
+
+def test_schedule_tables(gold_dir):
+    g = np.load(os.path.join(gold_dir, "schedule.npz"))
+    for kind in ("cosine", "linear", "sigmoid"):
+        tab = O.make_schedule(kind, 1000)
+        for k in O.SCHEDULE_BUFFERS:
+            assert np.array_equal(tab[k].numpy(), g[f"{kind}.{k}"]), (kind, k)
+    # documented landmarks
+    b = O.make_schedule("cosine", 1000)["betas"]
+    assert abs(float(b[0]) - 4.1284e-5) < 1e-8 and float(b[-1]) == pytest.approx(0.999)
+    assert float(O.make_schedule("cosine", 1000)["posterior_log_variance_clipped"][0]) == pytest.approx(-46.0517, abs=1e-3)
+
+
+def test_manifest(gold_dir):
+    man = json.load(open(os.path.join(gold_dir, "manifest_1d.json")))
+    for key, ref in man.items():
+        parts = key.split("_")
+        hz, F = int(parts[1][1:]), int(parts[2][1:])
+        mine = O.unet1d_param_shapes(hz, F, attention=not key.endswith("noattn"))
+        assert [(k, list(v)) for k, v in mine.items()] == [(k, v) for k, v in ref.items()], key
+    n = sum(int(np.prod(v)) for v in man["unet1d_h24_f8"].values())
+    assert n == 20762824 and len(man["unet1d_h24_f8"]) == 234
+
+
+def test_unet_forward(gold_dir, sd8, sd4):
+    g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
+    x = torch.from_numpy(g["x"])
+    for t in (0, 1, 10, 500, 999):
+        out = O.unet1d_forward(sd8, x, torch.full((4,), t, dtype=torch.long))
+        assert rel(out, g[f"eps_t{t}"]) < TOL, t
+    taps = {}
+    tt = torch.full((2,), 500, dtype=torch.long)
+    O.unet1d_forward(sd8, x[:2], tt, taps=taps)
+    for k in ("downs.0.0", "downs.0.1", "downs.0.2", "downs.0.3", "mid_block1", "mid_attn", "mid_block2", "ups.0.0",
+              "ups.0.3", "ups.1.1", "ups.2.2", "ups.2.3"):
+        assert rel(taps[k], g["tap." + k]) < TOL, k
+    out = O.unet1d_forward(sd4, torch.from_numpy(g["x_f4"]), torch.full((2,), 321, dtype=torch.long))
+    assert rel(out, g["eps_f4_t321"]) < TOL
+    sd16 = O.synth_state_dict(O.unet1d_param_shapes(24, 16), seed=0)
+    out = O.unet1d_forward(sd16, torch.from_numpy(g["x_f16"]), torch.full((2,), 321, dtype=torch.long))
+    assert rel(out, g["eps_f16_t321"]) < TOL
+    sdn = O.synth_state_dict(O.unet1d_param_shapes(24, 8, attention=False), seed=0)
+    assert rel(O.unet1d_forward(sdn, x[:2], tt), g["eps_noattn_t500"]) < TOL
+    for hz in (44, 8):
+        sdh = O.synth_state_dict(O.unet1d_param_shapes(hz, 8), seed=0)
+        assert rel(O.unet1d_forward(sdh, torch.from_numpy(g[f"x_h{hz}"]), tt), g[f"eps_h{hz}_t500"]) < TOL, hz
+
+
+STEP_CASES = {
+    "cfg2_outside_mean": ("outside", dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2), (999, 500, 1, 0)),
+    "cfg2_inside": ("inside", dict(compose_mode="mean-inside", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2), (500,)),
+    "cfg3_mean-inside": ("inside", dict(compose_mode="mean-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2), (999, 500, 1, 0)),
+    "cfg3_sum-inside": ("inside", dict(compose_mode="sum-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2), (999, 500, 1, 0)),
+    "cfg3_outside_mean": ("outside", dict(compose_mode="mean", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2), (999, 500, 0)),
+    "cfg3_outside_noise_sum": ("outside", dict(compose_mode="noise_sum", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2), (999, 500, 0)),
+    "default_outside_mean": ("outside", dict(compose_mode="mean", n_composed=2, compose_start_step=4, single_model_step=24, compose_n_bodies=2), (500, 1)),
+    "cfg4_paper_nb4": ("inside", dict(compose_mode="mean-inside", n_composed=0, compose_start_step=10, single_model_step=24, compose_n_bodies=4), (999, 500, 0)),
+    "nb4_w2": ("inside", dict(compose_mode="mean-inside", n_composed=1, compose_start_step=10, single_model_step=24, compose_n_bodies=4), (999, 500, 0)),
+    "nb4_outside_mean": ("outside", dict(compose_mode="mean", n_composed=0, compose_start_step=10, single_model_step=24, compose_n_bodies=4), (500,)),
+}
+
+
+def point_objective(x):
+    target = torch.tensor([0.25, -0.5], device=x.device)
+    return ((x[:, -1, 0:2] - target) ** 2).sum()
+
+
+@pytest.mark.parametrize("tag", sorted(STEP_CASES))
+def test_single_steps(gold_dir, sd8, tag):
+    g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
+    d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0)
+    kind, kw, ts = STEP_CASES[tag]
+    fn = O.p_sample_compose_inside if kind == "inside" else O.p_sample_compose_outside
+    for t in ts:
+        x = torch.from_numpy(g[f"{tag}.t{t}.x"])
+        nz = torch.from_numpy(g[f"{tag}.t{t}.noise"])
+        out, x0 = fn(d, x, None, t, nz, **kw)
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL, (tag, t)
+
+
+def test_guided_steps(gold_dir, sd8):
+    g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
+    d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0)
+    kwi = dict(compose_mode="mean-inside", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    for guid in ("standard", "standard-alpha", "standard-recurrence-3", "universal-forward", "universal-backward"):
+        for t in (500, 0):
+            tag = "design_" + guid
+            x = torch.from_numpy(g[f"{tag}.t{t}.x"])
+            nz = torch.from_numpy(g[f"{tag}.t{t}.noise"])
+            rn = torch.from_numpy(g[f"{tag}.t{t}.recur"]) if f"{tag}.t{t}.recur" in g else None
+            out, x0 = O.p_sample_compose_inside(d, x, None, t, nz, design_fn=point_objective, design_guidance=guid,
+                                                recur_noise=rn, **kwi)
+            assert rel(out, g[f"{tag}.t{t}.out"]) < TOL and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL, (guid, t)
+    kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    tag, t = "recur2_outside_iso", 500
+    out, x0 = O.p_sample_compose_outside(d, torch.from_numpy(g[f"{tag}.t{t}.x"]), None, t, torch.from_numpy(g[f"{tag}.t{t}.noise"]),
+                                         design_guidance="standard-recurrence-2", initial_state_overwrite=torch.from_numpy(g["iso"]),
+                                         recur_noise=torch.from_numpy(g[f"{tag}.t{t}.recur"]), **kw)
+    assert rel(out, g[f"{tag}.t{t}.out"]) < TOL
+
+
+def test_multibody_steps(gold_dir, sd8, sd4):
+    g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
+    d = O.Diffusion1D(sd8, image_size=20, conditioned_steps=4, sd_uncond=sd4)
+    cond = torch.from_numpy(g["cfg4_script.cond"])
+    for t in (399, 200, 1, 0):
+        out, x0 = O.p_sample(d, torch.from_numpy(g[f"cfg4_script.t{t}.x"]), cond, t, torch.from_numpy(g[f"cfg4_script.t{t}.noise"]))
+        assert rel(out, g[f"cfg4_script.t{t}.out"]) < TOL and rel(x0, g[f"cfg4_script.t{t}.x0"]) < TOL, t
+
+
+def test_identities(sd8):
+    """Oracle-verified identities of the reference: outside(mean, n_composed=0, nb=2) ==
+    inside(mean-inside, n_composed=0) == plain p_sample, bitwise; output shapes of sample()."""
+    d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0)
+    g = torch.Generator().manual_seed(3)
+    x, nz = torch.randn((2, 24, 8), generator=g), torch.randn((2, 24, 8), generator=g)
+    kw = dict(n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    a, _ = O.p_sample_compose_outside(d, x, None, 700, nz, compose_mode="mean", **kw)
+    b, _ = O.p_sample_compose_inside(d, x, None, 700, nz, compose_mode="mean-inside", **kw)
+    c, _ = O.p_sample(d, x, None, 700, nz)
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_chain_tails(gold_dir, sd8, sd4):
+    """Free-running chains: resume the oracle from the stored checkpoint at t=100 and reproduce the
+    reference-captured final state (the full 1000-step runs were checked in make_golden.py)."""
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0)
+
+    def ck(tag, t):
+        ts = list(g[tag + ".ckpt_t"])
+        return torch.from_numpy(g[tag + ".ckpt"][ts.index(t)])
+
+    tape = O.NoiseTape.make(1234, (4, 24, 8), 1000)
+    out = O.sample(d, 4, tape, n_composed=0, compose_n_bodies=2, resume=(100, ck("cfg1", 100)))
+    assert rel(out, g["cfg1.final"]) < TOL
+    tape = O.NoiseTape.make(1235, (2, 56, 8), 1000)
+    out = O.sample(d, 2, tape, n_composed=2, compose_start_step=16, compose_mode="mean-inside", resume=(100, ck("cfg3", 100)))
+    assert rel(out, g["cfg3.final"]) < TOL
+    d4 = O.Diffusion1D(sd8, image_size=20, conditioned_steps=4, sd_uncond=sd4)
+    cond4 = torch.from_numpy(np.load(os.path.join(gold_dir, "steps_1d.npz"))["cfg4_script.cond"])
+    tape = O.NoiseTape.make(1238, (2, 20, 16), 400)
+    out = O.sample_compose_multibodies(d4, cond4, 400, tape, resume=(100, ck("cfg4_script", 100)))
+    assert rel(out, g["cfg4_script.final"]) < TOL
