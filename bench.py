@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- design samples/sec of the composed DDPM sampler on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: a complete 1000-step DDPM reverse chain for a
+batch of 256 nbody-2 designs through TemporalUnet1D(dim=64, horizon=24) (BASELINE config 2), with
+synthetic generator-defined weights, x_T and per-step noise from the in-kernel counter-based generator.
+Inputs (weights, state) are resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank samples its own 256 designs
+(weak scaling, no communication inside the loop) and the final designs are all-gathered over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL = 160_382_976        # per U-Net row, attention=True, F=8
+PEAK_F32_MFMA_TF = 157.3           # /opt/skills/guides/MI355X_MICROARCH.md
+BATCH = 256
+TIMESTEPS = 1000
+
+
+def synth_weights(hz, F):
+    """Generator-defined random-init weights shared with the CPU baseline (oracle/ is test infrastructure;
+    here it only supplies the weight generator and, in cpu_baseline(), the timed CPU port)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cindm_oracle as O
+    return O.synth_state_dict(O.unet1d_param_shapes(hz, F, attention=True), seed=0)
+
+
+def cpu_baseline(sd, budget_s=20.0):
+    """The oracle (a torch-CPU port of the reference's path) timed on this box's host cores on a bounded
+    sample of the same workload: reverse steps of the batch-256 config, extrapolated to 1000 steps."""
+    import cindm_oracle as O
+    d = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((BATCH, 24, 8), generator=g)
+    nz = torch.randn((BATCH, 24, 8), generator=g)
+    kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    with torch.no_grad():
+        O.p_sample_compose_outside(d, x, None, 500, nz, **kw)          # warm-up
+        n, t0 = 0, time.time()
+        while True:
+            x, _ = O.p_sample_compose_outside(d, x, None, 500 - n, nz, **kw)
+            n += 1
+            if time.time() - t0 > budget_s or n >= 100:
+                break
+        dt = (time.time() - t0) / n
+    return {"value": BATCH / (dt * TIMESTEPS), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} reverse steps of batch {BATCH} ({dt * 1e3:.1f} ms/step), extrapolated x{TIMESTEPS}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH, help="designs per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cindm_amd
+    from cindm_amd import dist as cdist
+
+    sd = synth_weights(24, 8)
+    model = cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64, dim_mults=(1, 2, 4, 8),
+                                     attention=True)
+    model.load_state_dict(sd, strict=True)
+    diffusion = cindm_amd.GaussianDiffusion1D(model, image_size=24, conditioned_steps=0, timesteps=TIMESTEPS,
+                                              sampling_timesteps=TIMESTEPS, loss_type="l1").to(dev)
+    B = args.batch
+    total = B * world
+    stream = torch.cuda.Stream(device=dev)
+
+    def one_chain(i):
+        # rank r owns global designs [r*B, (r+1)*B): noise is keyed by the global index
+        local = diffusion.sample(batch_size=B, cond=None, n_composed=0, compose_n_bodies=2, seed=1234 + i,
+                                 sample_offset=rank * B)
+        return cdist.all_gather_designs(local, total) if distributed else local
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            out = one_chain(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = one_chain(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert tuple(out.shape) == (total, 24, 8) and bool(torch.isfinite(out).all())
+
+        # ---- roofline leg (rank 0): per-kernel durations from HIP events on the launch stream ----
+        roof = None
+        if rank == 0:
+            x = torch.randn((B, 24, 8), device=dev)
+            model.profile(x, 500)
+            acc = {}
+            reps = 10
+            for _ in range(reps):
+                for k, (n, ms, fl) in model.profile(x, 500).items():
+                    a = acc.setdefault(k, [0, 0.0, 0.0])
+                    a[0] += n; a[1] += ms; a[2] += fl
+            k5 = acc["conv_gemm_kernel<5>"]
+            tot_ms = sum(v[1] for v in acc.values())
+            achieved = k5[2] / (k5[1] * 1e-3) / 1e12          # algorithmic FLOPs of the k=5 conv launches / their time
+            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<5>", "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
+                    "traffic": None,
+                    "launches_per_forward": k5[0] // reps, "avg_launch_us": round(k5[1] / k5[0] * 1e3, 2),
+                    "share_of_forward_time": round(k5[1] / tot_ms, 3),
+                    "forward_ms_sum_of_kernels": round(tot_ms / reps, 3),
+                    "per_kind_us": {k: round(v[1] / reps * 1e3, 1) for k, v in acc.items()}}
+
+    if rank == 0:
+        chains = args.steps
+        value = total * chains / elapsed
+        line = {
+            "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / chains * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"nbody-2 TemporalUnet1D dim=64 horizon=24 attention, single model, batch {B}/GPU, "
+                                   f"{TIMESTEPS} DDPM steps per design (BASELINE configs[1])",
+                       "designs_per_step": total, "unet_evals_per_design": TIMESTEPS,
+                       "parallelism": f"dp{world} (batch-sharded, one all-gather of final designs)"},
+            "sample_steps_per_s": round(value * TIMESTEPS, 1),
+            "model_tflops": round(value * TIMESTEPS * FLOP_PER_EVAL / 1e12, 2),
+            "frac_of_f32_mfma_peak_whole_job": round(value * TIMESTEPS * FLOP_PER_EVAL / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

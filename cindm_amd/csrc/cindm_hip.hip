@@ -245,6 +245,17 @@ struct Emitter {
     const int* t_ptr; int t_imm;
     int launches = 0;
     hipError_t err = hipSuccess;
+    struct ProfRec { int kind; hipEvent_t e0, e1; double flops; };
+    std::vector<ProfRec>* prof = nullptr;     // when set, every launch is bracketed by HIP events
+
+    void prof_begin(int kind, double flops) {
+        if (!prof || dry) return;
+        ProfRec r; r.kind = kind; r.flops = flops;
+        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, stream);
+        prof->push_back(r);
+    }
+    void prof_end() { if (prof && !dry) (void)hipEventRecord(prof->back().e1, stream); }
 
     float* alloc(size_t nfloats) {
         size_t o = ws_off;
@@ -274,6 +285,11 @@ struct Emitter {
         ++launches;
         if (dry) return;
         dim3 grid(a.Npad / TN, (unsigned)((a.Bp + a.spt - 1) / a.spt));
+        {
+            const double cin = (double)a.src[0].C + (a.nsrc > 1 ? (double)a.src[1].C : 0.0);
+            const double taps = a.transposed ? T * 0.5 : (double)T;          // algorithmic: 2 of 4 taps hit per output
+            prof_begin(T == 0 ? 0 : T == 1 ? 1 : T == 3 ? 2 : T == 4 ? 3 : 4, 2.0 * a.Bp * a.Lout * a.N * cin * taps);
+        }
         switch (T) {
             case 0: hipLaunchKernelGGL(conv_gemm_kernel<0>, grid, dim3(256), 0, stream, a); break;
             case 1: hipLaunchKernelGGL(conv_gemm_kernel<1>, grid, dim3(256), 0, stream, a); break;
@@ -282,6 +298,7 @@ struct Emitter {
             case 5: hipLaunchKernelGGL(conv_gemm_kernel<5>, grid, dim3(256), 0, stream, a); break;
             default: err = hipErrorInvalidValue;
         }
+        prof_end();
         hipError_t e = hipGetLastError();
         if (e != hipSuccess && err == hipSuccess) err = e;
     }
@@ -370,7 +387,9 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             attr_set = true;
         }
+        E.prof_begin(5, (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));    // context + out contractions
         hipLaunchKernelGGL(linattn_core_kernel, dim3((unsigned)Bp), dim3(256), shm, E.stream, qkv.p, att.p, L);
+        E.prof_end();
     }
     E.base(a, wo, Bp, L, L);
     Emitter::plain(a.src[0], att);
@@ -562,6 +581,31 @@ extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, 
     Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, t_dev, t};
     emit_forward(E, x, eps);
     if (E.err != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(E.err));
+    return 0;
+}
+
+extern "C" int cindm_unet1d_profile(cindm_unet1d* h, const float* x, int32_t t, float* eps, int64_t rows, void* ws,
+                                    size_t ws_bytes, void* stream, int32_t counts[6], float ms[6], double flops[6]) {
+    REQUIRE(h && x && eps && ws && counts && ms && flops, "null argument");
+    REQUIRE(h->finalized, "cindm_unet1d_finalize has not been called");
+    REQUIRE(rows > 0 && rows <= 65535, "rows out of range (1..65535)");
+    REQUIRE(t >= 0 && t < h->d.timesteps, "timestep out of range");
+    REQUIRE(ws_bytes >= cindm_unet1d_workspace_bytes(h, rows), "workspace too small");
+    std::vector<Emitter::ProfRec> recs;
+    Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, nullptr, t};
+    E.prof = &recs;
+    h->taps.clear(); h->taps_rows = rows;
+    emit_forward(E, x, eps);
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    for (int i = 0; i < 6; ++i) { counts[i] = 0; ms[i] = 0.f; flops[i] = 0.0; }
+    for (auto& r : recs) {
+        float dt = 0.f;
+        (void)hipEventElapsedTime(&dt, r.e0, r.e1);
+        counts[r.kind] += 1; ms[r.kind] += dt; flops[r.kind] += r.flops;
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    if (E.err != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(E.err));
+    if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
     return 0;
 }
 

@@ -171,6 +171,24 @@ class TemporalUnet1D(nn.Module):
                                                        _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
         return out
 
+    KERNEL_KINDS = ("conv_gemm_kernel<0>", "conv_gemm_kernel<1>", "conv_gemm_kernel<3>", "conv_gemm_kernel<4>",
+                    "conv_gemm_kernel<5>", "linattn_core_kernel")
+
+    @torch.no_grad()
+    def profile(self, x, t):
+        """One forward with every launch bracketed by HIP events on the current stream.
+        Returns {kernel kind: (launches, total ms, total algorithmic FLOPs)}."""
+        self.sync_weights()
+        x = x.contiguous().float()
+        out = torch.empty_like(x)
+        ws = self.workspace(x.shape[0], x.device)
+        cnt, ms, fl = (C.c_int32 * 6)(), (C.c_float * 6)(), (C.c_double * 6)()
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().cindm_unet1d_profile(self._h, _ffi.ptr(x), int(t), _ffi.ptr(out), x.shape[0], _ffi.ptr(ws),
+                                                       ws.numel(), _ffi.current_stream(x.device), C.byref(cnt), C.byref(ms),
+                                                       C.byref(fl)))
+        return {k: (cnt[i], ms[i], fl[i]) for i, k in enumerate(self.KERNEL_KINDS)}
+
     def tap(self, name, rows):
         """Intermediate activation of the last forward as [rows, C, L] (the reference's layout)."""
         shape = (C.c_int64 * 3)()

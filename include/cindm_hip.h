@@ -85,6 +85,14 @@ int  cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int3
  * Names: reference module paths, e.g. "downs.0.0", "mid_attn", "ups.2.3", "final_conv.0". */
 int  cindm_unet1d_tap(cindm_unet1d* h, const char* name, int64_t rows, void* ws, float* dst,
                       int64_t dst_cap, int64_t shape[3], void* stream);
+/* Instrumented forward for bench.py's roofline leg: as cindm_unet1d_forward, but every launch is
+ * bracketed by HIP events recorded on `stream`; returns per kernel kind k
+ * (0..4 = conv_gemm_kernel<T> for T = 0,1,3,4,5; 5 = linattn_core_kernel) the launch count, the summed
+ * duration in ms and the summed ALGORITHMIC FLOPs (2*M*N*K of the layer, no padding).
+ * Synchronises `stream`. */
+int  cindm_unet1d_profile(cindm_unet1d* h, const float* x, int32_t t, float* eps, int64_t rows,
+                          void* ws, size_t ws_bytes, void* stream,
+                          int32_t counts[6], float ms[6], double flops[6]);
 /* Number of kernel launches one forward issues (for DESIGN/bench bookkeeping). */
 int  cindm_unet1d_launches_per_forward(const cindm_unet1d* h);
 

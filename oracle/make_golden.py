@@ -201,9 +201,9 @@ def main():
         fw[f"eps_f{F}_t321"] = ref.numpy()
     mN, sdN, _ = build_ref_unet(d1, 24, 8, attention=False)
     with torch.no_grad():
-        ref = mN(x2, tt, None)
+        ref = mN(x2, tt, None)                      # tt is still the t=321 tensor of the loop above
     assert relerr(O.unet1d_forward(sdN, x2, tt), ref) < 1e-6
-    fw["eps_noattn_t500"] = ref.numpy()
+    fw["eps_noattn_t321"] = ref.numpy()
     # horizon 44 (paper's 2-body long model: different level structure) and horizon 8
     for hz in (44, 8):
         mH, sdH, _ = build_ref_unet(d1, hz, 8)
@@ -212,7 +212,7 @@ def main():
             ref = mH(xH, tt, None)
         assert relerr(O.unet1d_forward(sdH, xH, tt), ref) < 1e-6
         fw[f"x_h{hz}"] = xH.numpy()
-        fw[f"eps_h{hz}_t500"] = ref.numpy()
+        fw[f"eps_h{hz}_t321"] = ref.numpy()
     np.savez_compressed(os.path.join(GOLD, "unet1d_fwd.npz"), **fw)
     print("unet forward done", time.time() - t0, report, flush=True)
 

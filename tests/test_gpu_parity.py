@@ -89,8 +89,8 @@ def test_unet_blocks_golden(gold_dir, device, unet8):
 
 
 @pytest.mark.parametrize("hz,F,att,key,xkey", [(24, 4, True, "eps_f4_t321", "x_f4"), (24, 16, True, "eps_f16_t321", "x_f16"),
-                                                 (24, 8, False, "eps_noattn_t500", None), (44, 8, True, "eps_h44_t500", "x_h44"),
-                                                 (8, 8, True, "eps_h8_t500", "x_h8")])
+                                                 (24, 8, False, "eps_noattn_t321", None), (44, 8, True, "eps_h44_t321", "x_h44"),
+                                                 (8, 8, True, "eps_h8_t321", "x_h8")])
 def test_unet_variants_golden(gold_dir, device, hz, F, att, key, xkey):
     g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
     m, _ = build_unet(device, hz, F, att)

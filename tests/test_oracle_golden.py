@@ -69,10 +69,11 @@ def test_unet_forward(gold_dir, sd8, sd4):
     out = O.unet1d_forward(sd16, torch.from_numpy(g["x_f16"]), torch.full((2,), 321, dtype=torch.long))
     assert rel(out, g["eps_f16_t321"]) < TOL
     sdn = O.synth_state_dict(O.unet1d_param_shapes(24, 8, attention=False), seed=0)
-    assert rel(O.unet1d_forward(sdn, x[:2], tt), g["eps_noattn_t500"]) < TOL
+    t321 = torch.full((2,), 321, dtype=torch.long)
+    assert rel(O.unet1d_forward(sdn, x[:2], t321), g["eps_noattn_t321"]) < TOL
     for hz in (44, 8):
         sdh = O.synth_state_dict(O.unet1d_param_shapes(hz, 8), seed=0)
-        assert rel(O.unet1d_forward(sdh, torch.from_numpy(g[f"x_h{hz}"]), tt), g[f"eps_h{hz}_t500"]) < TOL, hz
+        assert rel(O.unet1d_forward(sdh, torch.from_numpy(g[f"x_h{hz}"]), t321), g[f"eps_h{hz}_t321"]) < TOL, hz
 
 
 STEP_CASES = {
