@@ -61,6 +61,7 @@ SIGNATURES = {
     "cindm_unet1d_tap": (C.c_int, [_vp, C.c_char_p, _i64, _vp, _vp, _i64, C.POINTER(_i64 * 3), _vp]),
     "cindm_unet1d_profile": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp, C.POINTER(_i32 * 6),
                                        C.POINTER(C.c_float * 6), C.POINTER(C.c_double * 6)]),
+    "cindm_unet1d_profile_detail": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp, _i32, C.POINTER(_i32), _vp, _vp, _vp, _vp]),
     "cindm_unet1d_launches_per_forward": (C.c_int, [_vp]),
     "cindm_ddpm1d_create": (C.c_int, [C.POINTER(SchedDesc), C.POINTER(_vp)]),
     "cindm_ddpm1d_destroy": (None, [_vp]),

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -35,7 +36,7 @@ struct Param {
     bool set = false;
 };
 
-struct Packed { size_t off = 0; int T = 0, CinP = 0, Npad = 0, N = 0; size_t bias_off = 0; bool has_bias = false; };
+struct Packed { size_t off = 0; int T = 0, CinP = 0, Npad = 0, N = 0, KC = 32; size_t bias_off = 0; bool has_bias = false; };
 
 struct RtbDesc { std::string p; int cin, cout; int tb_off; };
 
@@ -201,21 +202,41 @@ static void pack_weight(cindm_unet1d* h, BlobBuilder& bb, const std::string& pre
     else if (kind == 1) { Ci = (int)w.shape[0]; Co = (int)w.shape[1]; K = (int)w.shape[2]; }
     else { Co = (int)w.shape[0]; Ci = (int)w.shape[1]; K = 1; }
     const int C0 = split ? split : Ci, C1 = Ci - C0;
-    const int C0p = ceil_to(C0, KC), C1p = C1 ? ceil_to(C1, KC) : 0;
-    Packed pk; pk.T = K; pk.CinP = C0p + C1p; pk.Npad = ceil_to(Co, TN); pk.N = Co;
+    // stage width: tap-ful convolutions stage 32 channels x T taps; 1x1 layers stage 64 or 128 channels
+    const int KC = (K > 1) ? 32 : ((C0 % 128 == 0 && C1 % 128 == 0) ? 128 : 64);
+    int C0p = ceil_to(C0, KC), C1p = C1 ? ceil_to(C1, KC) : 0;
+    // the kernel's two-set register pipeline wants an even number of stages (or exactly one): pad with a zero stage
+    if (((C0p + C1p) / KC) > 1 && ((C0p + C1p) / KC) % 2) { if (C1) C1p += KC; else C0p += KC; }
+    Packed pk; pk.T = K; pk.CinP = C0p + C1p; pk.Npad = ceil_to(Co, TN); pk.N = Co; pk.KC = KC;
+    // MFMA-fragment order: [n-tile][stage][q][thread = wave*64 + lane][4], flat j = 4q + e = (tap*CS + cs)*2 + nb: the
+    // value a lane feeds to v_mfma_f32_16x16x4_f32 as B[k = lane>>4][j = lane&15] of k-step (tap, cs), column block
+    // nb.  Every float4 load of a wave is 1 KiB contiguous.
+    const int nch = pk.CinP / KC, CPW = KC / 4, CS = CPW / 4, KS = K * CS;
     pk.off = bb.alloc((size_t)K * pk.CinP * pk.Npad);
-    for (int tap = 0; tap < K; ++tap)
-        for (int c = 0; c < Ci; ++c) {
-            const int cp = c < C0 ? c : C0p + (c - C0);
-            float* dst = bb.data.data() + pk.off + ((size_t)tap * pk.CinP + cp) * pk.Npad;
-            for (int n = 0; n < Co; ++n) {
-                float v;
-                if (kind == 0) v = w.host[((size_t)n * Ci + c) * K + tap];
-                else if (kind == 1) v = w.host[((size_t)c * Co + n) * K + tap];
-                else v = w.host[(size_t)n * Ci + c];
-                dst[n] = v;
+    float* base = bb.data.data() + pk.off;
+    for (int nt = 0; nt < pk.Npad / TN; ++nt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int tid = 0; tid < 256; ++tid) {
+                const int wv = tid >> 6, lane = tid & 63;
+                float* dst = base + ((size_t)nt * nch + ch) * 256 * (2 * KS);      // + ((j/4)*256 + tid)*4 + j%4
+                for (int tap = 0; tap < K; ++tap)
+                    for (int cs = 0; cs < CS; ++cs)
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int cp = ch * KC + wv * CPW + cs * 4 + (lane >> 4);     // padded channel index
+                            const int n = nt * TN + nb * 16 + (lane & 15);
+                            int c = -1;
+                            if (cp < C0) c = cp;
+                            else if (cp >= C0p && cp - C0p < C1) c = C0 + (cp - C0p);
+                            float v = 0.f;
+                            if (c >= 0 && n < Co) {
+                                if (kind == 0) v = w.host[((size_t)n * Ci + c) * K + tap];
+                                else if (kind == 1) v = w.host[((size_t)c * Co + n) * K + tap];
+                                else v = w.host[(size_t)n * Ci + c];
+                            }
+                            const int j = (tap * CS + cs) * 2 + nb;
+                            dst[((size_t)(j / 4) * 256 + tid) * 4 + (j % 4)] = v;
+                        }
             }
-        }
     auto bi = h->index.find(prefix + ".bias");
     if (bi != h->index.end()) {
         pk.has_bias = true;
@@ -245,12 +266,13 @@ struct Emitter {
     const int* t_ptr; int t_imm;
     int launches = 0;
     hipError_t err = hipSuccess;
-    struct ProfRec { int kind; hipEvent_t e0, e1; double flops; };
+    struct ProfRec { int kind; hipEvent_t e0, e1; double flops; int gx, gy, nstage; };
     std::vector<ProfRec>* prof = nullptr;     // when set, every launch is bracketed by HIP events
+    static constexpr int prof_reps = 8;
 
     void prof_begin(int kind, double flops) {
         if (!prof || dry) return;
-        ProfRec r; r.kind = kind; r.flops = flops;
+        ProfRec r; r.kind = kind; r.flops = flops; r.gx = r.gy = r.nstage = 0;
         (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
         (void)hipEventRecord(r.e0, stream);
         prof->push_back(r);
@@ -269,7 +291,7 @@ struct Emitter {
 
     void base(GemmArgs& a, const Packed& pk, int Bp, int Lin, int Lout) {
         std::memset(&a, 0, sizeof(a));
-        a.W = W(pk); a.bias = B(pk); a.CinP = pk.CinP; a.Npad = pk.Npad; a.N = pk.N;
+        a.W = W(pk); a.bias = B(pk); a.CinP = pk.CinP; a.Npad = pk.Npad; a.N = pk.N; a.KC = pk.KC;
         a.Bp = Bp; a.Lin = Lin; a.Lout = Lout; a.stride = 1; a.pad = pk.T / 2; a.transposed = 0;
         const int lmax = Lin > Lout ? Lin : Lout;
         a.spt = TM / (Lout > 0 ? Lout : 1);
@@ -289,15 +311,45 @@ struct Emitter {
             const double cin = (double)a.src[0].C + (a.nsrc > 1 ? (double)a.src[1].C : 0.0);
             const double taps = a.transposed ? T * 0.5 : (double)T;          // algorithmic: 2 of 4 taps hit per output
             prof_begin(T == 0 ? 0 : T == 1 ? 1 : T == 3 ? 2 : T == 4 ? 3 : 4, 2.0 * a.Bp * a.Lout * a.N * cin * taps);
+            if (prof && !dry) { prof->back().gx = grid.x; prof->back().gy = grid.y; prof->back().nstage = T ? a.CinP / a.KC : 0; }
         }
-        switch (T) {
-            case 0: hipLaunchKernelGGL(conv_gemm_kernel<0>, grid, dim3(256), 0, stream, a); break;
-            case 1: hipLaunchKernelGGL(conv_gemm_kernel<1>, grid, dim3(256), 0, stream, a); break;
-            case 3: hipLaunchKernelGGL(conv_gemm_kernel<3>, grid, dim3(256), 0, stream, a); break;
-            case 4: hipLaunchKernelGGL(conv_gemm_kernel<4>, grid, dim3(256), 0, stream, a); break;
-            case 5: hipLaunchKernelGGL(conv_gemm_kernel<5>, grid, dim3(256), 0, stream, a); break;
-            default: err = hipErrorInvalidValue;
+        const int mode = a.src[0].mode;
+#define CINDM_LAUNCH(T_, KC_, ROWS_, MODE_) hipLaunchKernelGGL((conv_gemm_kernel<T_, KC_, ROWS_, MODE_>), grid, dim3(256), 0, stream, a)
+        bool ok = true;
+        // profile mode: the (idempotent) launch is repeated inside one event bracket so that the ~6 us cost of the
+        // bracket itself is amortised; the reported time is bracket / prof_reps
+        for (int rep = 0; rep < (prof ? prof_reps : 1); ++rep) {
+        if (T == 0) CINDM_LAUNCH(0, 32, 48, SRC_PLAIN);
+        else if (T == 5 && mode == SRC_PLAIN) {
+            static const int dbg = getenv("CINDM_DBG") ? atoi(getenv("CINDM_DBG")) : 0;   // timing ablations (wrong results)
+            if (dbg == 1) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 1>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 2) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 2>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 3) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 3>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 4) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 4>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 5) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 5>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 6) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 6>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 7) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 7>), grid, dim3(256), 0, stream, a);
+            else if (dbg == 8) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 8>), grid, dim3(256), 0, stream, a);
+            else CINDM_LAUNCH(5, 32, 48, SRC_PLAIN);
         }
+        else if (T == 5 && mode == SRC_GN_MISH) CINDM_LAUNCH(5, 32, 48, SRC_GN_MISH);
+        else if (T == 3 && mode == SRC_PLAIN) CINDM_LAUNCH(3, 32, 96, SRC_PLAIN);
+        else if (T == 4 && mode == SRC_PLAIN) CINDM_LAUNCH(4, 32, 48, SRC_PLAIN);
+        else if (T == 1 && a.KC == 128) {
+            if (mode == SRC_PLAIN) CINDM_LAUNCH(1, 128, 48, SRC_PLAIN);
+            else if (mode == SRC_LN) CINDM_LAUNCH(1, 128, 48, SRC_LN);
+            else if (mode == SRC_MISH) CINDM_LAUNCH(1, 128, 48, SRC_MISH);
+            else ok = false;
+        } else if (T == 1 && a.KC == 64) {
+            if (mode == SRC_PLAIN) CINDM_LAUNCH(1, 64, 48, SRC_PLAIN);
+            else if (mode == SRC_LN) CINDM_LAUNCH(1, 64, 48, SRC_LN);
+            else if (mode == SRC_MISH) CINDM_LAUNCH(1, 64, 48, SRC_MISH);
+            else if (mode == SRC_GN_MISH) CINDM_LAUNCH(1, 64, 48, SRC_GN_MISH);
+            else ok = false;
+        } else ok = false;
+        }
+#undef CINDM_LAUNCH
+        if (!ok) err = hipErrorInvalidValue;
         prof_end();
         hipError_t e = hipGetLastError();
         if (e != hipSuccess && err == hipSuccess) err = e;
@@ -346,7 +398,7 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
         Emitter::plain(a.src[0], x0);
         if (x1) { Emitter::plain(a.src[1], *x1); a.nsrc = 2; }
     } else {
-        Packed none; none.T = 0; none.CinP = 0; none.Npad = ceil_to(cout, TN); none.N = cout;
+        Packed none; none.T = 0; none.CinP = 0; none.Npad = ceil_to(cout, TN); none.N = cout; none.KC = 32;
         E.base(a, none, Bp, L, L);
         a.W = nullptr; a.bias = nullptr; a.pad = 0;
         Emitter::plain(a.src[0], x0);
@@ -388,7 +440,8 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             attr_set = true;
         }
         E.prof_begin(5, (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));    // context + out contractions
-        hipLaunchKernelGGL(linattn_core_kernel, dim3((unsigned)Bp), dim3(256), shm, E.stream, qkv.p, att.p, L);
+        for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
+            hipLaunchKernelGGL(linattn_core_kernel, dim3((unsigned)Bp), dim3(256), shm, E.stream, qkv.p, att.p, L);
         E.prof_end();
     }
     E.base(a, wo, Bp, L, L);
@@ -601,9 +654,34 @@ extern "C" int cindm_unet1d_profile(cindm_unet1d* h, const float* x, int32_t t, 
     for (auto& r : recs) {
         float dt = 0.f;
         (void)hipEventElapsedTime(&dt, r.e0, r.e1);
-        counts[r.kind] += 1; ms[r.kind] += dt; flops[r.kind] += r.flops;
+        counts[r.kind] += 1; ms[r.kind] += dt / Emitter::prof_reps; flops[r.kind] += r.flops;
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
+    if (E.err != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(E.err));
+    if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
+    return 0;
+}
+
+extern "C" int cindm_unet1d_profile_detail(cindm_unet1d* h, const float* x, int32_t t, float* eps, int64_t rows, void* ws,
+                                           size_t ws_bytes, void* stream, int32_t cap, int32_t* n_out, int32_t* kind,
+                                           float* ms, double* flops, int32_t* grid_xy_stages) {
+    REQUIRE(h && x && eps && ws && n_out && kind && ms && flops && grid_xy_stages, "null argument");
+    REQUIRE(h->finalized, "cindm_unet1d_finalize has not been called");
+    REQUIRE(ws_bytes >= cindm_unet1d_workspace_bytes(h, rows), "workspace too small");
+    std::vector<Emitter::ProfRec> recs;
+    Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, nullptr, t};
+    E.prof = &recs;
+    h->taps.clear(); h->taps_rows = rows;
+    emit_forward(E, x, eps);
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    int n = 0;
+    for (auto& r : recs) {
+        float dt = 0.f;
+        (void)hipEventElapsedTime(&dt, r.e0, r.e1);
+        if (n < cap) { kind[n] = r.kind; ms[n] = dt / Emitter::prof_reps; flops[n] = r.flops; grid_xy_stages[3 * n] = r.gx; grid_xy_stages[3 * n + 1] = r.gy; grid_xy_stages[3 * n + 2] = r.nstage; ++n; }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    *n_out = n;
     if (E.err != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(E.err));
     if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
     return 0;
@@ -692,6 +770,8 @@ static int step_layout(const cindm_unet1d* pair, const cindm_unet1d* uncond, con
         REQUIRE(c->n_windows == 1 || (c->compose_start_step >= 1 && c->compose_start_step <= c->window), "windows must cover every step");
         REQUIRE(!(c->mode >= 3 && c->cond_steps > 0), "outside composition with conditioned_steps > 0 is not supported");
         s.pair_rows = (int64_t)c->n_windows * (nb * (nb - 1) / 2) * B; s.pair_F = 8; s.Tw = c->window;
+        // one window, one pair, nothing prepended: the gathered U-Net input IS the state
+        s.direct = (c->n_windows == 1 && nb == 2 && c->cond_steps == 0);
     }
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t o = 0;
@@ -724,7 +804,9 @@ extern "C" int cindm_ddpm1d_launches_per_step(const cindm_ddpm1d*, const cindm_u
                                               const cindm_compose_desc* c) {
     if (!pair || !c) return 0;
     int n = pair->launches + 1;                       // U-Net + update
-    if (!(c->mode == CINDM_COMPOSE_PLAIN && c->cond_steps == 0)) n += 1;   // gather
+    const bool direct = c->cond_steps == 0 && (c->mode == CINDM_COMPOSE_PLAIN ||
+                        (c->mode >= 1 && c->mode <= 4 && c->n_windows == 1 && c->n_bodies == 2));
+    if (!direct) n += 1;                              // gather
     if (c->mode == CINDM_COMPOSE_MULTIBODY && uncond) n += uncond->launches;
     return n;
 }

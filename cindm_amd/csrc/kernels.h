@@ -31,10 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 48;        // tile rows
 constexpr int TN = 32;        // tile cols
-constexpr int KC = 32;        // channels per staged chunk
-constexpr int LDA = 34;       // LDS row pitch (floats): 2*row + k spreads 16 rows x 2 k over 32 banks
 constexpr int MAXR = 96;      // max input rows per tile (stride-2 conv: 2 * 48)
-constexpr int ZROW = MAXR;    // index of the all-zero LDS row
 constexpr int LDR = 33;       // reduce / output tile pitch
 
 enum SrcMode { SRC_PLAIN = 0, SRC_GN_MISH = 1, SRC_LN = 2, SRC_MISH = 3 };
@@ -60,6 +57,7 @@ struct GemmArgs {
     const float* W;       // [T][CinP][Npad]
     const float* bias;    // [Npad] or null
     int CinP, Npad, N;
+    int KC;               // channels per pipeline stage the weights were packed for (host-side dispatch)
     int Bp, Lin, Lout, stride, pad, transposed, spt;
     float* out; int ldo;
     const float* res; int ldres;                         // + res
@@ -73,10 +71,12 @@ struct GemmArgs {
 __device__ __forceinline__ float mish_f(float x) {
     // Mish(x) = x * tanh(softplus(x)), PyTorch softplus threshold 20.
     // tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2),  n = e*(e+2)   (no cancellation)
-    if (x > 20.0f) return x;
-    float e = expf(x);
-    float n = e * (e + 2.0f);
-    return x * (n / (n + 2.0f));
+    // branch-free (the select keeps the hot loop free of divergent control flow) and cheap: one v_exp_f32
+    // and one v_rcp_f32 (each <= 1 ulp); |x| <= 20 keeps the exp2 argument's rounding below 4e-7 relative
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
+    const float n = e * (e + 2.0f);
+    const float r = x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
+    return x > 20.0f ? x : r;
 }
 
 __device__ __forceinline__ float wave_sum_seg(float v, int seg) {
@@ -99,13 +99,29 @@ __device__ __forceinline__ void merge_stats(const float* st, int P, float cnt, f
     rstd = 1.0f / sqrtf(M2 / (cnt * (float)P) + eps);
 }
 
-template <int T>
+// Pipeline: stage = KC input channels x all T taps.  While stage ch is multiplied, the B fragments and the
+// A rows of stage ch+1 are in flight (registers); A is transformed and written to the other LDS buffer
+// after the multiply; one barrier per stage.  The loop body is BRANCH-FREE (clamped addresses + selects,
+// the tail re-loads the last stage) so that hipcc keeps counted vmcnt waits instead of draining at every
+// join.  KC is 32 for the tap-ful convolutions and 64/128 for 1x1 layers (same bytes in flight per stage).
+template <int T, int KC, int ROWS, int MODE, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2][(MAXR + 1) * LDA];
+    constexpr int TT = T > 0 ? T : 1;
+    constexpr int LDAK = KC + 2;            // LDS row pitch: 2*row + k spreads 16 rows x 2 k over 32 banks
+    constexpr int CPW = KC / 4;             // channels per wave per stage
+    constexpr int CS = CPW / 4;             // k-steps per tap per stage
+    constexpr int KS = TT * CS;             // k-steps per stage per wave
+    constexpr int F4R = KC / 4;             // float4 per staged row
+    constexpr int RPP = 256 / F4R;          // rows per staging pass
+    constexpr int NP = (ROWS + RPP - 1) / RPP;
+    constexpr int LROWS = NP * RPP;         // staged rows (>= ROWS, so every staging store is unconditional)
+    constexpr int ZR = LROWS;               // index of the all-zero LDS row
+    __shared__ __attribute__((aligned(16))) float As[2][(LROWS + 1) * LDAK];
     __shared__ __attribute__((aligned(16))) float Red[4][TM * LDR];
     __shared__ float tabA[TM * 8 * 2];      // GN prologue: [spt][8](mean, rstd), spt <= 48;  LN: [rows_in <= 96](mean, rstd)
     __shared__ float tabE[TM * 8 * 2];      // epilogue GN table [spt][8](mean, rstd)
 
+    if constexpr (DBG == 6) return;             // DBG 6: launch floor
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * a.spt;
@@ -115,173 +131,217 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
     const int n0 = nt * TN;
     const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
 
-    // ---- zero rows + normalisation tables -------------------------------------------------
-    for (int i = tid; i < 2 * LDA; i += 256) As[i / LDA][ZROW * LDA + (i % LDA)] = 0.f;
-    {
-        const Src& s = a.src[0];
-        if (s.mode == SRC_GN_MISH) {
-            for (int i = tid; i < ns * 8; i += 256) {
-                float m, r;
-                merge_stats(s.stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
-                tabA[2 * i] = m; tabA[2 * i + 1] = r;
-            }
-        } else if (s.mode == SRC_LN) {
-            for (int i = tid; i < rows_in; i += 256) {
-                float m, r;
-                merge_stats(s.stats + (size_t)(b0 * a.Lin + i) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
-                tabA[2 * i] = m; tabA[2 * i + 1] = r;
-            }
-        }
-    }
-    if (a.e_y) {
-        for (int i = tid; i < ns * 8; i += 256) {
-            float m, r;
-            merge_stats(a.e_stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * a.e_P * 2, a.e_P, a.e_cnt, 1e-5f, m, r);
-            tabE[2 * i] = m; tabE[2 * i + 1] = r;
-        }
-    }
-
-    // ---- per-lane A fragment addresses (float index into one As buffer) --------------------
-    int aaddr[3][T > 0 ? T : 1];
-#pragma unroll
-    for (int mb = 0; mb < 3; ++mb) {
-        const int r = mb * 16 + (lane & 15);
-        const int s = r / a.Lout, lo = r - s * a.Lout;
-#pragma unroll
-        for (int tap = 0; tap < (T > 0 ? T : 1); ++tap) {
-            int row = ZROW;
-            if (r < rows_out) {
-                int li; bool ok;
-                if (!a.transposed) { li = lo * a.stride + tap - a.pad; ok = (li >= 0) && (li < a.Lin); }
-                else { int q = lo + a.pad - tap; li = q >> 1; ok = (q >= 0) && !(q & 1) && (li < a.Lin); }
-                if (ok) row = s * a.Lin + li;
-            }
-            aaddr[mb][tap] = row * LDA + w * 8 + (lane >> 4);
-        }
-    }
-
     f32x4 acc[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     if constexpr (T > 0) {
         const int nch0 = (a.src[0].C + KC - 1) / KC;
-        const int nch = nch0 + (a.nsrc > 1 ? (a.src[1].C + KC - 1) / KC : 0);
-        // staging role: thread -> (row r0 + 32p, channels c4*4..c4*4+3)
-        const int c4 = tid & 7, r0 = tid >> 3;
-        int srow[3];
+        const int nch = a.CinP / KC;           // includes the host's zero padding stage (even stage count)
+        const int c4 = tid % F4R, r0 = tid / F4R;
+        // per-thread staging constants: clamped global row offsets (always in-bounds) + validity
+        size_t goff[NP];
+        bool rok[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) srow[p] = (r0 + 32 * p) / a.Lin;
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + RPP * p;
+            rok[p] = r < rows_in;
+            goff[p] = (size_t)(b0 * a.Lin + min(r, rows_in - 1));
+        }
 
-        float4 stg[3];
-        auto stage_load = [&](int ch) {
-            const Src& s = (ch < nch0) ? a.src[0] : a.src[1];
-            const int cl = ((ch < nch0) ? ch : ch - nch0) * KC + c4 * 4;
+        float bcur[KS][2], bnxt[KS][2];
+        float4 areg[NP];
+        // weights are packed in MFMA-fragment order [n-tile][stage][q][thread][4] (host: pack_weight): the B operands of
+        // a whole stage are KS/2 float4 per lane, each wave-instruction reads 1 KiB contiguous, each stage 2*KS KiB
+        static_assert((2 * KS) % 4 == 0, "stage fragment must be float4-sized");
+        const float4* wbase = reinterpret_cast<const float4*>(a.W) + (size_t)nt * nch * 256 * (2 * KS / 4) + tid;
+        auto load_b = [&](int ch, float (&b)[KS][2]) {
+            const float4* wp = wbase + (size_t)ch * 256 * (2 * KS / 4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int r = r0 + 32 * p;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < rows_in && cl < s.C)
-                    v = *reinterpret_cast<const float4*>(s.p + (size_t)(b0 * a.Lin + r) * s.ld + cl);
-                stg[p] = v;
+            for (int q = 0; q < 2 * KS / 4; ++q) {
+                const float4 v = wp[q * 256];
+                b[2 * q][0] = v.x; b[2 * q][1] = v.y; b[2 * q + 1][0] = v.z; b[2 * q + 1][1] = v.w;
             }
         };
-        auto stage_store = [&](int ch) {
-            const Src& s = (ch < nch0) ? a.src[0] : a.src[1];
-            const int cl = ((ch < nch0) ? ch : ch - nch0) * KC + c4 * 4;
-            float* dst = As[ch & 1];
-            const bool cok = cl < s.C;
-            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f), tb = bt;
-            if (cok && (s.mode == SRC_GN_MISH || s.mode == SRC_LN)) {
-                g = *reinterpret_cast<const float4*>(s.gamma + cl);
-                if (s.beta) bt = *reinterpret_cast<const float4*>(s.beta + cl);
-            }
-            if (cok && s.tb) tb = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + cl);
+        // source of stage ch (branch-free select between the two concatenated sources)
+        auto src_ptr = [&](int ch, int& cl, int& C, int& ld) -> const float* {
+            const bool first = (ch < nch0) || (a.nsrc == 1);     // a padding stage of a single source stays on it
+            cl = (first ? ch : ch - nch0) * KC + c4 * 4;
+            C = first ? a.src[0].C : a.src[1].C;
+            ld = first ? a.src[0].ld : a.src[1].ld;
+            return first ? a.src[0].p : a.src[1].p;
+        };
+        float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), ptb = pb;   // norm params of the stage in flight
+        auto load_a = [&](int ch, float4 (&v)[NP]) {
+            int cl, C, ld;
+            const float* base = src_ptr(ch, cl, C, ld);
+            const int clc = min(cl, C - 4);                    // clamped: always a valid address
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int r = r0 + 32 * p;
-                if (r >= MAXR) continue;
-                float4 v = stg[p];
-                if (r < rows_in && cok) {
-                    if (s.mode == SRC_GN_MISH) {
-                        const int ti = (srow[p] * 8 + cl / s.gw) * 2;
-                        const float m = tabA[ti], rs = tabA[ti + 1];
-                        v.x = mish_f((v.x - m) * rs * g.x + bt.x) + tb.x;
-                        v.y = mish_f((v.y - m) * rs * g.y + bt.y) + tb.y;
-                        v.z = mish_f((v.z - m) * rs * g.z + bt.z) + tb.z;
-                        v.w = mish_f((v.w - m) * rs * g.w + bt.w) + tb.w;
-                    } else if (s.mode == SRC_LN) {
-                        const float m = tabA[2 * r], rs = tabA[2 * r + 1];
-                        v.x = (v.x - m) * rs * g.x; v.y = (v.y - m) * rs * g.y;
-                        v.z = (v.z - m) * rs * g.z; v.w = (v.w - m) * rs * g.w;
-                    } else if (s.mode == SRC_MISH) {
-                        v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w);
-                    }
+            for (int p = 0; p < NP; ++p)
+                v[p] = *reinterpret_cast<const float4*>(base + goff[p] * ld + clc);
+            if constexpr (MODE == SRC_GN_MISH || MODE == SRC_LN) {
+                const Src& s = a.src[0];
+                pg = *reinterpret_cast<const float4*>(s.gamma + clc);
+                if constexpr (MODE == SRC_GN_MISH) {
+                    pb = *reinterpret_cast<const float4*>(s.beta + clc);
+                    if (s.tb) ptb = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + clc);
                 }
-                float2* d2 = reinterpret_cast<float2*>(dst + r * LDA + c4 * 4);
+            }
+        };
+        // issue the first stage's global loads before anything else: their latency overlaps the set-up below
+        load_b(0, bcur);
+        load_a(0, areg);
+
+        // ---- zero rows + normalisation tables ---------------------------------------------
+        for (int i = tid; i < 2 * LDAK; i += 256) As[i / LDAK][ZR * LDAK + (i % LDAK)] = 0.f;
+        if constexpr (MODE == SRC_GN_MISH) {
+            const Src& s = a.src[0];
+            for (int i = tid; i < ns * 8; i += 256) {
+                float m, r;
+                merge_stats(s.stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
+                tabA[2 * i] = m; tabA[2 * i + 1] = r;
+            }
+        } else if constexpr (MODE == SRC_LN) {
+            const Src& s = a.src[0];
+            for (int i = tid; i < rows_in; i += 256) {
+                float m, r;
+                merge_stats(s.stats + (size_t)(b0 * a.Lin + i) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
+                tabA[2 * i] = m; tabA[2 * i + 1] = r;
+            }
+        }
+        if (a.e_y) {
+            for (int i = tid; i < ns * 8; i += 256) {
+                float m, r;
+                merge_stats(a.e_stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * a.e_P * 2, a.e_P, a.e_cnt, 1e-5f, m, r);
+                tabE[2 * i] = m; tabE[2 * i + 1] = r;
+            }
+        }
+
+        // ---- per-lane A fragment addresses (float index into one As buffer) ----------------
+        int aaddr[3][T];
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) {
+            const int r = mb * 16 + (lane & 15);
+            const int s = r / a.Lout, lo = r - s * a.Lout;
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                int li; bool ok;
+                if (!a.transposed) { li = lo * a.stride + tap - a.pad; ok = (li >= 0) && (li < a.Lin); }
+                else { const int q = lo + a.pad - tap; li = q >> 1; ok = (q >= 0) && !(q & 1) && (li < a.Lin); }
+                const int row = (ok && r < rows_out) ? s * a.Lin + li : ZR;
+                aaddr[mb][tap] = row * LDAK + w * CPW + (lane >> 4);
+            }
+        }
+        int srow8[NP];                       // (sample of staged row) * 8, for the GN table
+#pragma unroll
+        for (int p = 0; p < NP; ++p) srow8[p] = (min(r0 + RPP * p, rows_in - 1) / a.Lin) * 8;
+
+        auto store_a = [&](int ch, int buf, const float4 (&av)[NP]) {
+            int cl, C, ld;
+            (void)src_ptr(ch, cl, C, ld);
+            const bool cok = cl < C;
+            const int clc = min(cl, C - 4);
+            float* dst = As[buf];
+            const float4 g = pg, bt = pb, tb = ptb;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int r = r0 + RPP * p;
+                float4 v = av[p];
+                if constexpr (MODE == SRC_GN_MISH) {
+                    const int ti = (srow8[p] + clc / a.src[0].gw) * 2;
+                    const float m = tabA[ti], rs = tabA[ti + 1];
+                    v.x = mish_f((v.x - m) * rs * g.x + bt.x) + tb.x;
+                    v.y = mish_f((v.y - m) * rs * g.y + bt.y) + tb.y;
+                    v.z = mish_f((v.z - m) * rs * g.z + bt.z) + tb.z;
+                    v.w = mish_f((v.w - m) * rs * g.w + bt.w) + tb.w;
+                } else if constexpr (MODE == SRC_LN) {
+                    const int rc = min(r, rows_in - 1);
+                    const float m = tabA[2 * rc], rs = tabA[2 * rc + 1];
+                    v.x = (v.x - m) * rs * g.x; v.y = (v.y - m) * rs * g.y;
+                    v.z = (v.z - m) * rs * g.z; v.w = (v.w - m) * rs * g.w;
+                } else if constexpr (MODE == SRC_MISH) {
+                    v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w);
+                }
+                const bool ok = rok[p] && cok;              // zero padding is applied AFTER the activation
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                float2* d2 = reinterpret_cast<float2*>(dst + r * LDAK + c4 * 4);
                 d2[0] = make_float2(v.x, v.y);
                 d2[1] = make_float2(v.z, v.w);
             }
         };
 
-        float bcur[2 * T][2], bnxt[2 * T][2];
-        auto load_b = [&](int ch, float (&b)[2 * T][2]) {
-#pragma unroll
-            for (int tap = 0; tap < T; ++tap)
-#pragma unroll
-                for (int cs = 0; cs < 2; ++cs) {
-                    const size_t krow = (size_t)tap * a.CinP + ch * KC + w * 8 + cs * 4 + (lane >> 4);
-                    const float* wp = a.W + krow * a.Npad + n0 + (lane & 15);
-                    b[tap * 2 + cs][0] = wp[0];
-                    b[tap * 2 + cs][1] = wp[16];
-                }
-        };
-
         __syncthreads();          // tables + zero rows visible
-        load_b(0, bcur);
-        stage_load(0);
-        stage_store(0);
+        store_a(0, 0, areg);
         __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            const bool more = ch + 1 < nch;
-            if (more) { load_b(ch + 1, bnxt); stage_load(ch + 1); }
-            const float* Ab = As[ch & 1];
-#pragma unroll
-            for (int tap = 0; tap < T; ++tap)
-#pragma unroll
-                for (int cs = 0; cs < 2; ++cs) {
-                    const float a0 = Ab[aaddr[0][tap] + cs * 4];
-                    const float a1 = Ab[aaddr[1][tap] + cs * 4];
-                    const float a2 = Ab[aaddr[2][tap] + cs * 4];
-                    const float b0v = bcur[tap * 2 + cs][0], b1v = bcur[tap * 2 + cs][1];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0v, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1v, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0v, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc[1][1], 0, 0, 0);
-                    acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0v, acc[2][0], 0, 0, 0);
-                    acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1v, acc[2][1], 0, 0, 0);
-                }
-            if (more) {
-                stage_store(ch + 1);
-#pragma unroll
-                for (int i = 0; i < 2 * T; ++i) { bcur[i][0] = bnxt[i][0]; bcur[i][1] = bnxt[i][1]; }
+        // one pipeline stage: prefetch stage ch+1 (B -> bn, A -> areg), multiply stage ch from LDS buffer ch&1 with bc,
+        // write the prefetched A rows to the other LDS buffer, barrier.  Two explicit B register sets alternate
+        // (no register copies: hipcc hoists a copy of in-flight registers above the MFMA block and stalls on it).
+        auto stage = [&](int ch, const float (&bc)[KS][2], float (&bn)[KS][2]) {
+            const int chn = min(ch + 1, nch - 1);          // tail: harmless re-load of the last stage
+            if constexpr (DBG != 1 && DBG != 5) {          // DBG 1/5: ablate the global loads (timing experiments only)
+                load_b(chn, bn);
+                load_a(chn, areg);
             }
+            __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ABOVE the MFMA block (hipcc sinks it otherwise)
+            const float* Ab = As[ch & 1];
+            if constexpr (DBG != 2) {                      // DBG 2: ablate the MFMA block
+#pragma unroll
+                for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) {
+                        float a0, a1, a2;
+                        if constexpr (DBG == 4 || DBG == 5) {      // DBG 4/5: no LDS reads (operands from registers)
+                            a0 = bc[tap * CS + cs][0] + 1.f; a1 = bc[tap * CS + cs][1] + 2.f; a2 = a0 + a1;
+                        } else {
+                            a0 = Ab[aaddr[0][tap] + cs * 4];
+                            a1 = Ab[aaddr[1][tap] + cs * 4];
+                            a2 = Ab[aaddr[2][tap] + cs * 4];
+                        }
+                        const float b0v = bc[tap * CS + cs][0], b1v = bc[tap * CS + cs][1];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0v, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1v, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0v, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc[1][1], 0, 0, 0);
+                        acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0v, acc[2][0], 0, 0, 0);
+                        acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1v, acc[2][1], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DBG != 3) store_a(chn, (ch + 1) & 1, areg);     // DBG 3: ablate the LDS staging store
             __syncthreads();
+        };
+        if constexpr (DBG == 7 || DBG == 8) {              // DBG 7: prologue + epilogue only
+        } else if (nch == 1) {
+            stage(0, bcur, bnxt);
+        } else {                                           // host guarantees an even stage count (pack_weight)
+            for (int ch = 0; ch < nch; ch += 2) {
+                stage(ch, bcur, bnxt);
+                stage(ch + 1, bnxt, bcur);
+            }
         }
     } else {
+        if (a.e_y) {
+            for (int i = tid; i < ns * 8; i += 256) {
+                float m, r;
+                merge_stats(a.e_stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * a.e_P * 2, a.e_P, a.e_cnt, 1e-5f, m, r);
+                tabE[2 * i] = m; tabE[2 * i + 1] = r;
+            }
+        }
         __syncthreads();
     }
 
     // ---- cross-wave K reduction through LDS --------------------------------------------------
     // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if constexpr (T > 0) {
 #pragma unroll
-    for (int mb = 0; mb < 3; ++mb)
+        for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
-    __syncthreads();
+                for (int rg = 0; rg < 4; ++rg)
+                    Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
+        __syncthreads();
+    }
 
     const int n = tid & 31, rq = tid >> 5;
     const int gn = n0 + n;
@@ -289,6 +349,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
     const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
     float eg = 1.f, eb = 0.f;
     if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
+    // issue the epilogue's global reads first, then combine
+    float ey[6], rs[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        ey[q] = 0.f; rs[q] = 0.f;
+        if (r < rows_out && nok) {
+            const size_t grow = (size_t)b0 * a.Lout + r;
+            if (a.e_y) ey[q] = a.e_y[grow * a.e_ld + gn];
+            if (a.res) rs[q] = a.res[grow * a.ldres + gn];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int r = rq + 8 * q;
@@ -300,10 +372,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
             if (a.e_y) {
                 const int s = r / a.Lout;
                 const int ti = (s * 8 + gn / a.e_gw) * 2;
-                const float y = a.e_y[grow * a.e_ld + gn];
-                v += mish_f((y - tabE[ti]) * tabE[ti + 1] * eg + eb);
+                v += mish_f((ey[q] - tabE[ti]) * tabE[ti + 1] * eg + eb);
             }
-            if (a.res) v += a.res[grow * a.ldres + gn];
+            if (a.res) v += rs[q];
             a.out[grow * a.ldo + gn] = v;
         } else {
             v = 0.f;
@@ -311,6 +382,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
         Red[0][r * LDR + n] = v;     // finished tile kept for the statistics passes (own slot only)
     }
 
+    if constexpr (DBG == 8) return;             // DBG 8: no statistics passes
     if (a.stats_out || a.ln_out) __syncthreads();
 
     if (a.stats_out) {

@@ -189,6 +189,20 @@ class TemporalUnet1D(nn.Module):
                                                        C.byref(fl)))
         return {k: (cnt[i], ms[i], fl[i]) for i, k in enumerate(self.KERNEL_KINDS)}
 
+    @torch.no_grad()
+    def profile_detail(self, x, t, cap=256):
+        """Per-launch records of one instrumented forward: [(kind, ms, flops, grid_x, grid_y, stages)]."""
+        self.sync_weights()
+        x = x.contiguous().float()
+        out = torch.empty_like(x)
+        ws = self.workspace(x.shape[0], x.device)
+        n = C.c_int32()
+        kind, ms, fl, g = (C.c_int32 * cap)(), (C.c_float * cap)(), (C.c_double * cap)(), (C.c_int32 * (3 * cap))()
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().cindm_unet1d_profile_detail(self._h, _ffi.ptr(x), int(t), _ffi.ptr(out), x.shape[0], _ffi.ptr(ws),
+                                                              ws.numel(), _ffi.current_stream(x.device), cap, C.byref(n), kind, ms, fl, g))
+        return [(self.KERNEL_KINDS[kind[i]], ms[i], fl[i], g[3 * i], g[3 * i + 1], g[3 * i + 2]) for i in range(n.value)]
+
     def tap(self, name, rows):
         """Intermediate activation of the last forward as [rows, C, L] (the reference's layout)."""
         shape = (C.c_int64 * 3)()

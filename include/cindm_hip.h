@@ -86,13 +86,20 @@ int  cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int3
 int  cindm_unet1d_tap(cindm_unet1d* h, const char* name, int64_t rows, void* ws, float* dst,
                       int64_t dst_cap, int64_t shape[3], void* stream);
 /* Instrumented forward for bench.py's roofline leg: as cindm_unet1d_forward, but every launch is
- * bracketed by HIP events recorded on `stream`; returns per kernel kind k
+ * issued 8 times back-to-back (launches are idempotent) inside one pair of HIP events recorded on `stream`,
+ * the bracket time divided by 8 being the launch's duration (this amortises the ~6 us cost of an event
+ * bracket and includes the dependent-launch gap a kernel also pays inside the sampling graph); returns per kernel kind k
  * (0..4 = conv_gemm_kernel<T> for T = 0,1,3,4,5; 5 = linattn_core_kernel) the launch count, the summed
  * duration in ms and the summed ALGORITHMIC FLOPs (2*M*N*K of the layer, no padding).
  * Synchronises `stream`. */
 int  cindm_unet1d_profile(cindm_unet1d* h, const float* x, int32_t t, float* eps, int64_t rows,
                           void* ws, size_t ws_bytes, void* stream,
                           int32_t counts[6], float ms[6], double flops[6]);
+/* Same, one record per launch in issue order (at most cap): kernel kind, duration ms, algorithmic FLOPs,
+ * and (grid.x, grid.y, pipeline stages) triples. */
+int  cindm_unet1d_profile_detail(cindm_unet1d* h, const float* x, int32_t t, float* eps, int64_t rows,
+                                 void* ws, size_t ws_bytes, void* stream, int32_t cap, int32_t* n_out,
+                                 int32_t* kind, float* ms, double* flops, int32_t* grid_xy_stages);
 /* Number of kernel launches one forward issues (for DESIGN/bench bookkeeping). */
 int  cindm_unet1d_launches_per_forward(const cindm_unet1d* h);
 
