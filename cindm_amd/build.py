@@ -28,7 +28,10 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libcindm_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB + ".tmp", SRC]
+    # -ffp-contract=off: elementwise expressions keep the reference's separate roundings (PyTorch evaluates them
+    # as distinct ops) and the step identities between compose modes stay bitwise; MFMA builtins are unaffected
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o",
+           LIB + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -127,7 +127,9 @@ static int build_manifest(cindm_unet1d* h) {
 extern "C" int cindm_unet1d_create(const cindm_unet1d_desc* desc, cindm_unet1d** out) {
     REQUIRE(desc && out, "null argument");
     REQUIRE(desc->n_mults >= 1 && desc->n_mults <= 8, "n_mults out of range");
-    REQUIRE(desc->dim % 32 == 0 && desc->dim >= 32, "dim must be a multiple of 32");
+    REQUIRE(desc->dim >= 32 && (desc->dim & (desc->dim - 1)) == 0, "dim must be a power of two >= 32");
+    for (int i = 0; i < desc->n_mults; ++i)
+        REQUIRE(desc->dim_mults[i] >= 1 && (desc->dim_mults[i] & (desc->dim_mults[i] - 1)) == 0, "dim_mults must be powers of two");
     REQUIRE(desc->transition_dim % 4 == 0 && desc->transition_dim >= 4 && desc->transition_dim <= 32,
             "transition_dim must be a multiple of 4 in [4, 32]");
     REQUIRE(desc->horizon >= 2 && desc->horizon <= TM, "horizon must be in [2, 48]");
@@ -300,6 +302,8 @@ struct Emitter {
         (void)lmax;
         a.t_ptr = t_ptr; a.t_imm = t_imm;
         a.nsrc = 1;
+        a.lout_magic = (65536 + Lout - 1) / Lout;
+        a.lin_magic = (65536 + Lin - 1) / Lin;
     }
     static void plain(Src& s, const Ten& t) { s.p = t.p; s.ld = t.ld; s.C = t.C; s.mode = SRC_PLAIN; s.P = 1; s.gw = 1; s.cnt = 1.f; }
 
@@ -815,6 +819,7 @@ struct StepIO {
     const float* x; const float* cond; float* mean_out; float* x0_out; float* eps_out; float* x_out;
     const float* noise; int64_t noise_t_stride; uint64_t seed; int64_t sample_off; int add_noise;
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
+    int dec_t;              // sample loop: decrement the device step counter at the end of the step
 };
 
 static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -846,6 +851,7 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.mean_out = io.mean_out; a.x0_out = io.x0_out; a.eps_out = io.eps_out; a.x_out = io.x_out;
     a.noise = io.noise; a.noise_t_stride = io.noise_t_stride; a.seed = io.seed; a.sample_off = io.sample_off; a.add_noise = io.add_noise;
     a.inp_cond = io.inp_cond; a.inp_steps = io.inp_steps; a.inp_noise = io.inp_noise; a.inp_noise_t_stride = io.inp_noise_t_stride;
+    if (io.dec_t) { a.t_dec = h->t_dev; a.done = reinterpret_cast<unsigned*>(h->t_dev + 1); }
 
     const float* unet_in = io.x;
     if (!s.direct) {
@@ -885,7 +891,7 @@ extern "C" int cindm_ddpm1d_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet
     return run_step(h, pair, uncond, c, io, t, t_dev, B, ws, ws_bytes, (hipStream_t)stream);
 }
 
-__global__ void set_counter_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+__global__ void set_counter_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = v; p[1] = 0; } }
 
 extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
                                    float* x, const float* cond, const float* noise_steps, uint64_t seed, int64_t sample_offset,
@@ -909,12 +915,12 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     io.noise = noise_steps; io.noise_t_stride = (int64_t)B * Ltot * F; io.seed = seed; io.sample_off = sample_offset; io.add_noise = 1;
     io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
+    io.dec_t = 1;
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)t_start);
     const int nsteps = t_start - t_end + 1;
     if (!use_graph) {
         for (int i = 0; i < nsteps; ++i) {
             if (run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream) != 0) return -1;
-            hipLaunchKernelGGL(dec_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev);
         }
         HIPCHK(hipGetLastError());
         return 0;
@@ -923,7 +929,6 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     hipGraphExec_t exec = nullptr;
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     int rc = run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream);
-    hipLaunchKernelGGL(dec_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev);
     hipError_t ce = hipStreamEndCapture(stream, &graph);
     if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
     if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));

@@ -59,6 +59,7 @@ struct GemmArgs {
     int CinP, Npad, N;
     int KC;               // channels per pipeline stage the weights were packed for (host-side dispatch)
     int Bp, Lin, Lout, stride, pad, transposed, spt;
+    int lout_magic, lin_magic;   // ceil(65536 / L): floor(r / L) == (r * magic) >> 16 for r < 256 (host: Emitter::base)
     float* out; int ldo;
     const float* res; int ldres;                         // + res
     const float* e_y; int e_ld; const float* e_stats;    // + Mish(GN(e_y))
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int mb = 0; mb < 3; ++mb) {
             const int r = mb * 16 + (lane & 15);
-            const int s = r / a.Lout, lo = r - s * a.Lout;
+            const int s = (r * a.lout_magic) >> 16, lo = r - s * a.Lout;
 #pragma unroll
             for (int tap = 0; tap < T; ++tap) {
                 int li; bool ok;
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
         }
         int srow8[NP];                       // (sample of staged row) * 8, for the GN table
 #pragma unroll
-        for (int p = 0; p < NP; ++p) srow8[p] = (min(r0 + RPP * p, rows_in - 1) / a.Lin) * 8;
+        for (int p = 0; p < NP; ++p) srow8[p] = ((min(r0 + RPP * p, rows_in - 1) * a.lin_magic) >> 16) * 8;
+        const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);      // group widths are powers of two (host checks)
 
         auto store_a = [&](int ch, int buf, const float4 (&av)[NP]) {
             int cl, C, ld;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
                 const int r = r0 + RPP * p;
                 float4 v = av[p];
                 if constexpr (MODE == SRC_GN_MISH) {
-                    const int ti = (srow8[p] + clc / a.src[0].gw) * 2;
+                    const int ti = (srow8[p] + (clc >> gw_shift)) * 2;
                     const float m = tabA[ti], rs = tabA[ti + 1];
                     v.x = mish_f((v.x - m) * rs * g.x + bt.x) + tb.x;
                     v.y = mish_f((v.y - m) * rs * g.y + bt.y) + tb.y;
@@ -370,8 +372,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
         if (r < rows_out && nok) {
             const size_t grow = (size_t)b0 * a.Lout + r;
             if (a.e_y) {
-                const int s = r / a.Lout;
-                const int ti = (s * 8 + gn / a.e_gw) * 2;
+                const int s = (r * a.lout_magic) >> 16;
+                const int ti = (s * 8 + (gn >> (31 - __builtin_clz(a.e_gw)))) * 2;
                 v += mish_f((ey[q] - tabE[ti]) * tabE[ti + 1] * eg + eb);
             }
             if (a.res) v += rs[q];
@@ -386,31 +388,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
     if (a.stats_out || a.ln_out) __syncthreads();
 
     if (a.stats_out) {
-        // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group part).
-        const int gwt = min(a.so_gw, TN);             // group columns inside this tile
-        const int ngt = TN / gwt;                     // groups (or one part of a group) per tile
+        // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group or 32-column part of it).
+        // Thread (n = tid & 31, rg = tid >> 5) sums column n over the rows of samples rg, rg + 8, ...; the gwt
+        // columns of a group are adjacent lanes -> deterministic xor-shuffle reduction.  Two passes (mean, then M2).
+        const int gwt = min(a.so_gw, TN);             // group columns inside this tile (power of two)
         const int P = max(1, a.so_gw / TN);           // partials per statistic
-        const int S = a.spt * ngt;
-        const int ne = a.Lout * gwt;
-        int tps = 1;
-        while (tps * 2 * S <= 256 && tps < 64) tps <<= 1;
-        const int si = tid / tps, u = tid - si * tps;
-        const bool act = si < S;
-        const int s = act ? si / ngt : 0, gl = act ? si - (si / ngt) * ngt : 0;
-        float sum = 0.f;
-        if (act)
-            for (int e = u; e < ne; e += tps) { const int l = e / gwt, c = e - l * gwt; sum += Red[0][(s * a.Lout + l) * LDR + gl * gwt + c]; }
-        sum = wave_sum_seg(sum, tps);
-        const float mean = sum / (float)ne;
-        float m2 = 0.f;
-        if (act)
-            for (int e = u; e < ne; e += tps) { const int l = e / gwt, c = e - l * gwt; const float d = Red[0][(s * a.Lout + l) * LDR + gl * gwt + c] - mean; m2 += d * d; }
-        m2 = wave_sum_seg(m2, tps);
-        if (act && u == 0 && s < ns) {
-            const int g = (n0 + gl * gwt) / a.so_gw;
-            const int p = (n0 / TN) % P;
-            float* o = a.stats_out + (((size_t)(b0 + s) * 8 + g) * P + p) * 2;
-            o[0] = mean; o[1] = m2;
+        const float inv_ne = 1.0f / (float)(a.Lout * gwt);
+        for (int sidx = rq; sidx < a.spt; sidx += 8) {
+            const float* col = &Red[0][sidx * a.Lout * LDR + n];
+            float sum = 0.f;
+            for (int l = 0; l < a.Lout; ++l) sum += col[l * LDR];
+            sum = wave_sum_seg(sum, gwt);
+            const float mean = sum * inv_ne;
+            float m2 = 0.f;
+            for (int l = 0; l < a.Lout; ++l) { const float d = col[l * LDR] - mean; m2 += d * d; }
+            m2 = wave_sum_seg(m2, gwt);
+            if ((n & (gwt - 1)) == 0 && sidx < ns) {
+                const int g = (n0 + n) >> (31 - __builtin_clz(a.so_gw));
+                const int p = (n0 / TN) & (P - 1);
+                float* o = a.stats_out + (((size_t)(b0 + sidx) * 8 + g) * P + p) * 2;
+                o[0] = mean; o[1] = m2;
+            }
         }
     }
     if (a.ln_out) {
@@ -551,6 +549,7 @@ struct ComposeArgs {
     const float* noise; int64_t noise_t_stride;        // explicit noise (+ t * stride), or null
     uint64_t seed; int64_t sample_off; int add_noise;
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
+    int* t_dec; unsigned* done;     // sample loop: the last block to finish decrements the device step counter
 };
 
 __device__ __forceinline__ int pair_index(int i, int j, int nb) {   // i < j, order (0,1),(0,2),..,(1,2),..
@@ -603,12 +602,12 @@ __global__ void compose_gather_kernel(const ComposeArgs a) {
 __global__ void compose_update_kernel(const ComposeArgs a) {
     const int Lfull = a.Ltot + a.cond_steps;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B * (int64_t)a.Ltot * a.F) return;
+    const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
+    if (i < a.B * (int64_t)a.Ltot * a.F) {
     const int f = (int)(i % a.F);
     const int lx = (int)((i / a.F) % a.Ltot);
     const int64_t b = i / ((int64_t)a.F * a.Ltot);
     const int l = lx + a.cond_steps;             // row in the full sequence
-    const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
     const int body = f >> 2, comp = f & 3;
     const int P = a.nb * (a.nb - 1) / 2;
     const float xv = a.x[i];
@@ -622,13 +621,16 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         const int64_t row = ((int64_t)kk * P + p) * a.B + b;
         return a.pair_eps[(row * a.T + lw) * 8 + slot * 4 + comp];
     };
+    // explicit roundings (no FMA contraction): the reference evaluates these as separate elementwise ops, and the
+    // step identities (outside/mean == inside == plain for one window, one pair) must hold bitwise
     auto x0_of = [&](float eps_or_out) -> float {
         float x0;
-        if (a.objective == 0) x0 = ra * xv - rb * eps_or_out;
+        if (a.objective == 0) x0 = __fsub_rn(__fmul_rn(ra, xv), __fmul_rn(rb, eps_or_out));
         else if (a.objective == 1) x0 = eps_or_out;
-        else x0 = a.sqrt_ac[t] * xv - a.sqrt_1mac[t] * eps_or_out;
+        else x0 = __fsub_rn(__fmul_rn(a.sqrt_ac[t], xv), __fmul_rn(a.sqrt_1mac[t], eps_or_out));
         return x0;
     };
+    auto post_mean = [&](float x0v) -> float { return __fadd_rn(__fmul_rn(c1, x0v), __fmul_rn(c2, xv)); };
 
     float eps = 0.f, x0 = 0.f, mean = 0.f;
     int cover = 0;
@@ -639,7 +641,7 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         x0 = x0_of(o);
         eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
         if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-        mean = c1 * x0 + c2 * xv;
+        mean = post_mean(x0);
     } else if (a.mode == 1 || a.mode == 2 || a.mode == 4) {
         // eps aggregated over senders then windows (model/diffusion_1d.py:994-999, :1457-1458)
         float tot = 0.f;
@@ -655,7 +657,7 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         x0 = x0_of(o);
         eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
         if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-        mean = c1 * x0 + c2 * xv;
+        mean = post_mean(x0);
     } else if (a.mode == 3) {
         // p_mean_variance per (window, pair), then average mean and x0 (:1436-1452)
         float tm = 0.f, tx = 0.f, te = 0.f;
@@ -668,7 +670,7 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
                 const float e = pair_eps_at(kk, o, lw);
                 float x0e = x0_of(e);
                 if (a.clip) x0e = fminf(fmaxf(x0e, -1.f), 1.f);
-                sm += c1 * x0e + c2 * xv; sx += x0e; se += e;
+                sm += post_mean(x0e); sx += x0e; se += e;
             }
             tm += sm / (float)(a.nb - 1); tx += sx / (float)(a.nb - 1); te += se / (float)(a.nb - 1);
         }
@@ -681,7 +683,7 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         x0 = x0_of(o);
         eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
         if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-        mean = c1 * x0 + c2 * xv;
+        mean = post_mean(x0);
     }
 
     if (a.mean_out) a.mean_out[i] = mean;
@@ -702,6 +704,15 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
             v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z;
         }
         a.x_out[i] = v;
+    }
+    }
+    if (a.t_dec) {
+        // every block has read t before it arrives here; the last arriver publishes t - 1 for the next graph replay
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(a.done, 1u) == gridDim.x - 1) { *a.done = 0u; *a.t_dec = t - 1; }
+        }
     }
 }
 
