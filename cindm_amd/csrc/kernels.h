@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cindm {
 
@@ -58,6 +59,7 @@ struct GemmArgs {
     const float* bias;    // [Npad] or null
     int CinP, Npad, N;
     int KC;               // channels per pipeline stage the weights were packed for (host-side dispatch)
+    int h3;               // weights packed as split fp16 (hi, scaled lo) for conv_gemm_h3_kernel
     int Bp, Lin, Lout, stride, pad, transposed, spt;
     int lout_magic, lin_magic;   // ceil(65536 / L): floor(r / L) == (r * magic) >> 16 for r < 256 (host: Emitter::base)
     float* out; int ldo;
@@ -98,6 +100,117 @@ __device__ __forceinline__ void merge_stats(const float* st, int P, float cnt, f
     }
     mean = m;
     rstd = 1.0f / sqrtf(M2 / (cnt * (float)P) + eps);
+}
+
+// Shared epilogue of the GEMM kernels: cross-wave K reduction through LDS, bias, optional "+ Mish(GroupNorm(y))"
+// and "+ residual" terms, store, and (mean, M2) statistics of the output tile (GroupNorm / LayerNorm partials).
+template <bool HAS_ACC>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3][2], float (*Red)[TM * LDR], const float* tabE,
+                                              bool skip_stats) {
+    constexpr int T = HAS_ACC ? 1 : 0;
+    constexpr int DBG = 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int b0 = mt * a.spt;
+    const int ns = min(a.spt, a.Bp - b0);
+    const int rows_out = ns * a.Lout;
+    const int n0 = nt * TN;
+    // ---- cross-wave K reduction through LDS --------------------------------------------------
+    // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if constexpr (T > 0) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
+        __syncthreads();
+    }
+
+    const int n = tid & 31, rq = tid >> 5;
+    const int gn = n0 + n;
+    const bool nok = gn < a.N;
+    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+    float eg = 1.f, eb = 0.f;
+    if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
+    // issue the epilogue's global reads first, then combine
+    float ey[6], rs[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        ey[q] = 0.f; rs[q] = 0.f;
+        if (r < rows_out && nok) {
+            const size_t grow = (size_t)b0 * a.Lout + r;
+            if (a.e_y) ey[q] = a.e_y[grow * a.e_ld + gn];
+            if (a.res) rs[q] = a.res[grow * a.ldres + gn];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        float v = 0.f;
+        if (T > 0) v = (Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n]);
+        v += bias;
+        if (r < rows_out && nok) {
+            const size_t grow = (size_t)b0 * a.Lout + r;
+            if (a.e_y) {
+                const int s = (r * a.lout_magic) >> 16;
+                const int ti = (s * 8 + (gn >> (31 - __builtin_clz(a.e_gw)))) * 2;
+                v += mish_f((ey[q] - tabE[ti]) * tabE[ti + 1] * eg + eb);
+            }
+            if (a.res) v += rs[q];
+            a.out[grow * a.ldo + gn] = v;
+        } else {
+            v = 0.f;
+        }
+        Red[0][r * LDR + n] = v;     // finished tile kept for the statistics passes (own slot only)
+    }
+
+    if (skip_stats) return;                     // DBG 8: no statistics passes
+    if (a.stats_out || a.ln_out) __syncthreads();
+
+    if (a.stats_out) {
+        // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group or 32-column part of it).
+        // Thread (n = tid & 31, rg = tid >> 5) sums column n over the rows of samples rg, rg + 8, ...; the gwt
+        // columns of a group are adjacent lanes -> deterministic xor-shuffle reduction.  Two passes (mean, then M2).
+        const int gwt = min(a.so_gw, TN);             // group columns inside this tile (power of two)
+        const int P = max(1, a.so_gw / TN);           // partials per statistic
+        const float inv_ne = 1.0f / (float)(a.Lout * gwt);
+        for (int sidx = rq; sidx < a.spt; sidx += 8) {
+            const float* col = &Red[0][sidx * a.Lout * LDR + n];
+            float sum = 0.f;
+            for (int l = 0; l < a.Lout; ++l) sum += col[l * LDR];
+            sum = wave_sum_seg(sum, gwt);
+            const float mean = sum * inv_ne;
+            float m2 = 0.f;
+            for (int l = 0; l < a.Lout; ++l) { const float d = col[l * LDR] - mean; m2 += d * d; }
+            m2 = wave_sum_seg(m2, gwt);
+            if ((n & (gwt - 1)) == 0 && sidx < ns) {
+                const int g = (n0 + n) >> (31 - __builtin_clz(a.so_gw));
+                const int p = (n0 / TN) & (P - 1);
+                float* o = a.stats_out + (((size_t)(b0 + sidx) * 8 + g) * P + p) * 2;
+                o[0] = mean; o[1] = m2;
+            }
+        }
+    }
+    if (a.ln_out) {
+        // LayerNorm partial statistics per output row over this tile's 32 columns.
+        const int r = tid >> 2, sub = tid & 3;
+        float sum = 0.f;
+        if (r < TM)
+            for (int c = sub * 8; c < sub * 8 + 8; ++c) sum += Red[0][r * LDR + c];
+        sum = wave_sum_seg(sum, 4);
+        const float mean = sum * (1.0f / 32.0f);
+        float m2 = 0.f;
+        if (r < TM)
+            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - mean; m2 += d * d; }
+        m2 = wave_sum_seg(m2, 4);
+        if (sub == 0 && r < rows_out) {
+            float* o = a.ln_out + (((size_t)b0 * a.Lout + r) * (a.Npad / TN) + nt) * 2;
+            o[0] = mean; o[1] = m2;
+        }
+    }
 }
 
 // Pipeline: stage = KC input channels x all T taps.  While stage ch is multiplied, the B fragments and the
@@ -332,102 +445,236 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- cross-wave K reduction through LDS --------------------------------------------------
-    // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
-    if constexpr (T > 0) {
+    gemm_epilogue<(T > 0)>(a, acc, Red, tabE, DBG == 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_gemm_h3_kernel: the same implicit GEMM with every fp32 product a*b evaluated on the fp16 matrix cores as
+//     a*b ~= ah*bh + 2^-11 * (ah*bl' + al'*bh),   ah = fp16(a), al' = fp16((a - ah) * 2^11)   (same for b)
+// three v_mfma_f32_16x16x32_f16 with fp32 accumulation (two accumulator sets: main, and the 2^11-scaled low-order
+// terms).  a - ah is exact in fp32, the scaling keeps al' out of the fp16 subnormal range, the products of two
+// 11-bit significands are exact in the fp32 accumulator, so the only losses are the roundings of al', bl' (2^-24
+// relative to a, b) and the dropped al*bl (2^-24): fp32-faithful, at 16/3 of the fp32 MFMA rate.
+// Stage = 128 input channels (one 32-channel k-group per wave) x T taps.  A is staged as two fp16 planes
+// (hi, scaled lo) and read as ds_read_b128 fragments; B (pre-split and packed on the host in fragment order) is
+// re-loaded tap by tap for the next stage right after its last use, so its prefetch distance is T-1 taps.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
+
+template <int T, int ROWS, int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
+    constexpr int KC = 128;
+    constexpr int PITCH = 272;              // bytes per LDS row per plane: 128 halfs + 16 B pad
+    constexpr int F4R = KC / 4;             // float4 per staged row (32)
+    constexpr int RPP = 256 / F4R;          // rows per staging pass (8)
+    constexpr int NP = (ROWS + RPP - 1) / RPP;
+    constexpr int LROWS = NP * RPP;
+    constexpr int ZR = LROWS;
+    constexpr int PLANE = (LROWS + 1) * PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][2][PLANE];      // [buffer][plane hi/lo]
+    __shared__ __attribute__((aligned(16))) float Red[4][TM * LDR];
+    __shared__ float tabA[TM * 8 * 2];
+    __shared__ float tabE[TM * 8 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int b0 = mt * a.spt;
+    const int ns = min(a.spt, a.Bp - b0);
+    const int rows_out = ns * a.Lout;
+    const int rows_in = ns * a.Lin;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+
+    f32x4 accM[3][2], accL[3][2];
 #pragma unroll
-        for (int mb = 0; mb < 3; ++mb)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+        for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nch0 = (a.src[0].C + KC - 1) / KC;
+    const int nch = a.CinP / KC;
+    const int c4 = tid % F4R, r0 = tid / F4R;
+    size_t goff[NP];
+    bool rok[NP];
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
+    for (int p = 0; p < NP; ++p) {
+        const int r = r0 + RPP * p;
+        rok[p] = r < rows_in;
+        goff[p] = (size_t)(b0 * a.Lin + min(r, rows_in - 1));
+    }
+
+    // B: [n-tile][stage][q = (tap*2 + nb)*2 + plane][thread][8 halfs]
+    half8 breg[T][2][2];
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)nt * nch * (T * 4) * 256 + tid;
+    auto load_b_tap = [&](int ch, int tap) {
+        const uint4* wp = wbase + ((size_t)ch * (T * 4) + tap * 4) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = wp[q * 256];
+            breg[tap][q >> 1][q & 1] = __builtin_bit_cast(half8, v);
+        }
+    };
+    float4 areg[NP];
+    float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), ptb = pb;
+    auto src_ptr = [&](int ch, int& cl, int& C, int& ld) -> const float* {
+        const bool first = (ch < nch0) || (a.nsrc == 1);
+        cl = (first ? ch : ch - nch0) * KC + c4 * 4;
+        C = first ? a.src[0].C : a.src[1].C;
+        ld = first ? a.src[0].ld : a.src[1].ld;
+        return first ? a.src[0].p : a.src[1].p;
+    };
+    auto load_a = [&](int ch) {
+        int cl, C, ld;
+        const float* base = src_ptr(ch, cl, C, ld);
+        const int clc = min(cl, C - 4);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            areg[p] = *reinterpret_cast<const float4*>(base + goff[p] * ld + clc);
+        if constexpr (MODE == SRC_GN_MISH || MODE == SRC_LN) {
+            const Src& s = a.src[0];
+            pg = *reinterpret_cast<const float4*>(s.gamma + clc);
+            if constexpr (MODE == SRC_GN_MISH) {
+                pb = *reinterpret_cast<const float4*>(s.beta + clc);
+                if (s.tb) ptb = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + clc);
+            }
+        }
+    };
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
+    load_a(0);
+
+    for (int i = tid; i < 4 * (PITCH / 4); i += 256)
+        reinterpret_cast<float*>(&Ah[(i / (PITCH / 4)) >> 1][(i / (PITCH / 4)) & 1][ZR * PITCH])[i % (PITCH / 4)] = 0.f;
+    if constexpr (MODE == SRC_GN_MISH) {
+        const Src& s = a.src[0];
+        for (int i = tid; i < ns * 8; i += 256) {
+            float m, r;
+            merge_stats(s.stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
+            tabA[2 * i] = m; tabA[2 * i + 1] = r;
+        }
+    } else if constexpr (MODE == SRC_LN) {
+        const Src& s = a.src[0];
+        for (int i = tid; i < rows_in; i += 256) {
+            float m, r;
+            merge_stats(s.stats + (size_t)(b0 * a.Lin + i) * s.P * 2, s.P, s.cnt, 1e-5f, m, r);
+            tabA[2 * i] = m; tabA[2 * i + 1] = r;
+        }
+    }
+    if (a.e_y) {
+        for (int i = tid; i < ns * 8; i += 256) {
+            float m, r;
+            merge_stats(a.e_stats + ((size_t)(b0 + i / 8) * 8 + (i & 7)) * a.e_P * 2, a.e_P, a.e_cnt, 1e-5f, m, r);
+            tabE[2 * i] = m; tabE[2 * i + 1] = r;
+        }
+    }
+
+    // per-lane A fragment byte offsets inside one plane: row(i, tap) * PITCH + (wave's k-group) * 64 + (lane>>4) * 16
+    int aaddr[3][T];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        const int r = mb * 16 + (lane & 15);
+        const int s = (r * a.lout_magic) >> 16, lo = r - s * a.Lout;
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            int li; bool ok;
+            if (!a.transposed) { li = lo * a.stride + tap - a.pad; ok = (li >= 0) && (li < a.Lin); }
+            else { const int q = lo + a.pad - tap; li = q >> 1; ok = (q >= 0) && !(q & 1) && (li < a.Lin); }
+            const int row = (ok && r < rows_out) ? s * a.Lin + li : ZR;
+            aaddr[mb][tap] = row * PITCH + w * 64 + (lane >> 4) * 16;
+        }
+    }
+    int srow8[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) srow8[p] = ((min(r0 + RPP * p, rows_in - 1) * a.lin_magic) >> 16) * 8;
+    const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
+
+    auto store_a = [&](int ch, int buf, int p_lo, int p_hi) {      // staging rows [p_lo, p_hi) of the NP per thread
+        int cl, C, ld;
+        (void)src_ptr(ch, cl, C, ld);
+        const bool cok = cl < C;
+        const int clc = min(cl, C - 4);
+        const float4 g = pg, bt = pb, tb = ptb;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p < p_lo || p >= p_hi) continue;      // constant-folded: callers pass compile-time ranges after unrolling
+            const int r = r0 + RPP * p;
+            float4 v = areg[p];
+            if constexpr (MODE == SRC_GN_MISH) {
+                const int ti = (srow8[p] + (clc >> gw_shift)) * 2;
+                const float m = tabA[ti], rs = tabA[ti + 1];
+                v.x = mish_f((v.x - m) * rs * g.x + bt.x) + tb.x;
+                v.y = mish_f((v.y - m) * rs * g.y + bt.y) + tb.y;
+                v.z = mish_f((v.z - m) * rs * g.z + bt.z) + tb.z;
+                v.w = mish_f((v.w - m) * rs * g.w + bt.w) + tb.w;
+            } else if constexpr (MODE == SRC_LN) {
+                const int rc = min(r, rows_in - 1);
+                const float m = tabA[2 * rc], rs = tabA[2 * rc + 1];
+                v.x = (v.x - m) * rs * g.x; v.y = (v.y - m) * rs * g.y;
+                v.z = (v.z - m) * rs * g.z; v.w = (v.w - m) * rs * g.w;
+            } else if constexpr (MODE == SRC_MISH) {
+                v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w);
+            }
+            const bool ok = rok[p] && cok;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&Ah[buf][0][r * PITCH + c4 * 8]) = hi;
+            *reinterpret_cast<half4v*>(&Ah[buf][1][r * PITCH + c4 * 8]) = lo;
+        }
+    };
+
+    __syncthreads();
+    store_a(0, 0, 0, NP);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int chn = min(ch + 1, nch - 1);
+        load_a(chn);
+        const unsigned char* P0 = Ah[ch & 1][0];
+        const unsigned char* P1 = Ah[ch & 1][1];
+        // A fragments are read one tap AHEAD of their use into an explicit second register set (hipcc otherwise
+        // re-uses one set and exposes the LDS latency in front of every 6 MFMAs)
+        half8 fh[2][3], fl[2][3];
+        auto read_frags = [&](int tap, half8 (&ah)[3], half8 (&al)[3]) {
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb) {
+                ah[mb] = *reinterpret_cast<const half8*>(P0 + aaddr[mb][tap]);
+                al[mb] = *reinterpret_cast<const half8*>(P1 + aaddr[mb][tap]);
+            }
+        };
+        read_frags(0, fh[0], fl[0]);
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            if (tap + 1 < T) read_frags(tap + 1, fh[(tap + 1) & 1], fl[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 (&ah)[3] = fh[tap & 1];
+            const half8 (&al)[3] = fl[tap & 1];
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], breg[tap][nb][0], accM[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], breg[tap][nb][1], accL[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], breg[tap][nb][0], accL[mb][nb], 0, 0, 0);
+                }
+            load_b_tap(chn, tap);          // next stage's fragments for this tap, T-1 taps ahead of their use
+            // the next stage's A rows are normalised / split / written to the other LDS buffer in slices that sit in
+            // the same scheduling region as this tap's MFMAs, so their VALU work fills the MFMA shadows
+            if constexpr (T >= 3) {
+                if (tap >= 1) store_a(chn, (ch + 1) & 1, ((tap - 1) * NP) / (T - 1), (tap * NP) / (T - 1));
+            }
+        }
+        if constexpr (T < 3) store_a(chn, (ch + 1) & 1, 0, NP);
         __syncthreads();
     }
 
-    const int n = tid & 31, rq = tid >> 5;
-    const int gn = n0 + n;
-    const bool nok = gn < a.N;
-    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
-    float eg = 1.f, eb = 0.f;
-    if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
-    // issue the epilogue's global reads first, then combine
-    float ey[6], rs[6];
+    f32x4 acc[3][2];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int r = rq + 8 * q;
-        ey[q] = 0.f; rs[q] = 0.f;
-        if (r < rows_out && nok) {
-            const size_t grow = (size_t)b0 * a.Lout + r;
-            if (a.e_y) ey[q] = a.e_y[grow * a.e_ld + gn];
-            if (a.res) rs[q] = a.res[grow * a.ldres + gn];
-        }
-    }
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int r = rq + 8 * q;
-        float v = 0.f;
-        if (T > 0) v = (Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n]);
-        v += bias;
-        if (r < rows_out && nok) {
-            const size_t grow = (size_t)b0 * a.Lout + r;
-            if (a.e_y) {
-                const int s = (r * a.lout_magic) >> 16;
-                const int ti = (s * 8 + (gn >> (31 - __builtin_clz(a.e_gw)))) * 2;
-                v += mish_f((ey[q] - tabE[ti]) * tabE[ti + 1] * eg + eb);
-            }
-            if (a.res) v += rs[q];
-            a.out[grow * a.ldo + gn] = v;
-        } else {
-            v = 0.f;
-        }
-        Red[0][r * LDR + n] = v;     // finished tile kept for the statistics passes (own slot only)
-    }
-
-    if constexpr (DBG == 8) return;             // DBG 8: no statistics passes
-    if (a.stats_out || a.ln_out) __syncthreads();
-
-    if (a.stats_out) {
-        // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group or 32-column part of it).
-        // Thread (n = tid & 31, rg = tid >> 5) sums column n over the rows of samples rg, rg + 8, ...; the gwt
-        // columns of a group are adjacent lanes -> deterministic xor-shuffle reduction.  Two passes (mean, then M2).
-        const int gwt = min(a.so_gw, TN);             // group columns inside this tile (power of two)
-        const int P = max(1, a.so_gw / TN);           // partials per statistic
-        const float inv_ne = 1.0f / (float)(a.Lout * gwt);
-        for (int sidx = rq; sidx < a.spt; sidx += 8) {
-            const float* col = &Red[0][sidx * a.Lout * LDR + n];
-            float sum = 0.f;
-            for (int l = 0; l < a.Lout; ++l) sum += col[l * LDR];
-            sum = wave_sum_seg(sum, gwt);
-            const float mean = sum * inv_ne;
-            float m2 = 0.f;
-            for (int l = 0; l < a.Lout; ++l) { const float d = col[l * LDR] - mean; m2 += d * d; }
-            m2 = wave_sum_seg(m2, gwt);
-            if ((n & (gwt - 1)) == 0 && sidx < ns) {
-                const int g = (n0 + n) >> (31 - __builtin_clz(a.so_gw));
-                const int p = (n0 / TN) & (P - 1);
-                float* o = a.stats_out + (((size_t)(b0 + sidx) * 8 + g) * P + p) * 2;
-                o[0] = mean; o[1] = m2;
-            }
-        }
-    }
-    if (a.ln_out) {
-        // LayerNorm partial statistics per output row over this tile's 32 columns.
-        const int r = tid >> 2, sub = tid & 3;
-        float sum = 0.f;
-        if (r < TM)
-            for (int c = sub * 8; c < sub * 8 + 8; ++c) sum += Red[0][r * LDR + c];
-        sum = wave_sum_seg(sum, 4);
-        const float mean = sum * (1.0f / 32.0f);
-        float m2 = 0.f;
-        if (r < TM)
-            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - mean; m2 += d * d; }
-        m2 = wave_sum_seg(m2, 4);
-        if (sub == 0 && r < rows_out) {
-            float* o = a.ln_out + (((size_t)b0 * a.Lout + r) * (a.Npad / TN) + nt) * 2;
-            o[0] = mean; o[1] = m2;
-        }
-    }
+        for (int j = 0; j < 2; ++j) acc[i][j] = accM[i][j] + accL[i][j] * H3_INV;
+    gemm_epilogue<true>(a, acc, Red, tabE, false);
 }
 
 // ---------------------------------------------------------------------------------------------
