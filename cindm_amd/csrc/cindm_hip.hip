@@ -369,6 +369,8 @@ struct Emitter {
         // profile mode: the (idempotent) launch is repeated inside one event bracket so that the ~6 us cost of the
         // bracket itself is amortised; the reported time is bracket / prof_reps
         for (int rep = 0; rep < (prof ? prof_reps : 1); ++rep) {
+        static const int dbg_h3 = getenv("CINDM_DBG") ? atoi(getenv("CINDM_DBG")) : 0;
+        const_cast<GemmArgs&>(a).dbg = a.h3 ? dbg_h3 : 0;
         if (a.h3 && T == 5 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
         else if (a.h3 && T == 5 && mode == SRC_GN_MISH) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_GN_MISH>), grid, dim3(256), 0, stream, a);
         else if (a.h3) ok = false;

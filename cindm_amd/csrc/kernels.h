@@ -60,6 +60,7 @@ struct GemmArgs {
     int CinP, Npad, N;
     int KC;               // channels per pipeline stage the weights were packed for (host-side dispatch)
     int h3;               // weights packed as split fp16 (hi, scaled lo) for conv_gemm_h3_kernel
+    int dbg;              // timing ablations of the h3 kernel (CINDM_DBG; results are wrong when set)
     int Bp, Lin, Lout, stride, pad, transposed, spt;
     int lout_magic, lin_magic;   // ceil(65536 / L): floor(r / L) == (r * magic) >> 16 for r < 256 (host: Emitter::base)
     float* out; int ldo;
@@ -85,6 +86,22 @@ __device__ __forceinline__ float mish_f(float x) {
 __device__ __forceinline__ float wave_sum_seg(float v, int seg) {
     // deterministic butterfly sum over aligned lane segments of size seg (power of two <= 64)
     for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Segmented lane reduction on the DPP network (no LDS round trips): after the call the LAST lane of every aligned
+// seg-lane segment (seg = 4, 8, 16 or 32) holds the segment's sum, accumulated in a fixed order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float seg_total(float v, int seg) {
+    v = dpp_add<0x111, 0xf>(v);                    // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);                    // row_shr:2   -> 4-lane sums at lanes 3 (mod 4)
+    if (seg >= 8) v = dpp_add<0x114, 0xf>(v);      // row_shr:4   -> 8-lane sums at lanes 7 (mod 8)
+    if (seg >= 16) v = dpp_add<0x118, 0xf>(v);     // row_shr:8   -> 16-lane sums at lane 15 of each row
+    if (seg >= 32) v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3 -> 32-lane sums at lanes 31, 63
     return v;
 }
 
@@ -172,43 +189,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3]
 
     if (a.stats_out) {
         // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group or 32-column part of it).
-        // Thread (n = tid & 31, rg = tid >> 5) sums column n over the rows of samples rg, rg + 8, ...; the gwt
-        // columns of a group are adjacent lanes -> deterministic xor-shuffle reduction.  Two passes (mean, then M2).
+        // Thread (n = tid & 31, rq = tid >> 5) accumulates column n over the rows of samples rq, rq + 8, ... as sums
+        // of (x - K) and (x - K)^2 around a pivot K taken from the data (one pass, no cancellation); the gwt columns
+        // of a group are adjacent lanes and are combined on the DPP network in a fixed order.
         const int gwt = min(a.so_gw, TN);             // group columns inside this tile (power of two)
         const int P = max(1, a.so_gw / TN);           // partials per statistic
-        const float inv_ne = 1.0f / (float)(a.Lout * gwt);
+        const float ne = (float)(a.Lout * gwt), inv_ne = 1.0f / ne;
         for (int sidx = rq; sidx < a.spt; sidx += 8) {
             const float* col = &Red[0][sidx * a.Lout * LDR + n];
-            float sum = 0.f;
-            for (int l = 0; l < a.Lout; ++l) sum += col[l * LDR];
-            sum = wave_sum_seg(sum, gwt);
-            const float mean = sum * inv_ne;
-            float m2 = 0.f;
-            for (int l = 0; l < a.Lout; ++l) { const float d = col[l * LDR] - mean; m2 += d * d; }
-            m2 = wave_sum_seg(m2, gwt);
-            if ((n & (gwt - 1)) == 0 && sidx < ns) {
+            const float K = Red[0][sidx * a.Lout * LDR + (n & ~(gwt - 1))];
+            float s1 = 0.f, s2 = 0.f;
+            for (int l = 0; l < a.Lout; ++l) { const float d = col[l * LDR] - K; s1 += d; s2 += d * d; }
+            s1 = seg_total(s1, gwt);
+            s2 = seg_total(s2, gwt);
+            if ((n & (gwt - 1)) == gwt - 1 && sidx < ns) {
                 const int g = (n0 + n) >> (31 - __builtin_clz(a.so_gw));
                 const int p = (n0 / TN) & (P - 1);
                 float* o = a.stats_out + (((size_t)(b0 + sidx) * 8 + g) * P + p) * 2;
-                o[0] = mean; o[1] = m2;
+                o[0] = K + s1 * inv_ne;
+                o[1] = fmaxf(s2 - s1 * s1 * inv_ne, 0.f);
             }
         }
     }
     if (a.ln_out) {
-        // LayerNorm partial statistics per output row over this tile's 32 columns.
+        // LayerNorm partial statistics per output row over this tile's 32 columns (4 threads x 8 columns per row).
         const int r = tid >> 2, sub = tid & 3;
-        float sum = 0.f;
-        if (r < TM)
-            for (int c = sub * 8; c < sub * 8 + 8; ++c) sum += Red[0][r * LDR + c];
-        sum = wave_sum_seg(sum, 4);
-        const float mean = sum * (1.0f / 32.0f);
-        float m2 = 0.f;
-        if (r < TM)
-            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - mean; m2 += d * d; }
-        m2 = wave_sum_seg(m2, 4);
-        if (sub == 0 && r < rows_out) {
+        float s1 = 0.f, s2 = 0.f, K = 0.f;
+        if (r < TM) {
+            K = Red[0][r * LDR];
+            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - K; s1 += d; s2 += d * d; }
+        }
+        s1 = seg_total(s1, 4);
+        s2 = seg_total(s2, 4);
+        if (sub == 3 && r < rows_out) {
             float* o = a.ln_out + (((size_t)b0 * a.Lout + r) * (a.Npad / TN) + nt) * 2;
-            o[0] = mean; o[1] = m2;
+            o[0] = K + s1 * (1.0f / 32.0f);
+            o[1] = fmaxf(s2 - s1 * s1 * (1.0f / 32.0f), 0.f);
         }
     }
 }
@@ -477,6 +493,7 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     __shared__ float tabA[TM * 8 * 2];
     __shared__ float tabE[TM * 8 * 2];
 
+    if (a.dbg == 10) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * a.spt;
@@ -628,7 +645,8 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     __syncthreads();
     store_a(0, 0, 0, NP);
     __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
+    if (a.dbg == 11) return;                          // prologue only
+    for (int ch = 0; ch < (a.dbg == 7 ? 0 : nch); ++ch) {
         const int chn = min(ch + 1, nch - 1);
         load_a(chn);
         const unsigned char* P0 = Ah[ch & 1][0];
@@ -659,13 +677,9 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
                     accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], breg[tap][nb][0], accL[mb][nb], 0, 0, 0);
                 }
             load_b_tap(chn, tap);          // next stage's fragments for this tap, T-1 taps ahead of their use
-            // the next stage's A rows are normalised / split / written to the other LDS buffer in slices that sit in
-            // the same scheduling region as this tap's MFMAs, so their VALU work fills the MFMA shadows
-            if constexpr (T >= 3) {
-                if (tap >= 1) store_a(chn, (ch + 1) & 1, ((tap - 1) * NP) / (T - 1), (tap * NP) / (T - 1));
-            }
         }
-        if constexpr (T < 3) store_a(chn, (ch + 1) & 1, 0, NP);
+        // (staging the next stage's rows in per-tap slices was measured: no faster, and one build of it was flaky)
+        store_a(chn, (ch + 1) & 1, 0, NP);
         __syncthreads();
     }
 
@@ -674,7 +688,8 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = accM[i][j] + accL[i][j] * H3_INV;
-    gemm_epilogue<true>(a, acc, Red, tabE, false);
+    if (a.dbg == 9) { if (acc[0][0][0] == 123.456f) a.out[0] = 1.f; return; }      // no epilogue
+    gemm_epilogue<true>(a, acc, Red, tabE, a.dbg == 8);
 }
 
 // ---------------------------------------------------------------------------------------------
