@@ -127,10 +127,13 @@ def main():
                 for k, (n, ms, fl) in model.profile(x, 500).items():
                     a = acc.setdefault(k, [0, 0.0, 0.0])
                     a[0] += n; a[1] += ms; a[2] += fl
-            k5 = acc["conv_gemm_kernel<5>"]
+            k5 = acc["conv5_gemm"]
             tot_ms = sum(v[1] for v in acc.values())
             achieved = k5[2] / (k5[1] * 1e-3) / 1e12          # algorithmic FLOPs of the k=5 conv launches / their time
-            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<5>", "achieved": round(achieved, 2),
+            import os as _os
+            kname = "conv_gemm_kernel<5,32,48,*> (fp32 MFMA)" if _os.environ.get("CINDM_MFMA") == "f32" else \
+                "conv_gemm_h3_kernel<5,48,*> (k=5 conv; fp32 products as 3 fp16 MFMAs, fp32 accumulate)"
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
                     "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
                     "traffic": None,
                     "launches_per_forward": k5[0] // reps, "avg_launch_us": round(k5[1] / k5[0] * 1e3, 2),

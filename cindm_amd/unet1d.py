@@ -171,8 +171,10 @@ class TemporalUnet1D(nn.Module):
                                                        _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
         return out
 
+    # kind 4 = the k=5 convolutions: conv_gemm_h3_kernel<5,48,*> (split-fp16 MFMA; default) or
+    # conv_gemm_kernel<5,32,48,*> (fp32 MFMA; CINDM_MFMA=f32)
     KERNEL_KINDS = ("conv_gemm_kernel<0>", "conv_gemm_kernel<1>", "conv_gemm_kernel<3>", "conv_gemm_kernel<4>",
-                    "conv_gemm_kernel<5>", "linattn_core_kernel")
+                    "conv5_gemm", "linattn_core_kernel")
 
     @torch.no_grad()
     def profile(self, x, t):
