@@ -748,3 +748,276 @@ def synth_state_dict(shapes, seed=0):
             raise KeyError(k)
         sd[k] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)))
     return sd
+
+
+# ============================================================================
+# 2-D airfoil path: Unet (model/diffusion_2d.py:281-408) and GaussianDiffusion sampling (:551-907)
+# ============================================================================
+
+def unet2d_param_shapes(dim=64, dim_mults=(1, 2), channels=21, heads=4, dim_head=32):
+    """State-dict manifest of the reference's 2-D ``Unet`` (model/diffusion_2d.py:282-367), registration order:
+    init_conv, time_mlp, downs, ups, mid_block1, mid_attn, mid_block2, final_res_block, final_conv."""
+    dims = [dim] + [dim * m for m in dim_mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+    tdim = dim * 4
+    hid = heads * dim_head
+    sh = {}
+
+    def conv(p, i, o, k, bias=True):
+        sh[p + ".weight"] = (o, i, k, k)
+        if bias:
+            sh[p + ".bias"] = (o,)
+
+    def rb(p, i, o):
+        sh[p + ".mlp.1.weight"] = (2 * o, tdim)
+        sh[p + ".mlp.1.bias"] = (2 * o,)
+        for b, ci in (("block1", i), ("block2", o)):
+            conv(f"{p}.{b}.proj", ci, o, 3)
+            sh[f"{p}.{b}.norm.weight"] = (o,)
+            sh[f"{p}.{b}.norm.bias"] = (o,)
+        if i != o:
+            conv(p + ".res_conv", i, o, 1)
+
+    def lin_attn(p, c):
+        conv(p + ".fn.fn.to_qkv", c, hid * 3, 1, bias=False)
+        conv(p + ".fn.fn.to_out.0", hid, c, 1)
+        sh[p + ".fn.fn.to_out.1.g"] = (1, c, 1, 1)
+        sh[p + ".fn.norm.g"] = (1, c, 1, 1)
+
+    def full_attn(p, c):
+        conv(p + ".fn.fn.to_qkv", c, hid * 3, 1, bias=False)
+        conv(p + ".fn.fn.to_out", hid, c, 1)
+        sh[p + ".fn.norm.g"] = (1, c, 1, 1)
+
+    conv("init_conv", channels, dim, 7)
+    sh["time_mlp.1.weight"] = (tdim, dim); sh["time_mlp.1.bias"] = (tdim,)
+    sh["time_mlp.3.weight"] = (tdim, tdim); sh["time_mlp.3.bias"] = (tdim,)
+    n = len(in_out)
+    for ind, (ci, co) in enumerate(in_out):
+        p = f"downs.{ind}"
+        rb(p + ".0", ci, ci); rb(p + ".1", ci, ci); lin_attn(p + ".2", ci)
+        if ind < n - 1:
+            conv(p + ".3.1", ci * 4, co, 1)           # Downsample: pixel-unshuffle + 1x1 (:105-109)
+        else:
+            conv(p + ".3", ci, co, 3)
+    for ind, (ci, co) in enumerate(reversed(in_out)):
+        p = f"ups.{ind}"
+        rb(p + ".0", co + ci, co); rb(p + ".1", co + ci, co); lin_attn(p + ".2", co)
+        if ind < n - 1:
+            conv(p + ".3.1", co, ci, 3)               # Upsample: nearest x2 + 3x3 (:99-103)
+        else:
+            conv(p + ".3", co, ci, 3)
+    mid = dims[-1]
+    rb("mid_block1", mid, mid); full_attn("mid_attn", mid); rb("mid_block2", mid, mid)
+    rb("final_res_block", dim * 2, dim)
+    conv("final_conv", dim, channels, 1)
+    return sh
+
+
+def synth_state_dict_2d(shapes, seed=0):
+    """Generator-defined weights for the 2-D Unet (same recipe as synth_state_dict)."""
+    import zlib
+    import numpy as np
+    sd = {}
+    for k, s in shapes.items():
+        rng = np.random.default_rng([seed, zlib.crc32(k.encode())])
+        u = rng.uniform(-1.0, 1.0, size=s).astype(np.float32)
+        if k.endswith(".g"):
+            v = 1.0 + 0.1 * u
+        elif ".norm." in k:
+            v = (1.0 + 0.1 * u) if k.endswith("weight") else 0.1 * u
+        else:
+            wk = k.rsplit(".", 1)[0] + ".weight"
+            ws = shapes[wk]
+            fan = 1
+            for d_ in ws[1:]:
+                fan *= d_
+            v = u / np.float32(math.sqrt(fan))
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)))
+    return sd
+
+
+def _ws_conv2d(x, w, b, padding):
+    """WeightStandardizedConv2d.forward, model/diffusion_2d.py:116-124 (fp32: eps 1e-5, biased variance)."""
+    mean = w.mean(dim=(1, 2, 3), keepdim=True)
+    var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    return F.conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), b, padding=padding)
+
+
+def _ln2d(x, g):
+    """LayerNorm over channels, model/diffusion_2d.py:126-135."""
+    var = torch.var(x, dim=1, unbiased=False, keepdim=True)
+    mean = torch.mean(x, dim=1, keepdim=True)
+    return (x - mean) * (var + 1e-5).rsqrt() * g
+
+
+def resnet_block_2d(sd, p, x, temb):
+    """ResnetBlock.forward, model/diffusion_2d.py:212-224 (+ Block :189-198)."""
+    ss = F.linear(F.silu(temb), sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"])[:, :, None, None]
+    scale, shift = ss.chunk(2, dim=1)
+    h = _ws_conv2d(x, sd[p + ".block1.proj.weight"], sd[p + ".block1.proj.bias"], 1)
+    h = F.group_norm(h, 8, sd[p + ".block1.norm.weight"], sd[p + ".block1.norm.bias"], eps=1e-5)
+    h = F.silu(h * (scale + 1) + shift)
+    h = _ws_conv2d(h, sd[p + ".block2.proj.weight"], sd[p + ".block2.proj.bias"], 1)
+    h = F.silu(F.group_norm(h, 8, sd[p + ".block2.norm.weight"], sd[p + ".block2.norm.bias"], eps=1e-5))
+    if (p + ".res_conv.weight") in sd:
+        x = F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
+    return h + x
+
+
+def linear_attention_2d(sd, p, x, heads=4, dim_head=32):
+    """Residual(PreNorm(LinearAttention)), model/diffusion_2d.py:226-254."""
+    b, c, hh, ww = x.shape
+    y = _ln2d(x, sd[p + ".fn.norm.g"])
+    qkv = F.conv2d(y, sd[p + ".fn.fn.to_qkv.weight"]).chunk(3, dim=1)
+    q, k, v = (t.reshape(b, heads, dim_head, hh * ww) for t in qkv)
+    q = q.softmax(dim=-2)
+    k = k.softmax(dim=-1)
+    q = q * dim_head ** -0.5
+    v = v / (hh * ww)
+    context = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, heads * dim_head, hh, ww)
+    out = F.conv2d(out, sd[p + ".fn.fn.to_out.0.weight"], sd[p + ".fn.fn.to_out.0.bias"])
+    return _ln2d(out, sd[p + ".fn.fn.to_out.1.g"]) + x
+
+
+def full_attention_2d(sd, p, x, heads=4, dim_head=32):
+    """Residual(PreNorm(Attention)), model/diffusion_2d.py:256-278."""
+    b, c, hh, ww = x.shape
+    y = _ln2d(x, sd[p + ".fn.norm.g"])
+    qkv = F.conv2d(y, sd[p + ".fn.fn.to_qkv.weight"]).chunk(3, dim=1)
+    q, k, v = (t.reshape(b, heads, dim_head, hh * ww) for t in qkv)
+    q = q * dim_head ** -0.5
+    sim = torch.einsum("bhdi,bhdj->bhij", q, k)
+    attn = sim.softmax(dim=-1)
+    out = torch.einsum("bhij,bhdj->bhid", attn, v)
+    out = out.permute(0, 1, 3, 2).reshape(b, heads * dim_head, hh, ww)
+    return F.conv2d(out, sd[p + ".fn.fn.to_out.weight"], sd[p + ".fn.fn.to_out.bias"]) + x
+
+
+def unet2d_forward(sd, x, t, taps=None):
+    """Unet.forward, model/diffusion_2d.py:369-408 (self_condition False).  x [B, C, H, W], t [B] int64."""
+    dim = sd["init_conv.weight"].shape[0]
+    nl = 0
+    while f"downs.{nl}.0.mlp.1.weight" in sd:
+        nl += 1
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    x = F.conv2d(x, sd["init_conv.weight"], sd["init_conv.bias"], padding=3)
+    r = x
+    tap("init_conv", x)
+    e = sinusoidal_pos_emb(t, dim)
+    e = F.linear(e, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
+    e = F.gelu(e)
+    temb = F.linear(e, sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
+    h = []
+    for i in range(nl):
+        p = f"downs.{i}"
+        x = resnet_block_2d(sd, p + ".0", x, temb); tap(p + ".0", x)
+        h.append(x)
+        x = resnet_block_2d(sd, p + ".1", x, temb); tap(p + ".1", x)
+        x = linear_attention_2d(sd, p + ".2", x); tap(p + ".2", x)
+        h.append(x)
+        if (p + ".3.1.weight") in sd:
+            b, c, hh, ww = x.shape                    # 'b c (h p1) (w p2) -> b (c p1 p2) h w'
+            xs = x.reshape(b, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(b, c * 4, hh // 2, ww // 2)
+            x = F.conv2d(xs, sd[p + ".3.1.weight"], sd[p + ".3.1.bias"])
+        else:
+            x = F.conv2d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], padding=1)
+        tap(p + ".3", x)
+    x = resnet_block_2d(sd, "mid_block1", x, temb); tap("mid_block1", x)
+    x = full_attention_2d(sd, "mid_attn", x); tap("mid_attn", x)
+    x = resnet_block_2d(sd, "mid_block2", x, temb); tap("mid_block2", x)
+    for i in range(nl):
+        p = f"ups.{i}"
+        x = torch.cat((x, h.pop()), dim=1)
+        x = resnet_block_2d(sd, p + ".0", x, temb); tap(p + ".0", x)
+        x = torch.cat((x, h.pop()), dim=1)
+        x = resnet_block_2d(sd, p + ".1", x, temb); tap(p + ".1", x)
+        x = linear_attention_2d(sd, p + ".2", x); tap(p + ".2", x)
+        if (p + ".3.1.weight") in sd:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            x = F.conv2d(x, sd[p + ".3.1.weight"], sd[p + ".3.1.bias"], padding=1)
+        else:
+            x = F.conv2d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], padding=1)
+        tap(p + ".3", x)
+    x = torch.cat((x, r), dim=1)
+    x = resnet_block_2d(sd, "final_res_block", x, temb); tap("final_res_block", x)
+    return F.conv2d(x, sd["final_conv.weight"], sd["final_conv.bias"])
+
+
+class Diffusion2D:
+    """What GaussianDiffusion (2-D) holds for sampling, model/diffusion_2d.py:552-676."""
+
+    def __init__(self, sd, *, image_size=64, frames=6, timesteps=1000, beta_schedule="sigmoid", objective="pred_noise",
+                 standard_fixed_ratio=0.01, coeff_ratio=0.1, share_noise=True, use_average_share=True):
+        self.sd, self.image_size, self.frames = sd, image_size, frames
+        self.num_timesteps, self.objective = timesteps, objective
+        self.standard_fixed_ratio, self.coeff_ratio = standard_fixed_ratio, coeff_ratio
+        self.share_noise, self.use_average_share = share_noise, use_average_share
+        self.tab = make_schedule(beta_schedule, timesteps, objective)
+        self.channels = sd["final_conv.weight"].shape[0]
+
+
+def share_states_over_boundaries(x, B, nb, use_average_share=True):
+    """share_states_over_boundaries, model/diffusion_2d.py:712-725: the state channels [:-3] are replaced by their
+    mean (or sum) over the nb boundary copies of each design.  x [B*nb, C, H, W] -> new tensor."""
+    C, H, W = x.shape[1:]
+    s = x[:, :-3].reshape(B, nb, C - 3, H, W)
+    s = s.mean(dim=1, keepdim=True) if use_average_share else s.sum(dim=1, keepdim=True)
+    out = x.clone()
+    out[:, :-3] = s.expand(-1, nb, -1, -1, -1).reshape(B * nb, C - 3, H, W)
+    return out
+
+
+def sample_noise_2d(state, boundary):
+    """sample_noise, model/diffusion_2d.py:775-785: state noise [B,1,C-3,H,W] shared over boundaries, boundary
+    noise [B,nb,3,H,W] independent -> [B, nb, C, H, W]."""
+    nb = boundary.shape[1]
+    return torch.cat([state.expand(-1, nb, -1, -1, -1), boundary], dim=2)
+
+
+def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard", clip_denoised=True):
+    """GaussianDiffusion.p_sample, non-recurrence branch, model/diffusion_2d.py:788-845 (objective pred_noise,
+    share_noise True).  x [B*nb, C, H, W]; noise [B*nb, C, H, W] (= sample_noise(...).view) or None at t == 0;
+    design_fn returns a GRADIENT tensor (:813).  Returns (x_{t-1}, x_start)."""
+    assert d.objective == "pred_noise" and d.share_noise
+    B, nb = shape[0], shape[1]
+    T = d.tab
+    tt = torch.full((x.shape[0],), t, dtype=torch.long)
+    eps = unet2d_forward(d.sd, x, tt)
+    eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
+    x_start = T["sqrt_recip_alphas_cumprod"][t] * x - T["sqrt_recipm1_alphas_cumprod"][t] * eps
+    if clip_denoised:
+        x_start = x_start.clamp(-1.0, 1.0)
+    mean = T["posterior_mean_coef1"][t] * x_start + T["posterior_mean_coef2"][t] * x
+    pred = mean
+    if t > 0:
+        pred = mean + (0.5 * T["posterior_log_variance_clipped"][t]).exp() * noise
+    if design_fn is not None:
+        g = design_fn(x.clone())
+        if design_guidance == "standard":
+            pred = pred - d.standard_fixed_ratio * g
+        elif design_guidance == "standard-alpha":
+            eta = (d.coeff_ratio * T["betas"].flip(0))[t]
+            pred = pred - eta * g
+        else:
+            raise ValueError(design_guidance)
+    return pred, x_start
+
+
+def p_sample_loop_2d(d, shape, tape_init, tape_steps, design_fn=None, design_guidance="standard", t_stop=0, record=None):
+    """p_sample_loop, model/diffusion_2d.py:893-907.  tape_init = (state [B,1,C-3,H,W], boundary [B,nb,3,H,W]);
+    tape_steps[t] likewise for t > 0."""
+    B, nb, C, H, W = shape
+    img = sample_noise_2d(*tape_init)
+    for t in reversed(range(t_stop, d.num_timesteps)):
+        nz = sample_noise_2d(*tape_steps[t]).reshape(B * nb, C, H, W) if t > 0 else None
+        out, _ = p_sample_2d(d, shape, img.reshape(B * nb, C, H, W), t, nz, design_fn, design_guidance)
+        img = out.reshape(B, nb, C, H, W)
+        if record is not None:
+            record(t, img)
+    return img
