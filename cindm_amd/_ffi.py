@@ -22,6 +22,11 @@ class UnetDesc(C.Structure):
                 ("timesteps", C.c_int32)]
 
 
+class Unet2dDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 4), ("channels", C.c_int32),
+                ("image_size", C.c_int32), ("timesteps", C.c_int32)]
+
+
 SCHED_NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
                "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
                "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
@@ -74,6 +79,24 @@ SIGNATURES = {
                                       _vp, _i32, _vp, _i32, _i32, _i64, _vp, _sz, _vp, _i32]),
     "cindm_fill_normal": (C.c_int, [_vp, _i64, _i64, _u64, _i64, _i32, _vp]),
     "cindm_ddpm1d_launches_per_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc)]),
+    "cindm_unet2d_create": (C.c_int, [C.POINTER(Unet2dDesc), C.POINTER(_vp)]),
+    "cindm_unet2d_destroy": (None, [_vp]),
+    "cindm_unet2d_num_params": (C.c_int, [_vp]),
+    "cindm_unet2d_param_info": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(_i64 * 4), C.POINTER(C.c_int)]),
+    "cindm_unet2d_set_param": (C.c_int, [_vp, C.c_char_p, _vp, _i64, C.c_int]),
+    "cindm_unet2d_set_sinusoid_table": (C.c_int, [_vp, _vp, _i64]),
+    "cindm_unet2d_finalize": (C.c_int, [_vp, _vp]),
+    "cindm_unet2d_padded_channels": (C.c_int, [_vp]),
+    "cindm_unet2d_workspace_bytes": (_sz, [_vp, _i64]),
+    "cindm_unet2d_launches_per_forward": (C.c_int, [_vp]),
+    "cindm_unet2d_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "cindm_unet2d_tap": (C.c_int, [_vp, C.c_char_p, _i64, _vp, _vp, _i64, C.POINTER(_i64 * 3), _vp]),
+    "cindm_ddpm2d_workspace_bytes": (_sz, [_vp, _i64]),
+    "cindm_ddpm2d_step": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _vp, _vp, _vp,
+                                    _vp, _sz, _vp]),
+    "cindm_ddpm2d_sample": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _i32, _vp, _sz, _vp,
+                                      _i32]),
+    "cindm_fill_noise2d": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _u64, _i64, _i32, _vp]),
 }
 
 

@@ -3,6 +3,7 @@
 // reference) and of one DDPM reverse step (model/diffusion_1d.py:951-1044, :1047-1186, :1190-1376,
 // :1380-1652) out of the kernels in kernels.h.  gfx950 only.
 #include "kernels.h"
+#include "kernels2d.h"
 #include "../../include/cindm_hip.h"
 
 #include <cmath>
@@ -394,6 +395,8 @@ struct Emitter {
             if (mode == SRC_PLAIN) CINDM_LAUNCH(1, 128, 48, SRC_PLAIN);
             else if (mode == SRC_LN) CINDM_LAUNCH(1, 128, 48, SRC_LN);
             else if (mode == SRC_MISH) CINDM_LAUNCH(1, 128, 48, SRC_MISH);
+            else if (mode == SRC_GELU) CINDM_LAUNCH(1, 128, 48, SRC_GELU);
+            else if (mode == SRC_SILU) CINDM_LAUNCH(1, 128, 48, SRC_SILU);
             else ok = false;
         } else if (T == 1 && a.KC == 64) {
             if (mode == SRC_PLAIN) CINDM_LAUNCH(1, 64, 48, SRC_PLAIN);
@@ -1009,3 +1012,6 @@ extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+// ============================================================================ 2-D airfoil path
+#include "unet2d_host.inc"

@@ -35,7 +35,7 @@ constexpr int TN = 32;        // tile cols
 constexpr int MAXR = 96;      // max input rows per tile (stride-2 conv: 2 * 48)
 constexpr int LDR = 33;       // reduce / output tile pitch
 
-enum SrcMode { SRC_PLAIN = 0, SRC_GN_MISH = 1, SRC_LN = 2, SRC_MISH = 3 };
+enum SrcMode { SRC_PLAIN = 0, SRC_GN_MISH = 1, SRC_LN = 2, SRC_MISH = 3, SRC_GELU = 5, SRC_SILU = 6 };
 
 struct Src {
     const float* p;       // [rows, ld]
@@ -392,6 +392,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
                     v.z = (v.z - m) * rs * g.z; v.w = (v.w - m) * rs * g.w;
                 } else if constexpr (MODE == SRC_MISH) {
                     v.x = mish_f(v.x); v.y = mish_f(v.y); v.z = mish_f(v.z); v.w = mish_f(v.w);
+                } else if constexpr (MODE == SRC_GELU) {    // exact (erf) GELU, nn.GELU() default
+                    v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+                    v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+                } else if constexpr (MODE == SRC_SILU) {    // accurate form (init-time table only)
+                    v.x = v.x / (1.0f + expf(-v.x)); v.y = v.y / (1.0f + expf(-v.y));
+                    v.z = v.z / (1.0f + expf(-v.z)); v.w = v.w / (1.0f + expf(-v.w));
                 }
                 const bool ok = rok[p] && cok;              // zero padding is applied AFTER the activation
                 v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;

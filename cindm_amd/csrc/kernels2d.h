@@ -1,0 +1,580 @@
+// Device kernels of the 2-D airfoil path (model/diffusion_2d.py of the reference): Unet (:281-408) blocks and the
+// boundary-sharing DDPM update (:712-845).  gfx950 only.
+//
+// Layout: channel-last fp32 [image, y, x, C] = rows (image*H*W + y*W + x) x C.
+//
+// conv2d_gemm_kernel<NT, LROWS, MODE>: implicit-GEMM Conv2d on fp32 MFMA (v_mfma_f32_16x16x4_f32), same tile /
+// wave decomposition as the 1-D kernel (48 output pixels x 32 output channels per workgroup, K split over 4 waves,
+// B fragments straight from L2 in fragment order, A staged through LDS with normalise-on-load).  A tile is 48
+// consecutive pixels (row-major) of ONE image; the source pixels every tap of the tile can touch form one contiguous
+// range of the flattened source image, which is what gets staged; a tap is then an LDS row offset computed per lane
+// (out-of-image taps point at a zero row).  Tap geometries: k x k convolution (1x1, 3x3, 7x7 as 7 tap groups of 7),
+// 3x3 over the nearest-neighbour x2 upsampled source (Upsample :99-103), and the four taps of the pixel-unshuffle
+// 1x1 (Downsample :105-109) -- neither the upsampled nor the unshuffled tensor is ever materialised.
+#pragma once
+#include "kernels.h"
+
+namespace cindm {
+
+enum SrcMode2d { SRC2_PLAIN = 0, SRC2_GN_SS_SILU = 4, SRC2_LN = 2 };
+enum ConvKind { CONV_KXK = 0, CONV_UP2 = 1, CONV_UNSHUF = 2 };
+
+struct Conv2dArgs {
+    Src src[2];           // stats: merged GroupNorm (mean, M2) [NI][8][2] (cnt = H*W*gw) or LN partials [rows][P][2]
+    int nsrc;
+    const float* W;       // [n-tile][stage = chunk*TG + tap group][q][thread][4]
+    const float* bias;
+    int CinP, Npad, N;
+    int NI, Hin, Win, Hout, Wout, wout_log2;
+    int kind, kw, TG, tpi;
+    float* out; int ldo;
+    const float* res; int ldres;
+    const float* e_y; int e_ld; const float* e_stats; int e_gw; float e_cnt; const float* e_gamma; const float* e_beta;
+    float* stats_out; int so_gw;        // GroupNorm (mean, M2) partials per tile: [NI][8][tpi][2]
+    float* ln_out;                      // LayerNorm partials per row and 32-column tile: [rows][Npad/32][2]
+    const int* t_ptr; int t_imm;
+};
+
+__device__ __forceinline__ float silu_f(float x) {
+    // x * sigmoid(x); exp2-based, one v_exp_f32 + one v_rcp_f32
+    const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int NT, int LROWS, int MODE>
+__global__ __launch_bounds__(256) void conv2d_gemm_kernel(const Conv2dArgs a) {
+    constexpr int KC = 32, LDAK = KC + 2, CS = 2, KS = NT * CS;
+    constexpr int RPP = 32, NP = LROWS / RPP, ZR = LROWS;
+    static_assert(LROWS % RPP == 0, "LROWS must be a multiple of 32");
+    __shared__ __attribute__((aligned(16))) float As[2][(LROWS + 1) * LDAK];
+    __shared__ __attribute__((aligned(16))) float Red[4][TM * LDR];
+    __shared__ float tabA[128];             // GN: [8](mean, rstd) of this image;  LN: unused (row stats kept per thread)
+    __shared__ float tabE[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int img = mt / a.tpi, ti = mt - img * a.tpi;
+    const int HWo = a.Hout * a.Wout, HWi = a.Hin * a.Win;
+    const int p_lo = ti * TM;
+    const int rows_out = min(TM, HWo - p_lo);
+    const int p_hi = p_lo + rows_out - 1;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int pad = a.kw >> 1;
+
+    // contiguous source pixel range [s_lo, s_hi) that the taps of this tile can touch
+    int s_lo, s_hi;
+    if (a.kind == CONV_KXK) {
+        s_lo = max(0, p_lo - pad * a.Win - pad);
+        s_hi = min(HWi, p_hi + pad * a.Win + pad + 1);
+    } else if (a.kind == CONV_UP2) {
+        const int y0 = p_lo >> a.wout_log2, y1 = p_hi >> a.wout_log2;
+        s_lo = (max(0, y0 - 1) >> 1) * a.Win;
+        s_hi = ((min(a.Hout - 1, y1 + 1) >> 1) + 1) * a.Win;
+    } else {
+        const int y0 = p_lo >> a.wout_log2, y1 = p_hi >> a.wout_log2;
+        s_lo = (2 * y0) * a.Win;
+        s_hi = (2 * y1 + 2) * a.Win;
+    }
+    const int rows_in = s_hi - s_lo;        // <= LROWS by construction (host checks the geometry)
+
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nch0 = (a.src[0].C + KC - 1) / KC;
+    const int nst = (a.CinP / KC) * a.TG;           // stages (even or 1: host pads)
+    const int c4 = tid & 7, r0 = tid >> 3;
+    size_t goff[NP];
+    bool rok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = r0 + RPP * p;
+        rok[p] = r < rows_in;
+        goff[p] = (size_t)img * HWi + s_lo + min(r, rows_in - 1);
+    }
+    // LayerNorm on load: the statistics of the rows this thread stages (merged from the producer's partials)
+    float lnm[NP], lnr[NP];
+    if constexpr (MODE == SRC2_LN) {
+        const Src& s = a.src[0];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) merge_stats(s.stats + goff[p] * s.P * 2, s.P, s.cnt, 1e-5f, lnm[p], lnr[p]);
+    }
+
+    float bcur[KS][2], bnxt[KS][2];
+    float4 areg[NP];
+    const float4* wbase = reinterpret_cast<const float4*>(a.W) + (size_t)nt * nst * 256 * (2 * KS / 4) + tid;
+    auto load_b = [&](int st, float (&b)[KS][2]) {
+        const float4* wp = wbase + (size_t)st * 256 * (2 * KS / 4);
+#pragma unroll
+        for (int q = 0; q < 2 * KS / 4; ++q) {
+            const float4 v = wp[q * 256];
+            b[2 * q][0] = v.x; b[2 * q][1] = v.y; b[2 * q + 1][0] = v.z; b[2 * q + 1][1] = v.w;
+        }
+    };
+    auto src_ptr = [&](int cc, int& cl, int& C, int& ld) -> const float* {
+        const bool first = (cc < nch0) || (a.nsrc == 1);
+        cl = (first ? cc : cc - nch0) * KC + c4 * 4;
+        C = first ? a.src[0].C : a.src[1].C;
+        ld = first ? a.src[0].ld : a.src[1].ld;
+        return first ? a.src[0].p : a.src[1].p;
+    };
+    float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), psc = pb, psh = pb;
+    auto load_a = [&](int st, float4 (&v)[NP]) {
+        int cl, C, ld;
+        const float* base = src_ptr(st / a.TG, cl, C, ld);
+        const int clc = min(cl, C - 4);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            v[p] = *reinterpret_cast<const float4*>(base + goff[p] * ld + clc);
+        if constexpr (MODE == SRC2_GN_SS_SILU || MODE == SRC2_LN) {
+            const Src& s = a.src[0];
+            pg = *reinterpret_cast<const float4*>(s.gamma + clc);
+            if constexpr (MODE == SRC2_GN_SS_SILU) {
+                pb = *reinterpret_cast<const float4*>(s.beta + clc);
+                if (s.tb) {         // per-timestep (scale | shift) row of this block: [scale C | shift C]
+                    psc = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + clc);
+                    psh = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + s.C + clc);
+                }
+            }
+        }
+    };
+    load_b(0, bcur);
+    load_a(0, areg);
+
+    for (int i = tid; i < 2 * LDAK; i += 256) As[i / LDAK][ZR * LDAK + (i % LDAK)] = 0.f;
+    if constexpr (MODE == SRC2_GN_SS_SILU) {
+        const Src& s = a.src[0];
+        if (tid < 8) {
+            float m, r;
+            merge_stats(s.stats + ((size_t)img * 8 + tid) * 2, 1, s.cnt, 1e-5f, m, r);
+            tabA[2 * tid] = m; tabA[2 * tid + 1] = r;
+        }
+    }
+    if (a.e_y && tid < 8) {
+        float m, r;
+        merge_stats(a.e_stats + ((size_t)img * 8 + tid) * 2, 1, a.e_cnt, 1e-5f, m, r);
+        tabE[2 * tid] = m; tabE[2 * tid + 1] = r;
+    }
+    // output pixel (y, x) of this lane's fragment rows
+    int fy[3], fx[3];
+    bool fok[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        const int r = mb * 16 + (lane & 15);
+        const int pix = p_lo + min(r, rows_out - 1);
+        fy[mb] = pix >> a.wout_log2; fx[mb] = pix & (a.Wout - 1);
+        fok[mb] = r < rows_out;
+    }
+    const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
+
+    auto store_a = [&](int st, int buf, const float4 (&av)[NP]) {
+        int cl, C, ld;
+        (void)src_ptr(st / a.TG, cl, C, ld);
+        const bool cok = cl < C;
+        const int clc = min(cl, C - 4);
+        float* dst = As[buf];
+        float gm = 0.f, gr = 1.f;
+        if constexpr (MODE == SRC2_GN_SS_SILU) { const int ti2 = (clc >> gw_shift) * 2; gm = tabA[ti2]; gr = tabA[ti2 + 1]; }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + RPP * p;
+            float4 v = av[p];
+            if constexpr (MODE == SRC2_GN_SS_SILU) {
+                v.x = silu_f(((v.x - gm) * gr * pg.x + pb.x) * (psc.x + 1.0f) + psh.x);
+                v.y = silu_f(((v.y - gm) * gr * pg.y + pb.y) * (psc.y + 1.0f) + psh.y);
+                v.z = silu_f(((v.z - gm) * gr * pg.z + pb.z) * (psc.z + 1.0f) + psh.z);
+                v.w = silu_f(((v.w - gm) * gr * pg.w + pb.w) * (psc.w + 1.0f) + psh.w);
+            } else if constexpr (MODE == SRC2_LN) {
+                v.x = (v.x - lnm[p]) * lnr[p] * pg.x; v.y = (v.y - lnm[p]) * lnr[p] * pg.y;
+                v.z = (v.z - lnm[p]) * lnr[p] * pg.z; v.w = (v.w - lnm[p]) * lnr[p] * pg.w;
+            }
+            const bool ok = rok[p] && cok;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            float2* d2 = reinterpret_cast<float2*>(dst + r * LDAK + c4 * 4);
+            d2[0] = make_float2(v.x, v.y);
+            d2[1] = make_float2(v.z, v.w);
+        }
+    };
+    // LDS element offset of (fragment row mb, tap tt) for this lane
+    auto tap_addr = [&](int mb, int tt) -> int {
+        int ys, xs; bool ok;
+        if (a.kind == CONV_KXK) {
+            const int q = tt / a.kw;
+            ys = fy[mb] + q - pad; xs = fx[mb] + (tt - q * a.kw) - pad;
+            ok = (ys >= 0) && (ys < a.Hin) && (xs >= 0) && (xs < a.Win);
+        } else if (a.kind == CONV_UP2) {
+            const int q = tt / 3;
+            const int yy = fy[mb] + q - 1, xx = fx[mb] + (tt - q * 3) - 1;
+            ok = (yy >= 0) && (yy < a.Hout) && (xx >= 0) && (xx < a.Wout);
+            ys = yy >> 1; xs = xx >> 1;
+        } else {
+            ys = 2 * fy[mb] + (tt >> 1); xs = 2 * fx[mb] + (tt & 1); ok = true;
+        }
+        const int row = (ok && fok[mb]) ? (ys * a.Win + xs - s_lo) : ZR;
+        return row * LDAK + w * 8 + (lane >> 4);
+    };
+
+    auto stage = [&](int st, const float (&bc)[KS][2], float (&bn)[KS][2]) {
+        const int stn = min(st + 1, nst - 1);
+        load_b(stn, bn);
+        load_a(stn, areg);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ab = As[st & 1];
+        const int tg = st % a.TG;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int tt = tg * NT + j;
+            const int a0i = tap_addr(0, tt), a1i = tap_addr(1, tt), a2i = tap_addr(2, tt);
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const float a0 = Ab[a0i + cs * 4], a1 = Ab[a1i + cs * 4], a2 = Ab[a2i + cs * 4];
+                const float b0v = bc[j * CS + cs][0], b1v = bc[j * CS + cs][1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0v, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1v, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0v, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc[1][1], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0v, acc[2][0], 0, 0, 0);
+                acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1v, acc[2][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(stn, (st + 1) & 1, areg);
+        __syncthreads();
+    };
+
+    __syncthreads();
+    store_a(0, 0, areg);
+    __syncthreads();
+    if (nst == 1) {
+        stage(0, bcur, bnxt);
+    } else {
+        for (int st = 0; st < nst; st += 2) {
+            stage(st, bcur, bnxt);
+            stage(st + 1, bnxt, bcur);
+        }
+    }
+
+    // ---- epilogue: cross-wave reduce, bias, + SiLU(GroupNorm(e_y)), + residual, store, statistics --------
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
+    __syncthreads();
+    const int n = tid & 31, rq = tid >> 5;
+    const int n0 = nt * TN, gn = n0 + n;
+    const bool nok = gn < a.N;
+    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+    const size_t row_base = (size_t)img * HWo + p_lo;
+    float eg = 1.f, eb = 0.f, em = 0.f, er = 1.f;
+    if (a.e_y && nok) {
+        eg = a.e_gamma[gn]; eb = a.e_beta[gn];
+        const int g = gn >> (31 - __builtin_clz(a.e_gw));
+        em = tabE[2 * g]; er = tabE[2 * g + 1];
+    }
+    float ey[6], rs[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        ey[q] = 0.f; rs[q] = 0.f;
+        if (r < rows_out && nok) {
+            if (a.e_y) ey[q] = a.e_y[(row_base + r) * a.e_ld + gn];
+            if (a.res) rs[q] = a.res[(row_base + r) * a.ldres + gn];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        float v = (Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n]) + bias;
+        if (r < rows_out && nok) {
+            if (a.e_y) v += silu_f((ey[q] - em) * er * eg + eb);
+            if (a.res) v += rs[q];
+            a.out[(row_base + r) * a.ldo + gn] = v;
+        } else {
+            v = 0.f;
+        }
+        Red[0][r * LDR + n] = v;
+    }
+    if (a.stats_out || a.ln_out) __syncthreads();
+    if (a.stats_out && rq == 0) {
+        // GroupNorm partial of this tile: (mean, M2) over rows_out x gw elements, per group inside the 32 columns
+        const int gwt = a.so_gw;                       // 8 or 16 (< 32: whole groups inside the tile)
+        const float K = Red[0][n & ~(gwt - 1)];
+        float s1 = 0.f, s2 = 0.f;
+        for (int l = 0; l < rows_out; ++l) { const float d = Red[0][l * LDR + n] - K; s1 += d; s2 += d * d; }
+        s1 = seg_total(s1, gwt);
+        s2 = seg_total(s2, gwt);
+        if ((n & (gwt - 1)) == gwt - 1) {
+            const float ne = (float)(rows_out * gwt);
+            const int g = gn >> (31 - __builtin_clz(gwt));
+            float* o = a.stats_out + (((size_t)img * 8 + g) * a.tpi + ti) * 2;
+            o[0] = K + s1 / ne;
+            o[1] = fmaxf(s2 - s1 * s1 / ne, 0.f);
+        }
+    }
+    if (a.ln_out) {
+        const int r = tid >> 2, sub = tid & 3;
+        float s1 = 0.f, s2 = 0.f, K = 0.f;
+        if (r < TM) {
+            K = Red[0][r * LDR];
+            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - K; s1 += d; s2 += d * d; }
+        }
+        s1 = seg_total(s1, 4);
+        s2 = seg_total(s2, 4);
+        if (sub == 3 && r < rows_out) {
+            float* o = a.ln_out + ((row_base + r) * (a.Npad / TN) + nt) * 2;
+            o[0] = K + s1 * (1.0f / 32.0f);
+            o[1] = fmaxf(s2 - s1 * s1 * (1.0f / 32.0f), 0.f);
+        }
+    }
+}
+
+// Merge the per-tile GroupNorm partials of an image: [NI][8][tpi][2] -> [NI][8][2] = (mean, M2) over the whole
+// (image, group); tile counts are 48*gw except the last (HW - 48*(tpi-1))*gw.  Chan's formula, fixed order.
+__global__ void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ merged, int n_stats, int tpi, int HW, int gw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_stats) return;
+    const float* p = part + (size_t)i * tpi * 2;
+    float n = 0.f, mean = 0.f, M2 = 0.f;
+    for (int t = 0; t < tpi; ++t) {
+        const float nb = (float)(min(TM, HW - t * TM) * gw);
+        const float d = p[2 * t] - mean;
+        const float nn = n + nb;
+        mean += d * (nb / nn);
+        M2 += p[2 * t + 1] + d * d * (n * nb / nn);
+        n = nn;
+    }
+    merged[2 * i] = mean; merged[2 * i + 1] = M2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LinearAttention (model/diffusion_2d.py:239-254) on qkv [rows, 384] (q | k | v, heads*32 each), per image of n pixels:
+//   q = softmax over d (per pixel, per head) * 32^-1/2 ; k = softmax over the n pixels ; v /= n ;
+//   ctx[d][e] = sum_n k[d][n] v[e][n] ; out[e][n] = sum_d ctx[d][e] q[d][n].
+// Kernel 1: per (image, head) column statistics of k: max and sum(exp(k - max)) over the n pixels.
+__global__ __launch_bounds__(256) void la_kstats_kernel(const float* __restrict__ qkv, float* __restrict__ kst, int n) {
+    __shared__ float smx[8][32], ssm[8][32];
+    const int img = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int d = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const float* kp = qkv + (size_t)img * n * 384 + 128 + h * 32 + d;
+    float mx = -INFINITY, sum = 0.f;
+    for (int i = s; i < n; i += 8) {
+        const float v = kp[(size_t)i * 384];
+        if (v > mx) { sum = sum * expf(mx - v) + 1.0f; mx = v; } else sum += expf(v - mx);
+    }
+    smx[s][d] = mx; ssm[s][d] = sum;
+    __syncthreads();
+    if (s == 0) {
+        float M = smx[0][d];
+        for (int j = 1; j < 8; ++j) M = fmaxf(M, smx[j][d]);
+        float S = 0.f;
+        for (int j = 0; j < 8; ++j) S += ssm[j][d] * expf(smx[j][d] - M);
+        float* o = kst + ((size_t)blockIdx.x * 32 + d) * 2;
+        o[0] = M; o[1] = S;
+    }
+}
+// Kernel 2: partial contexts over a slice of the pixels: ctxp[img][h][split][d][e].
+constexpr int LA_SPLIT = 16;
+__global__ __launch_bounds__(256) void la_context_kernel(const float* __restrict__ qkv, const float* __restrict__ kst,
+                                                         float* __restrict__ ctxp, int n) {
+    const int split = blockIdx.x % LA_SPLIT, ih = blockIdx.x / LA_SPLIT;       // ih = img*4 + h
+    const int img = ih >> 2, h = ih & 3;
+    const int d = threadIdx.x & 31, eg = threadIdx.x >> 5;                        // e in [eg*4, eg*4+4)
+    const float M = kst[((size_t)ih * 32 + d) * 2], inv = 1.0f / kst[((size_t)ih * 32 + d) * 2 + 1];
+    const float invn = 1.0f / (float)n;
+    const int per = n / LA_SPLIT;
+    const float* base = qkv + ((size_t)img * n + split * per) * 384;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    for (int i = 0; i < per; ++i) {
+        const float* row = base + (size_t)i * 384;
+        const float p = expf(row[128 + h * 32 + d] - M) * inv;
+        const float4 v = *reinterpret_cast<const float4*>(row + 256 + h * 32 + eg * 4);
+        c0 += p * (v.x * invn); c1 += p * (v.y * invn); c2 += p * (v.z * invn); c3 += p * (v.w * invn);
+    }
+    float* o = ctxp + (((size_t)ih * LA_SPLIT + split) * 32 + d) * 32 + eg * 4;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// Kernel 3: out[pixel][h*32 + e] = sum_d ctx[d][e] * softmax_d(q[pixel][h*32 + :])[d] * 32^-1/2 ; one thread per (pixel, head).
+__global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctxp,
+                                                       float* __restrict__ att, int n) {
+    __shared__ float ctx[32 * 33];
+    const int ih = blockIdx.y, img = ih >> 2, h = ih & 3;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < LA_SPLIT; ++sp) s += ctxp[((size_t)ih * LA_SPLIT + sp) * 1024 + i];
+        ctx[(i >> 5) * 33 + (i & 31)] = s;
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= n) return;
+    const float* qp = qkv + ((size_t)img * n + pix) * 384 + h * 32;
+    float q[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(qp + 4 * j);
+        q[4 * j] = v.x; q[4 * j + 1] = v.y; q[4 * j + 2] = v.z; q[4 * j + 3] = v.w;
+        mx = fmaxf(fmaxf(fmaxf(mx, v.x), fmaxf(v.y, v.z)), v.w);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { q[d] = expf(q[d] - mx); sum += q[d]; }
+    const float sc = 0.17677669529663687f / sum;
+    float* op = att + ((size_t)img * n + pix) * 128 + h * 32;
+#pragma unroll
+    for (int e4 = 0; e4 < 8; ++e4) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            const float qd = q[d] * sc;
+            o0 += ctx[d * 33 + e4 * 4] * qd; o1 += ctx[d * 33 + e4 * 4 + 1] * qd;
+            o2 += ctx[d * 33 + e4 * 4 + 2] * qd; o3 += ctx[d * 33 + e4 * 4 + 3] * qd;
+        }
+        *reinterpret_cast<float4*>(op + e4 * 4) = make_float4(o0, o1, o2, o3);
+    }
+}
+// out = LayerNorm_channels(z) * g + x   (LinearAttention's to_out[1] and the Residual, :126-135, :96-97); one wave per pixel row.
+__global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                          const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* zp = z + row * C;
+    float v0 = lane < C ? zp[lane] : 0.f, v1 = lane + 64 < C ? zp[lane + 64] : 0.f;
+    float s = v0 + v1;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    const float d0 = lane < C ? v0 - mean : 0.f, d1 = lane + 64 < C ? v1 - mean : 0.f;
+    float m2 = d0 * d0 + d1 * d1;
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+    const float rstd = 1.0f / sqrtf(m2 / (float)C + 1e-5f);
+    if (lane < C) out[row * C + lane] = d0 * rstd * g[lane] + x[row * C + lane];
+    if (lane + 64 < C) out[row * C + lane + 64] = d1 * rstd * g[lane + 64] + x[row * C + lane + 64];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Full softmax attention (Attention.forward, :266-278) for n tokens, 4 heads x 32: one workgroup per (image, head,
+// 64 queries); keys/values streamed through LDS in chunks of 64; online softmax per query; 4 lanes per query.
+__global__ __launch_bounds__(256) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
+    __shared__ float Ks[64 * 33], Vs[64 * 33];
+    const int ih = blockIdx.y, img = ih >> 2, h = ih & 3;
+    const int qi = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;      // this lane owns d in [part*8, part*8+8)
+    const float* base = qkv + (size_t)img * n * 384;
+    float q[8];
+    {
+        const float* qp = base + (size_t)qi * 384 + h * 32 + part * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = qp[j] * 0.17677669529663687f;
+    }
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            Ks[r * 33 + c] = base[(size_t)(k0 + r) * 384 + 128 + h * 32 + c];
+            Vs[r * 33 + c] = base[(size_t)(k0 + r) * 384 + 256 + h * 32 + c];
+        }
+        __syncthreads();
+        for (int j = 0; j < 64; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += q[e] * Ks[j * 33 + part * 8 + e];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            const float mn = fmaxf(m, s);
+            const float corr = expf(m - mn), p = expf(s - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * corr + p * Vs[j * 33 + part * 8 + e];
+            m = mn;
+        }
+    }
+    const float inv = 1.0f / l;
+    float* op = out + ((size_t)img * n + qi) * 128 + h * 32 + part * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) op[e] = o[e] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DDPM update with boundary sharing (share_states_over_boundaries :712-725, p_mean_variance :757-773, p_sample
+// :804-808): one thread per state element of x [B*nb, HW, C] (channel-last).  The model output's state channels
+// (c < C-3) are replaced by their mean (or sum) over the nb boundary copies of the design; x0, clamp, posterior mean;
+// + sigma_t * z where z is SHARED over the boundary copies for the state channels (sample_noise :775-785).
+struct Update2dArgs {
+    const float* x; const float* eps; float* x_out; float* x0_out; float* mean_out;
+    int64_t B; int nb, HW, C, CP, use_avg, clip, add_noise;     // C logical channels (21), CP padded row pitch (24)
+    const float* sqrt_recip; const float* sqrt_recipm1; const float* coef1; const float* coef2; const float* logvar;
+    const int* t_ptr; int t_imm;
+    const float* noise_state; int64_t ns_t_stride;      // [B, HW, C-3] (+ t * stride) or null
+    const float* noise_bound; int64_t nb_t_stride;      // [B*nb, HW, 3]
+    uint64_t seed; int64_t sample_off;
+    int* t_dec; unsigned* done;
+};
+__global__ void update2d_kernel(const Update2dArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int64_t total = a.B * a.nb * (int64_t)a.HW * a.CP;
+    const int c = (int)(i % a.CP);
+    if (i < total && c < a.C) {
+        const int64_t pix = (i / a.CP) % a.HW;
+        const int64_t im = i / ((int64_t)a.CP * a.HW);
+        const int64_t b = im / a.nb;
+        const int Cs = a.C - 3;
+        float e;
+        if (c < Cs) {
+            float s = 0.f;
+            for (int k = 0; k < a.nb; ++k) s += a.eps[(((b * a.nb + k) * a.HW) + pix) * a.CP + c];
+            e = a.use_avg ? s / (float)a.nb : s;
+        } else {
+            e = a.eps[i];
+        }
+        const float xv = a.x[i];
+        float x0 = __fsub_rn(__fmul_rn(a.sqrt_recip[t], xv), __fmul_rn(a.sqrt_recipm1[t], e));
+        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        const float mean = __fadd_rn(__fmul_rn(a.coef1[t], x0), __fmul_rn(a.coef2[t], xv));
+        if (a.x0_out) a.x0_out[i] = x0;
+        if (a.mean_out) a.mean_out[i] = mean;
+        if (a.x_out) {
+            float v = mean;
+            if (a.add_noise && t > 0) {
+                float z;
+                if (c < Cs) {
+                    z = a.noise_state ? a.noise_state[(size_t)t * a.ns_t_stride + ((size_t)b * a.HW + pix) * Cs + c]
+                                      : counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, (uint32_t)(pix * Cs + c));
+                } else {
+                    z = a.noise_bound ? a.noise_bound[(size_t)t * a.nb_t_stride + ((size_t)im * a.HW + pix) * 3 + (c - Cs)]
+                                      : counter_normal(a.seed ^ 0x9e3779b97f4a7c15ull, (uint64_t)((a.sample_off + b) * a.nb + (im - b * a.nb)),
+                                                       (uint32_t)t, (uint32_t)(pix * 3 + (c - Cs)));
+                }
+                v += expf(0.5f * a.logvar[t]) * z;
+            }
+            a.x_out[i] = v;
+        }
+    }
+    if (a.t_dec) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(a.done, 1u) == gridDim.x - 1) { *a.done = 0u; *a.t_dec = t - 1; }
+        }
+    }
+}
+
+// x_T for the 2-D path from the counter-based generator (state channels shared over the boundaries of a design)
+__global__ void fill_noise2d_kernel(float* x, int64_t B, int nb, int HW, int C, int CP, uint64_t seed, int64_t off, uint32_t tag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nb * (int64_t)HW * CP) return;
+    const int c = (int)(i % CP);
+    const int64_t pix = (i / CP) % HW;
+    const int64_t im = i / ((int64_t)CP * HW);
+    const int64_t b = im / nb;
+    const int Cs = C - 3;
+    x[i] = (c >= C) ? 0.f : (c < Cs) ? counter_normal(seed, (uint64_t)(off + b), tag, (uint32_t)(pix * Cs + c))
+                    : counter_normal(seed ^ 0x9e3779b97f4a7c15ull, (uint64_t)((off + b) * nb + (im - b * nb)), tag, (uint32_t)(pix * 3 + (c - Cs)));
+}
+
+}  // namespace cindm

@@ -202,6 +202,78 @@ int  cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed,
 int  cindm_ddpm1d_launches_per_step(const cindm_ddpm1d* h, const cindm_unet1d* pair,
                                     const cindm_unet1d* uncond, const cindm_compose_desc* c);
 
+/* ===================================================================== 2-D airfoil path
+ * Replaces Unet.forward (model/diffusion_2d.py:369-408) and GaussianDiffusion.p_sample /
+ * p_sample_loop (model/diffusion_2d.py:788-907) of the reference for the sampling path
+ * (no self-conditioning, no learned variance, objective pred_noise).
+ *
+ * Device layout of states and model outputs: channel-last fp32 [images, H*W, CP] with
+ * CP = cindm_unet2d_padded_channels() (channels rounded up to a multiple of 4; padding
+ * channels are zero).  An "image" is one boundary of one design: images = B * num_boundaries,
+ * boundary-major inside a design, exactly the reference's [B, nb*C, H, W] -> [B*nb, C, H, W]
+ * view (:901). */
+typedef struct cindm_unet2d cindm_unet2d;
+
+typedef struct {
+    int32_t dim;              /* Unet(dim=...)                              :283 */
+    int32_t n_mults;
+    int32_t dim_mults[4];     /* entries 1 or 2                             :287 */
+    int32_t channels;         /* 21 for the airfoil states (6 frames*3 + 3) :288 */
+    int32_t image_size;       /* square, power of two <= 64                 :660 */
+    int32_t timesteps;        /* rows of the per-timestep scale/shift table */
+} cindm_unet2d_desc;
+
+int  cindm_unet2d_create(const cindm_unet2d_desc* desc, cindm_unet2d** out);
+void cindm_unet2d_destroy(cindm_unet2d* h);
+int  cindm_unet2d_num_params(const cindm_unet2d* h);
+int  cindm_unet2d_param_info(const cindm_unet2d* h, int idx, char* name, int name_cap,
+                             int64_t shape[4], int* ndim);
+int  cindm_unet2d_set_param(cindm_unet2d* h, const char* key, const float* src, int64_t numel,
+                            int on_device);
+int  cindm_unet2d_set_sinusoid_table(cindm_unet2d* h, const float* table, int64_t numel);
+/* Weight standardisation (WeightStandardizedConv2d :116-124) folded, MFMA-fragment repack,
+ * time path (SinusoidalPosEmb -> Linear -> GELU -> Linear -> per block SiLU -> Linear, :320-326,
+ * :205-208) evaluated for every timestep into a device table. */
+int  cindm_unet2d_finalize(cindm_unet2d* h, void* stream);
+int  cindm_unet2d_padded_channels(const cindm_unet2d* h);
+size_t cindm_unet2d_workspace_bytes(const cindm_unet2d* h, int64_t images);
+int  cindm_unet2d_launches_per_forward(const cindm_unet2d* h);
+/* eps[images, H*W, CP] = Unet(x[images, H*W, CP], t); t_dev (device int32) wins over t. */
+int  cindm_unet2d_forward(cindm_unet2d* h, const float* x, int32_t t, const int32_t* t_dev,
+                          float* eps, int64_t images, void* ws, size_t ws_bytes, void* stream);
+/* Test hook: copy the intermediate activation `name` of the last forward into dst as
+ * [images, H*W, C]; shape receives (images, H*W, C). */
+int  cindm_unet2d_tap(cindm_unet2d* h, const char* name, int64_t images, void* ws, float* dst,
+                      int64_t dst_cap, int64_t shape[3], void* stream);
+
+size_t cindm_ddpm2d_workspace_bytes(const cindm_unet2d* u, int64_t images);
+/* One reverse step x_t -> x_{t-1} of GaussianDiffusion.p_sample (:788-808) for B designs of
+ * nb boundaries: Unet on all B*nb images; the model output's state channels (all but the last
+ * 3) are averaged (use_average_share=1) or summed over the nb boundaries of a design
+ * (share_states_over_boundaries :712-725); x0 from eps, clamp; posterior mean; + sigma_t * z
+ * with z shared over the boundaries for the state channels (sample_noise :775-785).  z comes
+ * from noise_state [B, H*W, C-3] / noise_boundary [B*nb, H*W, 3] when given, else from the
+ * counter-based generator (seed, sample_offset + b, t).  In place on x.  Optional outputs:
+ * x0_out (clamped x_start), mean_out (posterior mean), both [B*nb, H*W, CP]. */
+int  cindm_ddpm2d_step(cindm_ddpm1d* sched, cindm_unet2d* u, float* x, int64_t B, int32_t nb,
+                       int32_t use_average_share, int32_t clip_denoised,
+                       const float* noise_state, const float* noise_boundary, uint64_t seed,
+                       int64_t sample_offset, int32_t t, const int32_t* t_dev, float* x0_out,
+                       float* mean_out, void* ws, size_t ws_bytes, void* stream);
+/* p_sample_loop (:893-907) without design guidance: steps t_start .. t_end in place on x, one
+ * captured HIP graph replayed per step when use_graph.  noise_*_steps, when given, are indexed
+ * [timesteps, ...] by t. */
+int  cindm_ddpm2d_sample(cindm_ddpm1d* sched, cindm_unet2d* u, float* x, int64_t B, int32_t nb,
+                         int32_t use_average_share, const float* noise_state_steps,
+                         const float* noise_boundary_steps, uint64_t seed, int64_t sample_offset,
+                         int32_t t_start, int32_t t_end, void* ws, size_t ws_bytes, void* stream,
+                         int32_t use_graph);
+/* x_T for the 2-D path (sample_noise :775-785, :895): state channels shared over the boundaries of a design. */
+int  cindm_fill_noise2d(float* x, int64_t B, int32_t nb, int32_t hw, int32_t channels,
+                        int32_t padded_channels, uint64_t seed, int64_t sample_offset,
+                        int32_t step_tag, void* stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,201 @@
+"""GPU (MI355X): the 2-D airfoil path (Unet + boundary-sharing DDPM, BASELINE config 5) through the C ABI, against
+(1) the committed golden vectors captured from the reference and (2) the CPU oracle on fresh seeded inputs, plus
+size-independent properties.
+
+Tolerances (max-abs error / max-abs value, fp32): single Unet forwards and single reverse steps 2e-5, the
+free-running 1000-step chain 1e-4 (north_star's trajectory tolerance)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cindm_amd
+import cindm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = 2e-5
+TOL_STEP = 2e-5
+TOL_CHAIN = 1e-4
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().float(), torch.as_tensor(b).detach().cpu().float()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def design_grad(x):
+    g = torch.zeros_like(x)
+    g[:, -3:] = x[:, -3:] - 0.25
+    return g
+
+
+def build_unet2d(device, image_size=64, seed=0):
+    sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), seed)
+    m = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=image_size)
+    m.load_state_dict(sd, strict=True)
+    return m.to(device), sd
+
+
+@pytest.fixture(scope="module")
+def unet2d(device):
+    return build_unet2d(device)
+
+
+@pytest.fixture(scope="module")
+def diff2d(device, unet2d):
+    return cindm_amd.GaussianDiffusion(unet2d[0], image_size=64, frames=6, cond_frames=2, timesteps=1000,
+                                       sampling_timesteps=1000, loss_type="l2", objective="pred_noise").to(device)
+
+
+TAPS = ["init_conv", "downs.0.0", "downs.0.1", "downs.0.2", "downs.0.3", "downs.1.0", "downs.1.2", "downs.1.3",
+        "mid_block1", "mid_attn", "mid_block2", "ups.0.0", "ups.0.1", "ups.0.2", "ups.0.3", "ups.1.1", "ups.1.2",
+        "ups.1.3", "final_res_block"]
+
+
+def test_unet2d_forward_golden(gold_dir, device, unet2d):
+    g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
+    m, _ = unet2d
+    x = torch.from_numpy(g["x"]).to(device)
+    for t in (0, 500, 999):
+        out = m(x, torch.full((2,), t, device=device))
+        assert rel(out, g[f"eps_t{t}"]) < TOL_FWD, t
+
+
+def test_unet2d_blocks_golden(gold_dir, device, unet2d):
+    """Every block's output (fingerprinted in the golden file by an 8x8 crop and per-channel means)."""
+    g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
+    m, _ = unet2d
+    x = torch.from_numpy(g["x"]).to(device)
+    m(x, torch.full((2,), 500, device=device))
+    for n in TAPS:
+        v = m.tap(n, 2).cpu()
+        ref_crop = torch.from_numpy(g["tap." + n + ".crop"])
+        ref_mean = torch.from_numpy(g["tap." + n + ".cmean"])
+        crop = v[:, :, 8:16, 24:32]
+        assert crop.shape == ref_crop.shape, n
+        scale = float(ref_crop.abs().max())
+        assert float((crop - ref_crop).abs().max()) / scale < 5e-5, n
+        assert float((v.mean(dim=(2, 3)) - ref_mean).abs().max()) / scale < 2e-5, n
+
+
+def test_unet2d_vs_oracle_fresh_inputs(device, unet2d):
+    m, sd = unet2d
+    gx = torch.Generator().manual_seed(77)
+    x = torch.randn((3, 21, 64, 64), generator=gx) * 0.8
+    for t in (7, 650):
+        ref = O.unet2d_forward(sd, x, torch.full((3,), t, dtype=torch.long))
+        out = m(x.to(device), t)
+        assert rel(out, ref) < TOL_FWD, t
+
+
+def test_unet2d_image_size_32_vs_oracle(device):
+    """Another geometry (32x32 -> 16x16 bottleneck) exercises the tile / halo arithmetic away from the 64x64 case."""
+    m, sd = build_unet2d(device, image_size=32, seed=3)
+    gx = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 21, 32, 32), generator=gx)
+    ref = O.unet2d_forward(sd, x, torch.full((2,), 123, dtype=torch.long))
+    out = m(x.to(device), 123)
+    assert rel(out, ref) < TOL_FWD
+
+
+def test_unet2d_repeatable(device, unet2d):
+    m, _ = unet2d
+    x = torch.randn((4, 21, 64, 64), device=device)
+    a = m(x, 300)
+    for _ in range(5):
+        assert torch.equal(m(x, 300), a)
+
+
+# ------------------------------------------------------------------ single reverse steps
+@pytest.mark.parametrize("tag,fn,guid,ts", [("plain", None, "standard", (999, 500, 1, 0)),
+                                            ("design_std", design_grad, "standard", (500,)),
+                                            ("design_alpha", design_grad, "standard-alpha", (500,))])
+def test_step2d_golden(gold_dir, device, diff2d, tag, fn, guid, ts):
+    g = np.load(os.path.join(gold_dir, "steps_2d.npz"))
+    shape = (1, 2, 21, 64, 64)
+    for t in ts:
+        x = torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device)
+        nz = O.sample_noise_2d(torch.from_numpy(g[f"{tag}.t{t}.state"]), torch.from_numpy(g[f"{tag}.t{t}.boundary"]))
+        out, x0 = diff2d.p_sample(shape, x, t, None, design_fn=fn, design_guidance=guid,
+                                  noise=nz.reshape(2, 21, 64, 64).to(device))
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP, (tag, t)
+        assert rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (tag, t)
+
+
+def test_step2d_sum_share_vs_oracle(device, unet2d):
+    """use_average_share=False (sum over boundaries), 3 boundaries, 2 designs."""
+    m, sd = unet2d
+    d = cindm_amd.GaussianDiffusion(m, image_size=64, frames=6, timesteps=1000, use_average_share=False).to(device)
+    od = O.Diffusion2D(sd, image_size=64, frames=6, use_average_share=False)
+    shape = (2, 3, 21, 64, 64)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((6, 21, 64, 64), generator=g)
+    nz = O.sample_noise_2d(torch.randn((2, 1, 18, 64, 64), generator=g), torch.randn((2, 3, 3, 64, 64), generator=g)).reshape(6, 21, 64, 64)
+    ref, ref0 = O.p_sample_2d(od, shape, x.clone(), 400, nz)
+    out, x0 = d.p_sample(shape, x.to(device), 400, noise=nz.to(device))
+    assert rel(out, ref) < TOL_STEP and rel(x0, ref0) < TOL_STEP
+
+
+# ------------------------------------------------------------------ whole chains
+def _tape(seed, B, nb, C, H, W, T):
+    g = torch.Generator().manual_seed(seed)
+    init = (torch.randn((B, 1, C - 3, H, W), generator=g), torch.randn((B, nb, 3, H, W), generator=g))
+    ss = torch.zeros((T, B, 1, C - 3, H, W))
+    sb = torch.zeros((T, B, nb, 3, H, W))
+    for t in range(T - 1, 0, -1):
+        ss[t] = torch.randn((B, 1, C - 3, H, W), generator=g)
+        sb[t] = torch.randn((B, nb, 3, H, W), generator=g)
+    return cindm_amd.NoiseTape2D(init, ss, sb)
+
+
+def test_chain2d_cfg5_golden(gold_dir, device, diff2d):
+    """BASELINE config 5: sample(batch_size=1, num_boundaries=2), 1000 steps, the reference's own noise draws."""
+    g = np.load(os.path.join(gold_dir, "chains_2d.npz"))
+    tape = _tape(2001, 1, 2, 21, 64, 64, 1000)
+    out = diff2d.sample(batch_size=1, num_boundaries=2, noise=tape)
+    assert out.shape == (1, 2, 21, 64, 64)
+    assert rel(out, g["cfg5.final"]) < TOL_CHAIN
+    # intermediate checkpoints: re-run stopping early
+    for t, crop in zip(g["cfg5.ckpt_t"], g["cfg5.ckpt_crop"]):
+        if t in (750, 250):
+            part = diff2d.sample(batch_size=1, num_boundaries=2, noise=tape, t_stop=int(t))
+            assert rel(part[:, :, :, 16:32, 16:32], crop) < TOL_CHAIN, t
+
+
+def test_chain2d_graph_equals_stream(device, diff2d):
+    a = diff2d.sample(batch_size=2, num_boundaries=2, seed=11, t_stop=980)
+    b = diff2d.sample(batch_size=2, num_boundaries=2, seed=11, t_stop=980, use_graph=False)
+    assert torch.equal(a, b)
+    c = diff2d.sample(batch_size=2, num_boundaries=2, seed=12, t_stop=980)
+    assert not torch.equal(a, c)
+
+
+def test_chain2d_states_shared_over_boundaries(device, diff2d):
+    """Size-independent property: the state channels of all boundary copies of a design stay identical through the
+    whole chain (shared x_T, shared predicted noise, shared step noise); the boundary channels do not."""
+    out = diff2d.sample(batch_size=3, num_boundaries=3, seed=5, t_stop=900)
+    assert torch.equal(out[:, 0, :-3], out[:, 1, :-3]) and torch.equal(out[:, 0, :-3], out[:, 2, :-3])
+    assert not torch.equal(out[:, 0, -3:], out[:, 1, -3:])
+    assert torch.isfinite(out).all()
+
+
+def test_chain2d_sharding_invariance(device, diff2d):
+    """Designs are independent: sampling designs [0,4) at once equals [0,2) and [2,4) with sample_offset."""
+    full = diff2d.sample(batch_size=4, num_boundaries=2, seed=3, t_stop=990)
+    lo = diff2d.sample(batch_size=2, num_boundaries=2, seed=3, t_stop=990, sample_offset=0)
+    hi = diff2d.sample(batch_size=2, num_boundaries=2, seed=3, t_stop=990, sample_offset=2)
+    assert torch.equal(full[:2], lo) and torch.equal(full[2:], hi)
+
+
+def test_guided_chain2d_vs_oracle_short(device, unet2d, diff2d):
+    """design_fn guidance over the first 6 steps against the oracle with the same tape."""
+    _, sd = unet2d
+    od = O.Diffusion2D(sd, image_size=64, frames=6)
+    tape = _tape(77, 1, 2, 21, 64, 64, 1000)
+    steps = {t: (tape.step_state[t], tape.step_boundary[t]) for t in range(1, 1000)}
+    ref = O.p_sample_loop_2d(od, (1, 2, 21, 64, 64), tape.init, steps, design_grad, "standard-alpha", t_stop=994)
+    out = diff2d.sample(batch_size=1, num_boundaries=2, design_fn=design_grad, design_guidance="standard-alpha",
+                        noise=tape, t_stop=994)
+    assert rel(out, ref) < TOL_STEP * 3
