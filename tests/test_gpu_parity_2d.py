@@ -121,7 +121,10 @@ def test_step2d_golden(gold_dir, device, diff2d, tag, fn, guid, ts):
         out, x0 = diff2d.p_sample(shape, x, t, None, design_fn=fn, design_guidance=guid,
                                   noise=nz.reshape(2, 21, 64, 64).to(device))
         assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP, (tag, t)
-        assert rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (tag, t)
+        # x_start = sqrt(1/abar) x - sqrt(1/abar - 1) eps amplifies the Unet's own rounding by sqrt(1/abar - 1), which is
+        # 1.8e3 at t = 999 of the sigmoid schedule (unclamped entries only): the tolerance of x_start carries that factor
+        amp = max(1.0, float(diff2d.sqrt_recipm1_alphas_cumprod[t]))
+        assert rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP * amp, (tag, t)
 
 
 def test_step2d_sum_share_vs_oracle(device, unet2d):

@@ -33,6 +33,41 @@ def test_descriptor_structs_match_header_layout():
     assert C.sizeof(_ffi.UnetDesc) == 4 * (4 + 8 + 2)
     assert C.sizeof(_ffi.ComposeDesc) == 9 * 4
     assert C.sizeof(_ffi.SchedDesc) == 8 + 13 * 8
+    assert C.sizeof(_ffi.Unet2dDesc) == 4 * (2 + 4 + 3)
+
+
+def test_state_dict_contract_2d(gold_dir):
+    man = json.load(open(os.path.join(gold_dir, "manifest_2d.json")))["unet2d_d64_m12_c21"]
+    m = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21)
+    assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == list(man.items())
+    sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
+    m.load_state_dict(sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+    assert m.channels == 21 and m.out_dim == 21 and m.padded_channels == 24 and not m.self_condition
+    with pytest.raises(NotImplementedError):
+        cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, self_condition=True)
+    with pytest.raises(cindm_amd.CindmError):
+        cindm_amd.Unet(dim=32, dim_mults=(1, 2), channels=21)
+    with pytest.raises(cindm_amd.CindmError):                 # no CPU execution path
+        m(torch.zeros(1, 21, 64, 64), 0)
+    d = cindm_amd.GaussianDiffusion(m, image_size=64, frames=6, timesteps=1000)
+    tab = O.make_schedule("sigmoid", 1000)
+    for k in O.SCHEDULE_BUFFERS:
+        assert torch.equal(getattr(d, k), tab[k]), k
+    with pytest.raises(cindm_amd.CindmError):
+        d.sample(batch_size=1, num_boundaries=2)
+    with pytest.raises(NotImplementedError):
+        cindm_amd.GaussianDiffusion(m, image_size=64, frames=6, objective="pred_x0")
+
+
+def test_layout_round_trip_2d():
+    from cindm_amd.unet2d import from_device_layout, to_device_layout
+    x = torch.randn(3, 21, 8, 8)
+    y = to_device_layout(x, 24)
+    assert y.shape == (3, 64, 24) and torch.equal(y[:, :, 21:], torch.zeros(3, 64, 3))
+    assert torch.equal(y[1, 2 * 8 + 5, 7], x[1, 7, 2, 5])
+    assert torch.equal(from_device_layout(y, 21, 8, 8), x)
 
 
 @pytest.mark.parametrize("hz,F,att", [(24, 8, True), (24, 4, True), (24, 16, True), (44, 8, True), (8, 8, True), (6, 8, True), (24, 8, False)])

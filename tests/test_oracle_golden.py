@@ -172,3 +172,83 @@ def test_chain_tails(gold_dir, sd8, sd4):
     tape = O.NoiseTape.make(1238, (2, 20, 16), 400)
     out = O.sample_compose_multibodies(d4, cond4, 400, tape, resume=(100, ck("cfg4_script", 100)))
     assert rel(out, g["cfg4_script.final"]) < TOL
+
+
+# ====================================================================== 2-D airfoil path (BASELINE config 5)
+@pytest.fixture(scope="module")
+def sd2d():
+    return O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
+
+
+def design_grad_2d(x):
+    """The design callback the 2-D goldens were captured with (oracle/make_golden_2d.py): returns a gradient."""
+    g = torch.zeros_like(x)
+    g[:, -3:] = x[:, -3:] - 0.25
+    return g
+
+
+def tape_2d(seed, B, nb, C, H, W, T):
+    g = torch.Generator().manual_seed(seed)
+    init = (torch.randn((B, 1, C - 3, H, W), generator=g), torch.randn((B, nb, 3, H, W), generator=g))
+    steps = {}
+    for t in range(T - 1, 0, -1):
+        steps[t] = (torch.randn((B, 1, C - 3, H, W), generator=g), torch.randn((B, nb, 3, H, W), generator=g))
+    return init, steps
+
+
+def test_manifest_2d(gold_dir):
+    ref = json.load(open(os.path.join(gold_dir, "manifest_2d.json")))["unet2d_d64_m12_c21"]
+    mine = O.unet2d_param_shapes(64, (1, 2), 21)
+    assert [(k, list(v)) for k, v in mine.items()] == list(ref.items())
+    assert len(ref) == 160 and sum(int(np.prod(v)) for v in ref.values()) == 3108501
+
+
+def test_unet2d_forward(gold_dir, sd2d):
+    g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
+    x = torch.from_numpy(g["x"])
+    taps = {}
+    out = O.unet2d_forward(sd2d, x, torch.full((2,), 500, dtype=torch.long), taps=taps)
+    assert rel(out, g["eps_t500"]) < TOL
+    for k in g.files:
+        if k.startswith("tap.") and k.endswith(".crop"):
+            n = k[4:-5]
+            assert rel(taps[n][:, :, 8:16, 24:32], g[k]) < TOL, n
+            assert rel(taps[n].mean(dim=(2, 3)), g["tap." + n + ".cmean"]) < 1e-5, n
+    out = O.unet2d_forward(sd2d, x, torch.full((2,), 0, dtype=torch.long))
+    assert rel(out, g["eps_t0"]) < TOL
+
+
+@pytest.mark.parametrize("tag,fn,guid,ts", [("plain", None, "standard", (999, 1, 0)),
+                                            ("design_std", design_grad_2d, "standard", (500,)),
+                                            ("design_alpha", design_grad_2d, "standard-alpha", (500,))])
+def test_steps_2d(gold_dir, sd2d, tag, fn, guid, ts):
+    g = np.load(os.path.join(gold_dir, "steps_2d.npz"))
+    od = O.Diffusion2D(sd2d, image_size=64, frames=6)
+    shape = (1, 2, 21, 64, 64)
+    for t in ts:
+        nz = O.sample_noise_2d(torch.from_numpy(g[f"{tag}.t{t}.state"]), torch.from_numpy(g[f"{tag}.t{t}.boundary"]))
+        out, x0 = O.p_sample_2d(od, shape, torch.from_numpy(g[f"{tag}.t{t}.x"]), t, nz.reshape(2, 21, 64, 64), fn, guid)
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL, (tag, t)
+
+
+def test_share_states_properties():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((6, 21, 8, 8), generator=g)
+    y = O.share_states_over_boundaries(x, 2, 3, True)
+    assert torch.equal(y[:, -3:], x[:, -3:])                              # boundary channels untouched
+    assert torch.equal(y[0, :-3], y[1, :-3]) and torch.equal(y[3, :-3], y[5, :-3])
+    assert torch.allclose(y[0, :-3], x[:3, :-3].mean(0))
+    s = O.share_states_over_boundaries(x, 2, 3, False)
+    assert torch.allclose(s[0, :-3], x[:3, :-3].sum(0))
+    assert torch.equal(O.share_states_over_boundaries(y, 2, 3, True)[:, :-3], y[:, :-3]) or \
+        torch.allclose(O.share_states_over_boundaries(y, 2, 3, True), y, atol=1e-6)   # idempotent
+
+
+def test_chain_2d_head(gold_dir, sd2d):
+    """First 250 steps of the config-5 chain (1 design x 2 boundaries) against the reference's checkpoint."""
+    g = np.load(os.path.join(gold_dir, "chains_2d.npz"))
+    od = O.Diffusion2D(sd2d, image_size=64, frames=6)
+    init, steps = tape_2d(2001, 1, 2, 21, 64, 64, 1000)
+    out = O.p_sample_loop_2d(od, (1, 2, 21, 64, 64), init, steps, t_stop=750)
+    i = list(g["cfg5.ckpt_t"]).index(750)
+    assert rel(out[:, :, :, 16:32, 16:32], g["cfg5.ckpt_crop"][i]) < TOL
