@@ -3,35 +3,41 @@
 //
 // Layout: channel-last fp32 [image, y, x, C] = rows (image*H*W + y*W + x) x C.
 //
-// conv2d_gemm_kernel<NT, LROWS, MODE>: implicit-GEMM Conv2d on fp32 MFMA (v_mfma_f32_16x16x4_f32), same tile /
-// wave decomposition as the 1-D kernel (48 output pixels x 32 output channels per workgroup, K split over 4 waves,
-// B fragments straight from L2 in fragment order, A staged through LDS with normalise-on-load).  A tile is 48
-// consecutive pixels (row-major) of ONE image; the source pixels every tap of the tile can touch form one contiguous
-// range of the flattened source image, which is what gets staged; a tap is then an LDS row offset computed per lane
-// (out-of-image taps point at a zero row).  Tap geometries: k x k convolution (1x1, 3x3, 7x7 as 7 tap groups of 7),
-// 3x3 over the nearest-neighbour x2 upsampled source (Upsample :99-103), and the four taps of the pixel-unshuffle
-// 1x1 (Downsample :105-109) -- neither the upsampled nor the unshuffled tensor is ever materialised.
+// conv2d_tile_kernel<KIND, MODE>: implicit-GEMM Conv2d on fp32 MFMA (v_mfma_f32_16x16x4_f32).  One workgroup =
+// a 4 x 16 pixel tile of one image x 64 output channels; K (input channels x taps) is split over the 4 waves inside
+// every 32/64-channel chunk and reduced through LDS once at the end; B fragments come straight from L2 in fragment
+// order; the A halo tile ((4+2) x (16+2) pixels for 3x3) is staged through LDS with normalise-on-load, image borders
+// zero-filled at staging time, so every tap of every fragment row is the SAME constant LDS offset from a per-lane
+// base (ds_read immediates, no address arithmetic in the loop).  Tap geometries: 3x3, 1x1, 3x3 over the
+// nearest-neighbour x2 upsampled source (Upsample :99-103; the halo tile is staged from source pixel (y>>1, x>>1)),
+// and the four taps of the pixel-unshuffle 1x1 (Downsample :105-109; an 8 x 32 source tile) -- neither the upsampled
+// nor the unshuffled tensor is ever materialised.  conv2d_stem7_kernel: the 7x7 stem, K flattened over
+// (tap, channel) so that the 21(24)-channel input wastes no MFMA lanes.
 #pragma once
 #include "kernels.h"
 
 namespace cindm {
 
 enum SrcMode2d { SRC2_PLAIN = 0, SRC2_GN_SS_SILU = 4, SRC2_LN = 2 };
-enum ConvKind { CONV_KXK = 0, CONV_UP2 = 1, CONV_UNSHUF = 2 };
+enum ConvKind { CONV_3X3 = 0, CONV_1X1 = 1, CONV_UP2 = 2, CONV_UNSHUF = 3, CONV_STEM7 = 4 };
+
+constexpr int T2Y = 4, T2X = 16, T2M = T2Y * T2X;    // output pixel tile 4 x 16
+constexpr int T2N = 64;                               // output channels per workgroup
+constexpr int LDR2 = 33;                              // reduce tile pitch (32 columns per pass)
 
 struct Conv2dArgs {
     Src src[2];           // stats: merged GroupNorm (mean, M2) [NI][8][2] (cnt = H*W*gw) or LN partials [rows][P][2]
     int nsrc;
-    const float* W;       // [n-tile][stage = chunk*TG + tap group][q][thread][4]
+    const float* W;       // [n-tile][stage][q][thread][4]
     const float* bias;
     int CinP, Npad, N;
-    int NI, Hin, Win, Hout, Wout, wout_log2;
-    int kind, kw, TG, tpi;
+    int NI, Hin, Win, Hout, Wout;
+    int tiles_x, tpi;     // tiles per image row / per image
     float* out; int ldo;
     const float* res; int ldres;
     const float* e_y; int e_ld; const float* e_stats; int e_gw; float e_cnt; const float* e_gamma; const float* e_beta;
     float* stats_out; int so_gw;        // GroupNorm (mean, M2) partials per tile: [NI][8][tpi][2]
-    float* ln_out;                      // LayerNorm partials per row and 32-column tile: [rows][Npad/32][2]
+    float* ln_out;                      // LayerNorm partials per pixel and 32-column block: [rows][Npad/32][2]
     const int* t_ptr; int t_imm;
 };
 
@@ -41,58 +47,190 @@ __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int NT, int LROWS, int MODE>
-__global__ __launch_bounds__(256) void conv2d_gemm_kernel(const Conv2dArgs a) {
-    constexpr int KC = 32, LDAK = KC + 2, CS = 2, KS = NT * CS;
-    constexpr int RPP = 32, NP = LROWS / RPP, ZR = LROWS;
-    static_assert(LROWS % RPP == 0, "LROWS must be a multiple of 32");
-    __shared__ __attribute__((aligned(16))) float As[2][(LROWS + 1) * LDAK];
-    __shared__ __attribute__((aligned(16))) float Red[4][TM * LDR];
-    __shared__ float tabA[128];             // GN: [8](mean, rstd) of this image;  LN: unused (row stats kept per thread)
+template <int KIND> struct Cfg2 {
+    static constexpr int KC = (KIND == CONV_1X1) ? 64 : 32;                       // channels per chunk
+    static constexpr int CS = KC / 16;                                            // k-steps (of 4 channels) per wave per tap
+    static constexpr int TPS = (KIND == CONV_1X1) ? 1 : (KIND == CONV_UNSHUF) ? 4 : 3;   // taps per B stage
+    static constexpr int SPC = (KIND == CONV_3X3 || KIND == CONV_UP2) ? 3 : 1;    // B stages per chunk
+    static constexpr int SW = (KIND == CONV_1X1) ? 16 : (KIND == CONV_UNSHUF) ? 32 : 18;  // staged tile width
+    static constexpr int R = (KIND == CONV_1X1) ? 64 : (KIND == CONV_UNSHUF) ? 256 : 108; // staged rows
+    static constexpr int LDAK = KC + 4;                                           // LDS row pitch (conflict-free fragments)
+    static constexpr int NBF = TPS * CS;                                          // float4 of B per thread per stage
+    static constexpr int F4 = KC / 4, RPP = 256 / F4, NP = (R + RPP - 1) / RPP;   // staging: float4 per row, rows per pass
+};
+
+// 16 MFMAs per k-step: 4 pixel rows x 4 column blocks; A fragments read one k-step ahead into a second register set
+template <int KIND, int TR>
+__device__ __forceinline__ void mma_stage(const float* __restrict__ Ab, const float (&b)[Cfg2<KIND>::NBF][4], f32x4 (&acc)[4][4]) {
+    using C = Cfg2<KIND>;
+    constexpr int NK = C::TPS * C::CS;
+    float af[2][4];
+    auto off = [](int mb, int ks) constexpr -> int {
+        const int j = ks / C::CS, cs = ks % C::CS;
+        int row = 0;
+        if (KIND == CONV_1X1) row = mb * 16;
+        else if (KIND == CONV_UNSHUF) row = (2 * mb + (j >> 1)) * 32 + (j & 1);
+        else row = (mb + TR) * C::SW + j;
+        return row * C::LDAK + cs * 4;
+    };
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) af[0][mb] = Ab[off(mb, 0)];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) af[(ks + 1) & 1][mb] = Ab[off(mb, ks + 1)];
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][mb], b[ks][nb], acc[mb][nb], 0, 0, 0);
+    }
+}
+
+// Shared epilogue: cross-wave K reduction through LDS in two 32-column passes, bias, + SiLU(GroupNorm(e_y)),
+// + residual, store, GroupNorm (mean, M2) partial of the tile, LayerNorm row partials.
+__device__ __forceinline__ void conv2d_epilogue(const Conv2dArgs& a, f32x4 (&acc)[4][4], float (*Red)[T2M * LDR2], const float* tabE,
+                                                int img, int ti, int ty0, int tx0) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x;
+    const int n = tid & 31, rq = tid >> 5;
+    const size_t img_base = (size_t)img * a.Hout * a.Wout;
+    size_t prow[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = rq + 8 * q;
+        prow[q] = img_base + (size_t)(ty0 + (r >> 4)) * a.Wout + tx0 + (r & 15);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int gn = nt * T2N + h * 32 + n;
+        if (nt * T2N + h * 32 >= a.N) break;             // uniform: nothing real in this half
+        const bool nok = gn < a.N;
+        const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+        float eg = 1.f, eb = 0.f, em = 0.f, er = 1.f;
+        float ey[8], rs[8];
+        if (a.e_y && nok) {
+            eg = a.e_gamma[gn]; eb = a.e_beta[gn];
+            const int g = gn >> (31 - __builtin_clz(a.e_gw));
+            em = tabE[2 * g]; er = tabE[2 * g + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ey[q] = (a.e_y && nok) ? a.e_y[prow[q] * a.e_ld + gn] : 0.f;
+            rs[q] = (a.res && nok) ? a.res[prow[q] * a.ldres + gn] : 0.f;
+        }
+        if (h) __syncthreads();                            // pass 0's statistics readers are done with Red
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR2 + nb * 16 + (lane & 15)] = acc[mb][2 * h + nb][rg];
+        __syncthreads();
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = rq + 8 * q;
+            float x = (Red[0][r * LDR2 + n] + Red[1][r * LDR2 + n]) + (Red[2][r * LDR2 + n] + Red[3][r * LDR2 + n]) + bias;
+            if (a.e_y) x += silu_f((ey[q] - em) * er * eg + eb);
+            if (a.res) x += rs[q];
+            if (nok) a.out[prow[q] * a.ldo + gn] = x;
+            v[q] = nok ? x : 0.f;
+        }
+        if (!a.stats_out && !a.ln_out) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Red[0][(rq + 8 * q) * LDR2 + n] = v[q];     // own slots only
+        __syncthreads();
+        if (a.stats_out) {
+            // GroupNorm partial of this tile: shifted one-pass sums about a pivot of the group, 8 rows per thread
+            const int gwt = a.so_gw;                       // 8 or 16: whole groups inside the 32 columns
+            const float K = Red[0][n & ~(gwt - 1)];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float d = v[q] - K; s1 += d; s2 += d * d; }
+            Red[1][rq * 32 + n] = s1; Red[2][rq * 32 + n] = s2;
+            __syncthreads();
+            if (tid < 32) {
+                s1 = 0.f; s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1 += Red[1][j * 32 + n]; s2 += Red[2][j * 32 + n]; }
+                s1 = seg_total(s1, gwt);
+                s2 = seg_total(s2, gwt);
+                if ((n & (gwt - 1)) == gwt - 1 && nok) {
+                    const float ne = (float)(T2M * gwt);
+                    const int g = gn >> (31 - __builtin_clz(gwt));
+                    float* o = a.stats_out + (((size_t)img * 8 + g) * a.tpi + ti) * 2;
+                    o[0] = K + s1 / ne;
+                    o[1] = fmaxf(s2 - s1 * s1 / ne, 0.f);
+                }
+            }
+        }
+        if (a.ln_out) {
+            const int r = tid >> 2, sub = tid & 3;         // 64 rows x 4 sub-ranges of 8 columns
+            const float K = Red[0][r * LDR2];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float d = Red[0][r * LDR2 + sub * 8 + c] - K; s1 += d; s2 += d * d; }
+            s1 = seg_total(s1, 4);
+            s2 = seg_total(s2, 4);
+            if (sub == 3) {
+                const size_t pr = img_base + (size_t)(ty0 + (r >> 4)) * a.Wout + tx0 + (r & 15);
+                float* o = a.ln_out + (pr * (a.Npad / 32) + nt * 2 + h) * 2;
+                o[0] = K + s1 * (1.0f / 32.0f);
+                o[1] = fmaxf(s2 - s1 * s1 * (1.0f / 32.0f), 0.f);
+            }
+        }
+    }
+}
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256, 2) void conv2d_tile_kernel(const Conv2dArgs a) {
+    using C = Cfg2<KIND>;
+    constexpr int KC = C::KC, LDAK = C::LDAK, NBF = C::NBF, NP = C::NP, R = C::R, SW = C::SW, RPP = C::RPP, F4 = C::F4, SPC = C::SPC;
+    __shared__ __attribute__((aligned(16))) float As[2][R * LDAK];
+    __shared__ __attribute__((aligned(16))) float Red[4][T2M * LDR2];
+    __shared__ float tabA[16];
     __shared__ float tabE[16];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int img = mt / a.tpi, ti = mt - img * a.tpi;
-    const int HWo = a.Hout * a.Wout, HWi = a.Hin * a.Win;
-    const int p_lo = ti * TM;
-    const int rows_out = min(TM, HWo - p_lo);
-    const int p_hi = p_lo + rows_out - 1;
+    const int tyi = ti / a.tiles_x;
+    const int ty0 = tyi * T2Y, tx0 = (ti - tyi * a.tiles_x) * T2X;
+    const int HWi = a.Hin * a.Win;
     const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
-    const int pad = a.kw >> 1;
 
-    // contiguous source pixel range [s_lo, s_hi) that the taps of this tile can touch
-    int s_lo, s_hi;
-    if (a.kind == CONV_KXK) {
-        s_lo = max(0, p_lo - pad * a.Win - pad);
-        s_hi = min(HWi, p_hi + pad * a.Win + pad + 1);
-    } else if (a.kind == CONV_UP2) {
-        const int y0 = p_lo >> a.wout_log2, y1 = p_hi >> a.wout_log2;
-        s_lo = (max(0, y0 - 1) >> 1) * a.Win;
-        s_hi = ((min(a.Hout - 1, y1 + 1) >> 1) + 1) * a.Win;
-    } else {
-        const int y0 = p_lo >> a.wout_log2, y1 = p_hi >> a.wout_log2;
-        s_lo = (2 * y0) * a.Win;
-        s_hi = (2 * y1 + 2) * a.Win;
-    }
-    const int rows_in = s_hi - s_lo;        // <= LROWS by construction (host checks the geometry)
-
-    f32x4 acc[3][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nch0 = (a.src[0].C + KC - 1) / KC;
-    const int nst = (a.CinP / KC) * a.TG;           // stages (even or 1: host pads)
-    const int c4 = tid & 7, r0 = tid >> 3;
+    // ---- staging geometry: this thread stages float4 c4 of rows r0 + RPP*p of the halo tile ------------------
+    const int c4 = tid % F4, r0 = tid / F4;
     size_t goff[NP];
     bool rok[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int r = r0 + RPP * p;
-        rok[p] = r < rows_in;
-        goff[p] = (size_t)img * HWi + s_lo + min(r, rows_in - 1);
+        const int hy = r / SW, hx = r - hy * SW;
+        int y, x, srcpix;
+        bool ok = r < R;
+        if (KIND == CONV_3X3 || KIND == CONV_UP2) {
+            y = ty0 - 1 + hy; x = tx0 - 1 + hx;
+            ok = ok && (y >= 0) && (y < a.Hout) && (x >= 0) && (x < a.Wout);
+            srcpix = (KIND == CONV_UP2) ? (y >> 1) * a.Win + (x >> 1) : y * a.Win + x;
+        } else if (KIND == CONV_1X1) {
+            y = ty0 + hy; x = tx0 + hx; srcpix = y * a.Win + x;
+        } else {
+            y = 2 * ty0 + hy; x = 2 * tx0 + hx; srcpix = y * a.Win + x;
+        }
+        rok[p] = ok;
+        goff[p] = (size_t)img * HWi + (ok ? srcpix : 0);
     }
-    // LayerNorm on load: the statistics of the rows this thread stages (merged from the producer's partials)
     float lnm[NP], lnr[NP];
     if constexpr (MODE == SRC2_LN) {
         const Src& s = a.src[0];
@@ -100,29 +238,32 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const Conv2dArgs a) {
         for (int p = 0; p < NP; ++p) merge_stats(s.stats + goff[p] * s.P * 2, s.P, s.cnt, 1e-5f, lnm[p], lnr[p]);
     }
 
-    float bcur[KS][2], bnxt[KS][2];
+    const int nch0 = (a.src[0].C + KC - 1) / KC;
+    const int nch = a.CinP / KC;                    // chunks (even or 1: host pads)
+    const int nst = nch * SPC;
+    float bA[NBF][4], bB[NBF][4];
     float4 areg[NP];
-    const float4* wbase = reinterpret_cast<const float4*>(a.W) + (size_t)nt * nst * 256 * (2 * KS / 4) + tid;
-    auto load_b = [&](int st, float (&b)[KS][2]) {
-        const float4* wp = wbase + (size_t)st * 256 * (2 * KS / 4);
+    const float4* wbase = reinterpret_cast<const float4*>(a.W) + (size_t)nt * nst * 256 * NBF + tid;
+    auto load_b = [&](int st, float (&b)[NBF][4]) {
+        const float4* wp = wbase + (size_t)st * 256 * NBF;
 #pragma unroll
-        for (int q = 0; q < 2 * KS / 4; ++q) {
+        for (int q = 0; q < NBF; ++q) {
             const float4 v = wp[q * 256];
-            b[2 * q][0] = v.x; b[2 * q][1] = v.y; b[2 * q + 1][0] = v.z; b[2 * q + 1][1] = v.w;
+            b[q][0] = v.x; b[q][1] = v.y; b[q][2] = v.z; b[q][3] = v.w;
         }
     };
-    auto src_ptr = [&](int cc, int& cl, int& C, int& ld) -> const float* {
+    auto src_ptr = [&](int cc, int& cl, int& Cc, int& ld) -> const float* {
         const bool first = (cc < nch0) || (a.nsrc == 1);
         cl = (first ? cc : cc - nch0) * KC + c4 * 4;
-        C = first ? a.src[0].C : a.src[1].C;
+        Cc = first ? a.src[0].C : a.src[1].C;
         ld = first ? a.src[0].ld : a.src[1].ld;
         return first ? a.src[0].p : a.src[1].p;
     };
     float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), psc = pb, psh = pb;
-    auto load_a = [&](int st, float4 (&v)[NP]) {
-        int cl, C, ld;
-        const float* base = src_ptr(st / a.TG, cl, C, ld);
-        const int clc = min(cl, C - 4);
+    auto load_a = [&](int cc, float4 (&v)[NP]) {
+        int cl, Cc, ld;
+        const float* base = src_ptr(cc, cl, Cc, ld);
+        const int clc = min(cl, Cc - 4);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
             v[p] = *reinterpret_cast<const float4*>(base + goff[p] * ld + clc);
@@ -131,17 +272,16 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const Conv2dArgs a) {
             pg = *reinterpret_cast<const float4*>(s.gamma + clc);
             if constexpr (MODE == SRC2_GN_SS_SILU) {
                 pb = *reinterpret_cast<const float4*>(s.beta + clc);
-                if (s.tb) {         // per-timestep (scale | shift) row of this block: [scale C | shift C]
+                if (s.tb) {         // per-timestep row of this block: [scale C | shift C]
                     psc = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + clc);
                     psh = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + s.C + clc);
                 }
             }
         }
     };
-    load_b(0, bcur);
+    load_b(0, bA);
     load_a(0, areg);
 
-    for (int i = tid; i < 2 * LDAK; i += 256) As[i / LDAK][ZR * LDAK + (i % LDAK)] = 0.f;
     if constexpr (MODE == SRC2_GN_SS_SILU) {
         const Src& s = a.src[0];
         if (tid < 8) {
@@ -150,28 +290,18 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const Conv2dArgs a) {
             tabA[2 * tid] = m; tabA[2 * tid + 1] = r;
         }
     }
-    if (a.e_y && tid < 8) {
+    if (a.e_y && tid >= 64 && tid < 72) {
         float m, r;
-        merge_stats(a.e_stats + ((size_t)img * 8 + tid) * 2, 1, a.e_cnt, 1e-5f, m, r);
-        tabE[2 * tid] = m; tabE[2 * tid + 1] = r;
-    }
-    // output pixel (y, x) of this lane's fragment rows
-    int fy[3], fx[3];
-    bool fok[3];
-#pragma unroll
-    for (int mb = 0; mb < 3; ++mb) {
-        const int r = mb * 16 + (lane & 15);
-        const int pix = p_lo + min(r, rows_out - 1);
-        fy[mb] = pix >> a.wout_log2; fx[mb] = pix & (a.Wout - 1);
-        fok[mb] = r < rows_out;
+        merge_stats(a.e_stats + ((size_t)img * 8 + (tid - 64)) * 2, 1, a.e_cnt, 1e-5f, m, r);
+        tabE[2 * (tid - 64)] = m; tabE[2 * (tid - 64) + 1] = r;
     }
     const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
 
-    auto store_a = [&](int st, int buf, const float4 (&av)[NP]) {
-        int cl, C, ld;
-        (void)src_ptr(st / a.TG, cl, C, ld);
-        const bool cok = cl < C;
-        const int clc = min(cl, C - 4);
+    auto store_a = [&](int cc, int buf, const float4 (&av)[NP]) {
+        int cl, Cc, ld;
+        (void)src_ptr(cc, cl, Cc, ld);
+        const bool cok = cl < Cc;
+        const int clc = min(cl, Cc - 4);
         float* dst = As[buf];
         float gm = 0.f, gr = 1.f;
         if constexpr (MODE == SRC2_GN_SS_SILU) { const int ti2 = (clc >> gw_shift) * 2; gm = tabA[ti2]; gr = tabA[ti2 + 1]; }
@@ -190,156 +320,165 @@ __global__ __launch_bounds__(256) void conv2d_gemm_kernel(const Conv2dArgs a) {
             }
             const bool ok = rok[p] && cok;
             v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            float2* d2 = reinterpret_cast<float2*>(dst + r * LDAK + c4 * 4);
-            d2[0] = make_float2(v.x, v.y);
-            d2[1] = make_float2(v.z, v.w);
+            if (R % RPP == 0 || r < R) *reinterpret_cast<float4*>(dst + r * LDAK + c4 * 4) = v;
         }
     };
-    // LDS element offset of (fragment row mb, tap tt) for this lane
-    auto tap_addr = [&](int mb, int tt) -> int {
-        int ys, xs; bool ok;
-        if (a.kind == CONV_KXK) {
-            const int q = tt / a.kw;
-            ys = fy[mb] + q - pad; xs = fx[mb] + (tt - q * a.kw) - pad;
-            ok = (ys >= 0) && (ys < a.Hin) && (xs >= 0) && (xs < a.Win);
-        } else if (a.kind == CONV_UP2) {
-            const int q = tt / 3;
-            const int yy = fy[mb] + q - 1, xx = fx[mb] + (tt - q * 3) - 1;
-            ok = (yy >= 0) && (yy < a.Hout) && (xx >= 0) && (xx < a.Wout);
-            ys = yy >> 1; xs = xx >> 1;
-        } else {
-            ys = 2 * fy[mb] + (tt >> 1); xs = 2 * fx[mb] + (tt & 1); ok = true;
-        }
-        const int row = (ok && fok[mb]) ? (ys * a.Win + xs - s_lo) : ZR;
-        return row * LDAK + w * 8 + (lane >> 4);
-    };
+    // per-lane fragment base: pixel column (lane & 15) of the tile, this wave's channel slice, k = lane >> 4
+    const int abase = ((KIND == CONV_UNSHUF) ? 2 * (lane & 15) : (lane & 15)) * LDAK + w * (KC / 4) + (lane >> 4);
 
-    auto stage = [&](int st, const float (&bc)[KS][2], float (&bn)[KS][2]) {
-        const int stn = min(st + 1, nst - 1);
-        load_b(stn, bn);
-        load_a(stn, areg);
-        __builtin_amdgcn_sched_barrier(0);
-        const float* Ab = As[st & 1];
-        const int tg = st % a.TG;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int tt = tg * NT + j;
-            const int a0i = tap_addr(0, tt), a1i = tap_addr(1, tt), a2i = tap_addr(2, tt);
-#pragma unroll
-            for (int cs = 0; cs < CS; ++cs) {
-                const float a0 = Ab[a0i + cs * 4], a1 = Ab[a1i + cs * 4], a2 = Ab[a2i + cs * 4];
-                const float b0v = bc[j * CS + cs][0], b1v = bc[j * CS + cs][1];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0v, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1v, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0v, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc[1][1], 0, 0, 0);
-                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0v, acc[2][0], 0, 0, 0);
-                acc[2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1v, acc[2][1], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(stn, (st + 1) & 1, areg);
-        __syncthreads();
-    };
-
-    __syncthreads();
+    __syncthreads();                 // tabA / tabE visible
     store_a(0, 0, areg);
     __syncthreads();
-    if (nst == 1) {
-        stage(0, bcur, bnxt);
-    } else {
-        for (int st = 0; st < nst; st += 2) {
-            stage(st, bcur, bnxt);
-            stage(st + 1, bnxt, bcur);
-        }
-    }
 
-    // ---- epilogue: cross-wave reduce, bias, + SiLU(GroupNorm(e_y)), + residual, store, statistics --------
-#pragma unroll
-    for (int mb = 0; mb < 3; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
-    __syncthreads();
-    const int n = tid & 31, rq = tid >> 5;
-    const int n0 = nt * TN, gn = n0 + n;
-    const bool nok = gn < a.N;
-    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
-    const size_t row_base = (size_t)img * HWo + p_lo;
-    float eg = 1.f, eb = 0.f, em = 0.f, er = 1.f;
-    if (a.e_y && nok) {
-        eg = a.e_gamma[gn]; eb = a.e_beta[gn];
-        const int g = gn >> (31 - __builtin_clz(a.e_gw));
-        em = tabE[2 * g]; er = tabE[2 * g + 1];
-    }
-    float ey[6], rs[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int r = rq + 8 * q;
-        ey[q] = 0.f; rs[q] = 0.f;
-        if (r < rows_out && nok) {
-            if (a.e_y) ey[q] = a.e_y[(row_base + r) * a.e_ld + gn];
-            if (a.res) rs[q] = a.res[(row_base + r) * a.ldres + gn];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int r = rq + 8 * q;
-        float v = (Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n]) + bias;
-        if (r < rows_out && nok) {
-            if (a.e_y) v += silu_f((ey[q] - em) * er * eg + eb);
-            if (a.res) v += rs[q];
-            a.out[(row_base + r) * a.ldo + gn] = v;
+    if (nch == 1) {
+        if constexpr (SPC == 3) {
+            load_b(1, bB);
+            mma_stage<KIND, 0>(As[0] + abase, bA, acc);
+            load_b(2, bA);
+            mma_stage<KIND, 1>(As[0] + abase, bB, acc);
+            mma_stage<KIND, 2>(As[0] + abase, bA, acc);
         } else {
-            v = 0.f;
+            mma_stage<KIND, 0>(As[0] + abase, bA, acc);
         }
-        Red[0][r * LDR + n] = v;
+    } else {
+        for (int ch = 0; ch < nch; ch += 2) {
+            const int chn = min(ch + 2, nch - 1);
+            if constexpr (SPC == 3) {
+                const int st = ch * 3;
+                load_b(st + 1, bB);
+                load_a(ch + 1, areg);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 0>(As[0] + abase, bA, acc);
+                load_b(st + 2, bA);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 1>(As[0] + abase, bB, acc);
+                load_b(st + 3, bB);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 2>(As[0] + abase, bA, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                store_a(ch + 1, 1, areg);
+                __syncthreads();
+                load_b(st + 4, bA);
+                load_a(chn, areg);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 0>(As[1] + abase, bB, acc);
+                load_b(st + 5, bB);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 1>(As[1] + abase, bA, acc);
+                load_b(min(st + 6, nst - 1), bA);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 2>(As[1] + abase, bB, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                store_a(chn, 0, areg);
+                __syncthreads();
+            } else {
+                load_b(ch + 1, bB);
+                load_a(ch + 1, areg);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 0>(As[0] + abase, bA, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                store_a(ch + 1, 1, areg);
+                __syncthreads();
+                load_b(chn, bA);
+                load_a(chn, areg);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_stage<KIND, 0>(As[1] + abase, bB, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                store_a(chn, 0, areg);
+                __syncthreads();
+            }
+        }
     }
-    if (a.stats_out || a.ln_out) __syncthreads();
-    if (a.stats_out && rq == 0) {
-        // GroupNorm partial of this tile: (mean, M2) over rows_out x gw elements, per group inside the 32 columns
-        const int gwt = a.so_gw;                       // 8 or 16 (< 32: whole groups inside the tile)
-        const float K = Red[0][n & ~(gwt - 1)];
-        float s1 = 0.f, s2 = 0.f;
-        for (int l = 0; l < rows_out; ++l) { const float d = Red[0][l * LDR + n] - K; s1 += d; s2 += d * d; }
-        s1 = seg_total(s1, gwt);
-        s2 = seg_total(s2, gwt);
-        if ((n & (gwt - 1)) == gwt - 1) {
-            const float ne = (float)(rows_out * gwt);
-            const int g = gn >> (31 - __builtin_clz(gwt));
-            float* o = a.stats_out + (((size_t)img * 8 + g) * a.tpi + ti) * 2;
-            o[0] = K + s1 / ne;
-            o[1] = fmaxf(s2 - s1 * s1 / ne, 0.f);
+    conv2d_epilogue(a, acc, Red, tabE, img, ti, ty0, tx0);
+}
+
+// 7x7 stem (init_conv, :303): input = the padded state (CP = 24 channels, 21 real).  Halo tile 10 x 22 pixels x 24
+// channels staged once; K = 49 taps x 6 channel-quads = 294 k-steps (padded to 320), k-step 4i + w belongs to wave w,
+// so no MFMA is spent on padding channels beyond 24.  8 k-steps per B stage, 10 stages.
+constexpr int STEM_KSTEPS = 320, STEM_NBF = 8, STEM_NST = 10;
+__global__ __launch_bounds__(256, 2) void conv2d_stem7_kernel(const Conv2dArgs a) {
+    constexpr int CP = 24, LDAK = 28, SW = 22, SH = 10, R = SW * SH, NP = (R * 6 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[R * LDAK];
+    __shared__ __attribute__((aligned(16))) float Red[4][T2M * LDR2];
+    __shared__ float tabE[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int img = mt / a.tpi, ti = mt - img * a.tpi;
+    const int tyi = ti / a.tiles_x;
+    const int ty0 = tyi * T2Y, tx0 = (ti - tyi * a.tiles_x) * T2X;
+    const int HWi = a.Hin * a.Win;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float bA[STEM_NBF][4], bB[STEM_NBF][4];
+    const float4* wbase = reinterpret_cast<const float4*>(a.W) + (size_t)nt * STEM_NST * 256 * STEM_NBF + tid;
+    auto load_b = [&](int st, float (&b)[STEM_NBF][4]) {
+        const float4* wp = wbase + (size_t)st * 256 * STEM_NBF;
+#pragma unroll
+        for (int q = 0; q < STEM_NBF; ++q) {
+            const float4 v = wp[q * 256];
+            b[q][0] = v.x; b[q][1] = v.y; b[q][2] = v.z; b[q][3] = v.w;
         }
+    };
+    load_b(0, bA);
+    // stage the halo tile: R rows x 6 float4
+    const float* src = a.src[0].p;
+    const int ld = a.src[0].ld;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = tid + 256 * p;
+        const int r = i / 6, c4 = i - r * 6;
+        const int hy = r / SW, hx = r - hy * SW;
+        const int y = ty0 - 3 + hy, x = tx0 - 3 + hx;
+        const bool ok = (r < R) && (y >= 0) && (y < a.Hin) && (x >= 0) && (x < a.Win);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(src + ((size_t)img * HWi + (size_t)y * a.Win + x) * ld + c4 * 4);
+        if (r < R) *reinterpret_cast<float4*>(As + r * LDAK + c4 * 4) = v;
     }
-    if (a.ln_out) {
-        const int r = tid >> 2, sub = tid & 3;
-        float s1 = 0.f, s2 = 0.f, K = 0.f;
-        if (r < TM) {
-            K = Red[0][r * LDR];
-            for (int c = sub * 8; c < sub * 8 + 8; ++c) { const float d = Red[0][r * LDR + c] - K; s1 += d; s2 += d * d; }
+    __syncthreads();
+    const float* Ab = As + (lane & 15) * LDAK + (lane >> 4);
+    auto stage = [&](int st, const float (&b)[STEM_NBF][4]) {
+#pragma unroll
+        for (int q = 0; q < STEM_NBF; ++q) {
+            const int kidx = min(4 * (st * STEM_NBF + q) + w, 293);          // wave-uniform; padded k-steps carry zero weights
+            const int tap = kidx / 6, cs = kidx - tap * 6;
+            const int dy = tap / 7, dx = tap - dy * 7;
+            const float* ap = Ab + (dy * SW + dx) * LDAK + cs * 4;
+            float af[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) af[mb] = ap[mb * SW * LDAK];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mb], b[q][nb], acc[mb][nb], 0, 0, 0);
         }
-        s1 = seg_total(s1, 4);
-        s2 = seg_total(s2, 4);
-        if (sub == 3 && r < rows_out) {
-            float* o = a.ln_out + ((row_base + r) * (a.Npad / TN) + nt) * 2;
-            o[0] = K + s1 * (1.0f / 32.0f);
-            o[1] = fmaxf(s2 - s1 * s1 * (1.0f / 32.0f), 0.f);
-        }
+    };
+    for (int st = 0; st < STEM_NST; st += 2) {
+        load_b(st + 1, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(st, bA);
+        load_b(min(st + 2, STEM_NST - 1), bA);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(st + 1, bB);
     }
+    conv2d_epilogue(a, acc, Red, tabE, img, ti, ty0, tx0);
 }
 
 // Merge the per-tile GroupNorm partials of an image: [NI][8][tpi][2] -> [NI][8][2] = (mean, M2) over the whole
-// (image, group); tile counts are 48*gw except the last (HW - 48*(tpi-1))*gw.  Chan's formula, fixed order.
-__global__ void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ merged, int n_stats, int tpi, int HW, int gw) {
+// (image, group); every tile holds 64*gw elements.  Chan's formula, fixed order.
+__global__ void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ merged, int n_stats, int tpi, int gw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_stats) return;
     const float* p = part + (size_t)i * tpi * 2;
+    const float nb = (float)(T2M * gw);
     float n = 0.f, mean = 0.f, M2 = 0.f;
     for (int t = 0; t < tpi; ++t) {
-        const float nb = (float)(min(TM, HW - t * TM) * gw);
         const float d = p[2 * t] - mean;
         const float nn = n + nb;
         mean += d * (nb / nn);
