@@ -786,6 +786,21 @@ __device__ __forceinline__ float counter_normal(uint64_t seed, uint64_t sample, 
     return (j & 1) ? rad * sn : rad * cs;
 }
 
+// the four normals of elements 4*elem4 .. 4*elem4+3 (identical values to counter_normal on those elements)
+__device__ __forceinline__ void counter_normal4(uint64_t seed, uint64_t sample, uint32_t step, uint32_t elem4, float (&z)[4]) {
+    uint32_t r[4];
+    philox4x32_10(elem4, (uint32_t)sample, step, (uint32_t)(sample >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+    }
+}
+
 __global__ void fill_normal_kernel(float* out, int64_t B, int64_t per, uint64_t seed, int64_t off, uint32_t step) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * per) return;

@@ -594,48 +594,103 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Full softmax attention (Attention.forward, :266-278) for n tokens, 4 heads x 32: one workgroup per (image, head,
-// 64 queries); keys/values streamed through LDS in chunks of 64; online softmax per query; 4 lanes per query.
-__global__ __launch_bounds__(256) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
-    __shared__ float Ks[64 * 33], Vs[64 * 33];
+// Full softmax attention (Attention.forward, :266-278) for n tokens, 4 heads x 32, on fp32 MFMA.  One workgroup per
+// (image, head, 64 queries), one wave per 16 queries; keys/values streamed through LDS in chunks of 64 (double
+// buffered).  Both products are computed TRANSPOSED so that the probabilities never leave registers:
+//   S^T[key][q] = K[key][:] . Q^T[:][q]       (A = K from LDS, B = Q^T held in registers, pre-scaled by 32^-1/2 log2 e)
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q]   (A = V from LDS, B = P^T = the S^T accumulators after exp2)
+// The k index of the second product enumerates keys in the accumulator layout's order (16*mb + 4*(lane>>4) + rg), which
+// a contraction does not care about.  Online softmax per query column (lane & 15): the running max is shared by the
+// four 16-lane groups (two cross-lane exchanges per chunk), the running sum stays a per-lane partial until the end.
+__global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
+    constexpr int LDK = 36;
+    __shared__ __attribute__((aligned(16))) float Ks[2][64 * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[2][64 * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ih = blockIdx.y, img = ih >> 2, h = ih & 3;
-    const int qi = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;      // this lane owns d in [part*8, part*8+8)
+    const int q0 = blockIdx.x * 64 + w * 16;
     const float* base = qkv + (size_t)img * n * 384;
-    float q[8];
+    const int lq = lane & 15, lg = lane >> 4;
+    float qb[8];
     {
-        const float* qp = base + (size_t)qi * 384 + h * 32 + part * 8;
+        const float* qp = base + (size_t)(q0 + lq) * 384 + h * 32 + lg;
+        const float sc = 0.17677669529663687f * 1.4426950408889634f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) q[j] = qp[j] * 0.17677669529663687f;
+        for (int ks = 0; ks < 8; ++ks) qb[ks] = qp[ks * 4] * sc;
     }
-    float m = -INFINITY, l = 0.f, o[8];
+    const int sr = tid >> 3, sc4 = tid & 7;
+    float4 kreg[2], vreg[2];
+    auto load_kv = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 64 * 32; i += 256) {
-            const int r = i >> 5, c = i & 31;
-            Ks[r * 33 + c] = base[(size_t)(k0 + r) * 384 + 128 + h * 32 + c];
-            Vs[r * 33 + c] = base[(size_t)(k0 + r) * 384 + 256 + h * 32 + c];
+        for (int p = 0; p < 2; ++p) {
+            const float* rp = base + (size_t)(k0 + sr + 32 * p) * 384 + h * 32 + sc4 * 4;
+            kreg[p] = *reinterpret_cast<const float4*>(rp + 128);
+            vreg[p] = *reinterpret_cast<const float4*>(rp + 256);
         }
-        __syncthreads();
-        for (int j = 0; j < 64; ++j) {
-            float s = 0.f;
+    };
+    auto store_kv = [&](int buf) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += q[e] * Ks[j * 33 + part * 8 + e];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            const float mn = fmaxf(m, s);
-            const float corr = expf(m - mn), p = expf(s - mn);
-            l = l * corr + p;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = o[e] * corr + p * Vs[j * 33 + part * 8 + e];
-            m = mn;
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<float4*>(&Ks[buf][(sr + 32 * p) * LDK + sc4 * 4]) = kreg[p];
+            *reinterpret_cast<float4*>(&Vs[buf][(sr + 32 * p) * LDK + sc4 * 4]) = vreg[p];
         }
+    };
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    float m = -INFINITY, l = 0.f;
+    const int nchunk = n >> 6;
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        load_kv(min(c + 1, nchunk - 1) << 6);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Kb = &Ks[buf][lq * LDK + lg];
+        f32x4 s[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            s[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                s[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Kb[mb * 16 * LDK + ks * 4], qb[ks], s[mb], 0, 0, 0);
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, s[mb][rg]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float corr = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) { s[mb][rg] = __builtin_amdgcn_exp2f(s[mb][rg] - mn); ps += s[mb][rg]; }
+        l = l * corr + ps;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { o[db][0] *= corr; o[db][1] *= corr; o[db][2] *= corr; o[db][3] *= corr; }
+        const float* Vb = &Vs[buf][lg * 4 * LDK + lq];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vb[(mb * 16 + rg) * LDK + db * 16], s[mb][rg], o[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_kv(buf ^ 1);
+        __syncthreads();
     }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    float* op = out + ((size_t)img * n + qi) * 128 + h * 32 + part * 8;
+    float* op = out + ((size_t)img * n + q0 + lq) * 128 + h * 32 + lg * 4;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) op[e] = o[e] * inv;
+    for (int db = 0; db < 2; ++db)
+        *reinterpret_cast<float4*>(op + db * 16) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -645,7 +700,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const float* __restrict_
 // + sigma_t * z where z is SHARED over the boundary copies for the state channels (sample_noise :775-785).
 struct Update2dArgs {
     const float* x; const float* eps; float* x_out; float* x0_out; float* mean_out;
-    int64_t B; int nb, HW, C, CP, use_avg, clip, add_noise;     // C logical channels (21), CP padded row pitch (24)
+    int B; int nb, HW, C, CP, use_avg, clip, add_noise;     // C logical channels (21), CP padded row pitch (24)
     const float* sqrt_recip; const float* sqrt_recipm1; const float* coef1; const float* coef2; const float* logvar;
     const int* t_ptr; int t_imm;
     const float* noise_state; int64_t ns_t_stride;      // [B, HW, C-3] (+ t * stride) or null
@@ -653,45 +708,81 @@ struct Update2dArgs {
     uint64_t seed; int64_t sample_off;
     int* t_dec; unsigned* done;
 };
-__global__ void update2d_kernel(const Update2dArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// counter-based noise of the 2-D path: element index = pix * CP + c (float4-aligned groups); state channels keyed by
+// the design (shared over its boundary copies), boundary channels keyed by the image
+__device__ __forceinline__ void noise2d_state4(uint64_t seed, int64_t design, uint32_t tag, uint32_t pix, int G, int g, float (&z)[4]) {
+    counter_normal4(seed, (uint64_t)design, tag, pix * (uint32_t)G + (uint32_t)g, z);
+}
+__device__ __forceinline__ void noise2d_bound4(uint64_t seed, int64_t image, uint32_t tag, uint32_t pix, int G, int g, float (&z)[4]) {
+    counter_normal4(seed ^ 0x9e3779b97f4a7c15ull, (uint64_t)image, tag, pix * (uint32_t)G + (uint32_t)g, z);
+}
+// one thread per (design, pixel, group of 4 channels); loops over the nb boundary copies
+__global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
+    const int G = a.CP >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
-    const int64_t total = a.B * a.nb * (int64_t)a.HW * a.CP;
-    const int c = (int)(i % a.CP);
-    if (i < total && c < a.C) {
-        const int64_t pix = (i / a.CP) % a.HW;
-        const int64_t im = i / ((int64_t)a.CP * a.HW);
-        const int64_t b = im / a.nb;
-        const int Cs = a.C - 3;
-        float e;
-        if (c < Cs) {
-            float s = 0.f;
-            for (int k = 0; k < a.nb; ++k) s += a.eps[(((b * a.nb + k) * a.HW) + pix) * a.CP + c];
-            e = a.use_avg ? s / (float)a.nb : s;
-        } else {
-            e = a.eps[i];
-        }
-        const float xv = a.x[i];
-        float x0 = __fsub_rn(__fmul_rn(a.sqrt_recip[t], xv), __fmul_rn(a.sqrt_recipm1[t], e));
-        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-        const float mean = __fadd_rn(__fmul_rn(a.coef1[t], x0), __fmul_rn(a.coef2[t], xv));
-        if (a.x0_out) a.x0_out[i] = x0;
-        if (a.mean_out) a.mean_out[i] = mean;
-        if (a.x_out) {
-            float v = mean;
-            if (a.add_noise && t > 0) {
-                float z;
-                if (c < Cs) {
-                    z = a.noise_state ? a.noise_state[(size_t)t * a.ns_t_stride + ((size_t)b * a.HW + pix) * Cs + c]
-                                      : counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, (uint32_t)(pix * Cs + c));
-                } else {
-                    z = a.noise_bound ? a.noise_bound[(size_t)t * a.nb_t_stride + ((size_t)im * a.HW + pix) * 3 + (c - Cs)]
-                                      : counter_normal(a.seed ^ 0x9e3779b97f4a7c15ull, (uint64_t)((a.sample_off + b) * a.nb + (im - b * a.nb)),
-                                                       (uint32_t)t, (uint32_t)(pix * 3 + (c - Cs)));
-                }
-                v += expf(0.5f * a.logvar[t]) * z;
+    const int total = a.B * a.HW * G;
+    if (i < total) {
+        const int g = i % G;
+        const int bp = i / G;
+        const int pix = bp % a.HW;
+        const int b = bp / a.HW;
+        const int c0 = 4 * g, Cs = a.C - 3;
+        const float ra = a.sqrt_recip[t], rb = a.sqrt_recipm1[t], k1 = a.coef1[t], k2 = a.coef2[t];
+        const float sigma = (a.add_noise && t > 0) ? expf(0.5f * a.logvar[t]) : 0.f;
+        const bool noisy = a.add_noise && t > 0;
+        // shared prediction of the state channels: mean (or sum) over the boundary copies
+        float es[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < Cs) {
+            for (int k = 0; k < a.nb; ++k) {
+                const float4 e = *reinterpret_cast<const float4*>(a.eps + (((size_t)(b * a.nb + k) * a.HW) + pix) * a.CP + c0);
+                es[0] += e.x; es[1] += e.y; es[2] += e.z; es[3] += e.w;
             }
-            a.x_out[i] = v;
+            if (a.use_avg) { const float inv = (float)a.nb; es[0] /= inv; es[1] /= inv; es[2] /= inv; es[3] /= inv; }
+        }
+        float zs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (noisy && c0 < Cs) {
+            if (a.noise_state) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + j < Cs) zs[j] = a.noise_state[(size_t)t * a.ns_t_stride + ((size_t)b * a.HW + pix) * Cs + c0 + j];
+            } else {
+                noise2d_state4(a.seed, a.sample_off + b, (uint32_t)t, (uint32_t)pix, G, g, zs);
+            }
+        }
+        for (int k = 0; k < a.nb; ++k) {
+            const int im = b * a.nb + k;
+            const size_t o = (((size_t)im * a.HW) + pix) * a.CP + c0;
+            const float4 e4 = *reinterpret_cast<const float4*>(a.eps + o);
+            const float4 x4 = *reinterpret_cast<const float4*>(a.x + o);
+            const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+            float zb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (noisy && c0 + 3 >= Cs && c0 < a.C) {
+                if (a.noise_bound) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j >= Cs && c0 + j < a.C)
+                            zb[j] = a.noise_bound[(size_t)t * a.nb_t_stride + ((size_t)im * a.HW + pix) * 3 + (c0 + j - Cs)];
+                } else {
+                    noise2d_bound4(a.seed, (a.sample_off + b) * a.nb + k, (uint32_t)t, (uint32_t)pix, G, g, zb);
+                }
+            }
+            float r0[4], rm[4], rx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                const float e = (c < Cs) ? es[j] : ev[j];
+                float x0 = __fsub_rn(__fmul_rn(ra, xv[j]), __fmul_rn(rb, e));
+                if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                const float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[j]));
+                const float z = (c < Cs) ? zs[j] : zb[j];
+                const bool real = c < a.C;
+                r0[j] = real ? x0 : 0.f; rm[j] = real ? mean : 0.f;
+                rx[j] = real ? (noisy ? mean + sigma * z : mean) : 0.f;
+            }
+            if (a.x0_out) *reinterpret_cast<float4*>(a.x0_out + o) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+            if (a.mean_out) *reinterpret_cast<float4*>(a.mean_out + o) = make_float4(rm[0], rm[1], rm[2], rm[3]);
+            if (a.x_out) *reinterpret_cast<float4*>(a.x_out + o) = make_float4(rx[0], rx[1], rx[2], rx[3]);
         }
     }
     if (a.t_dec) {
@@ -704,16 +795,23 @@ __global__ void update2d_kernel(const Update2dArgs a) {
 }
 
 // x_T for the 2-D path from the counter-based generator (state channels shared over the boundaries of a design)
-__global__ void fill_noise2d_kernel(float* x, int64_t B, int nb, int HW, int C, int CP, uint64_t seed, int64_t off, uint32_t tag) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * nb * (int64_t)HW * CP) return;
-    const int c = (int)(i % CP);
-    const int64_t pix = (i / CP) % HW;
-    const int64_t im = i / ((int64_t)CP * HW);
-    const int64_t b = im / nb;
-    const int Cs = C - 3;
-    x[i] = (c >= C) ? 0.f : (c < Cs) ? counter_normal(seed, (uint64_t)(off + b), tag, (uint32_t)(pix * Cs + c))
-                    : counter_normal(seed ^ 0x9e3779b97f4a7c15ull, (uint64_t)((off + b) * nb + (im - b * nb)), tag, (uint32_t)(pix * 3 + (c - Cs)));
+__global__ void fill_noise2d_kernel(float* x, int B, int nb, int HW, int C, int CP, uint64_t seed, int64_t off, uint32_t tag) {
+    const int G = CP >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nb * HW * G) return;
+    const int g = i % G;
+    const int ip = i / G;
+    const int pix = ip % HW;
+    const int im = ip / HW;
+    const int b = im / nb;
+    const int c0 = 4 * g, Cs = C - 3;
+    float zs[4] = {0.f, 0.f, 0.f, 0.f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < Cs) noise2d_state4(seed, off + b, tag, (uint32_t)pix, G, g, zs);
+    if (c0 + 3 >= Cs && c0 < C) noise2d_bound4(seed, (off + b) * nb + (im - b * nb), tag, (uint32_t)pix, G, g, zb);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = c0 + j; v[j] = (c >= C) ? 0.f : (c < Cs) ? zs[j] : zb[j]; }
+    *reinterpret_cast<float4*>(x + (size_t)i * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 }  // namespace cindm
