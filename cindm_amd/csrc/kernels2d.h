@@ -19,7 +19,7 @@
 namespace cindm {
 
 enum SrcMode2d { SRC2_PLAIN = 0, SRC2_GN_SS_SILU = 4, SRC2_LN = 2 };
-enum ConvKind { CONV_3X3 = 0, CONV_1X1 = 1, CONV_UP2 = 2, CONV_UNSHUF = 3, CONV_STEM7 = 4 };
+enum ConvKind { CONV_3X3 = 0, CONV_1X1 = 1, CONV_UP2 = 2, CONV_UNSHUF = 3, CONV_STEM7 = 4, CONV_1X1_WIDE = 5 };
 
 constexpr int T2Y = 4, T2X = 16, T2M = T2Y * T2X;    // output pixel tile 4 x 16
 constexpr int T2N = 64;                               // output channels per workgroup
@@ -470,6 +470,87 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem7_kernel(const Conv2dArgs a
     conv2d_epilogue(a, acc, Red, tabE, img, ti, ty0, tx0);
 }
 
+// conv1x1_wide_kernel<KT, MODE>: 1x1 convolution with few input channels (KT = 64 or 128) and many output
+// channels (the attention qkv projections, N = 384), no bias.  One workgroup = 64 consecutive pixels; the input tile is
+// staged through LDS once (LayerNorm-on-load), every lane then keeps its B fragments of the WHOLE K range in
+// registers, and the workgroup loops over the N / 64 output tiles with no LDS traffic and no barrier: wave w owns 16
+// output channels of each tile, computes out^T[n][px] = W[n][:] . x^T[:][px] (A = weights straight from L2 in fragment
+// order, B = the resident input fragments), and stores float4 runs of 4 consecutive channels per pixel.
+template <int KT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv1x1_wide_kernel(const Conv2dArgs a) {
+    constexpr int LDA = KT + 4, F4 = KT / 4, RPP = 256 / F4, NP = 64 / RPP, NKS = KT / 4, NQ = KT / 16;
+    __shared__ __attribute__((aligned(16))) float As[64 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lq = lane & 15, lg = lane >> 4;
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const Src& s = a.src[0];
+    const int c4 = tid % F4, r0 = tid / F4;
+    const int ntile = a.Npad / T2N;
+    const float4* wbase = reinterpret_cast<const float4*>(a.W) + tid;
+    float4 wA[NQ], wB[NQ];
+    auto load_w = [&](int it, float4 (&wv)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wv[q] = wbase[((size_t)it * NQ + q) * 256];
+    };
+    load_w(0, wA);
+    {
+        const int cl = c4 * 4;
+        const bool cok = cl < s.C;
+        const int clc = min(cl, s.C - 4);
+        float4 pg = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (MODE == SRC2_LN) pg = *reinterpret_cast<const float4*>(s.gamma + clc);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + RPP * p;
+            float4 v = *reinterpret_cast<const float4*>(s.p + (row0 + r) * s.ld + clc);
+            if constexpr (MODE == SRC2_LN) {
+                float mean, rstd;
+                merge_stats(s.stats + (row0 + r) * s.P * 2, s.P, s.cnt, 1e-5f, mean, rstd);
+                v.x = (v.x - mean) * rstd * pg.x; v.y = (v.y - mean) * rstd * pg.y;
+                v.z = (v.z - mean) * rstd * pg.z; v.w = (v.w - mean) * rstd * pg.w;
+            }
+            if (!cok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(As + r * LDA + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+    float xb[NKS][4];                 // resident B fragments: x[px = pb*16 + lq][k = ks*4 + lg]
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) xb[ks][pb] = As[(pb * 16 + lq) * LDA + ks * 4 + lg];
+
+    auto tile = [&](int it, const float4 (&wv)[NQ]) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acc[pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float wq[4] = {wv[q].x, wv[q].y, wv[q].z, wv[q].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb)
+                    acc[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[j], xb[q * 4 + j][pb], acc[pb], 0, 0, 0);
+        }
+        const int col = it * T2N + w * 16 + lg * 4;
+        if (col < a.N) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+                *reinterpret_cast<float4*>(a.out + (row0 + pb * 16 + lq) * a.ldo + col) =
+                    make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]);
+        }
+    };
+    for (int it = 0; it < ntile; it += 2) {
+        load_w(min(it + 1, ntile - 1), wB);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(it, wA);
+        load_w(min(it + 2, ntile - 1), wA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < ntile) tile(it + 1, wB);
+    }
+}
+
 // Merge the per-tile GroupNorm partials of an image: [NI][8][tpi][2] -> [NI][8][2] = (mean, M2) over the whole
 // (image, group); every tile holds 64*gw elements.  Chan's formula, fixed order.
 __global__ void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ merged, int n_stats, int tpi, int gw) {
@@ -492,57 +573,82 @@ __global__ void gn_merge_kernel(const float* __restrict__ part, float* __restric
 // LinearAttention (model/diffusion_2d.py:239-254) on qkv [rows, 384] (q | k | v, heads*32 each), per image of n pixels:
 //   q = softmax over d (per pixel, per head) * 32^-1/2 ; k = softmax over the n pixels ; v /= n ;
 //   ctx[d][e] = sum_n k[d][n] v[e][n] ; out[e][n] = sum_d ctx[d][e] q[d][n].
-// Kernel 1: per (image, head) column statistics of k: max and sum(exp(k - max)) over the n pixels.
-__global__ __launch_bounds__(256) void la_kstats_kernel(const float* __restrict__ qkv, float* __restrict__ kst, int n) {
-    __shared__ float smx[8][32], ssm[8][32];
-    const int img = blockIdx.x >> 2, h = blockIdx.x & 3;
-    const int d = threadIdx.x & 31, s = threadIdx.x >> 5;
-    const float* kp = qkv + (size_t)img * n * 384 + 128 + h * 32 + d;
-    float mx = -INFINITY, sum = 0.f;
-    for (int i = s; i < n; i += 8) {
-        const float v = kp[(size_t)i * 384];
-        if (v > mx) { sum = sum * expf(mx - v) + 1.0f; mx = v; } else sum += expf(v - mx);
-    }
-    smx[s][d] = mx; ssm[s][d] = sum;
-    __syncthreads();
-    if (s == 0) {
-        float M = smx[0][d];
-        for (int j = 1; j < 8; ++j) M = fmaxf(M, smx[j][d]);
-        float S = 0.f;
-        for (int j = 0; j < 8; ++j) S += ssm[j][d] * expf(smx[j][d] - M);
-        float* o = kst + ((size_t)blockIdx.x * 32 + d) * 2;
-        o[0] = M; o[1] = S;
-    }
-}
-// Kernel 2: partial contexts over a slice of the pixels: ctxp[img][h][split][d][e].
+// Kernel 1: partial contexts over a slice of the pixels with the slice's OWN softmax shift (online softmax over
+// slices): per (image, head, slice): M_s[d] = max over the slice, S_s[d] = sum exp(k - M_s), ctxp[d][e] = sum
+// exp(k - M_s) v[e].  The slices are merged (rescaled by exp(M_s - M)) in kernel 2's prologue -- no separate pass over
+// k for the global column maximum.
 constexpr int LA_SPLIT = 16;
-__global__ __launch_bounds__(256) void la_context_kernel(const float* __restrict__ qkv, const float* __restrict__ kst,
+__global__ __launch_bounds__(256) void la_context_kernel(const float* __restrict__ qkv, float* __restrict__ kst,
                                                          float* __restrict__ ctxp, int n) {
+    __shared__ float P[256 * 32];
+    __shared__ float smx[8][32], ssm[8][32];
     const int split = blockIdx.x % LA_SPLIT, ih = blockIdx.x / LA_SPLIT;       // ih = img*4 + h
     const int img = ih >> 2, h = ih & 3;
     const int d = threadIdx.x & 31, eg = threadIdx.x >> 5;                        // e in [eg*4, eg*4+4)
-    const float M = kst[((size_t)ih * 32 + d) * 2], inv = 1.0f / kst[((size_t)ih * 32 + d) * 2 + 1];
-    const float invn = 1.0f / (float)n;
-    const int per = n / LA_SPLIT;
+    const int per = n / LA_SPLIT;                                                 // <= 256
     const float* base = qkv + ((size_t)img * n + split * per) * 384;
+    const float* kp = base + 128 + h * 32 + d;
+    // slice maximum of column d (thread group eg takes pixels eg, eg+8, ...), the k values kept in registers
+    float kv[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int i = eg + 8 * j;
+        kv[j] = (i < per) ? kp[(size_t)i * 384] : -INFINITY;
+        mx = fmaxf(mx, kv[j]);
+    }
+    smx[eg][d] = mx;
+    __syncthreads();
+    float M = smx[0][d];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) M = fmaxf(M, smx[j][d]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int i = eg + 8 * j;
+        if (i < per) { const float p = expf(kv[j] - M); P[i * 32 + d] = p; sum += p; }
+    }
+    ssm[eg][d] = sum;
+    __syncthreads();
+    if (eg == 0) {
+        float S = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S += ssm[j][d];
+        float* o = kst + (((size_t)ih * LA_SPLIT + split) * 32 + d) * 2;
+        o[0] = M; o[1] = S;
+    }
+    const float* vp = base + 256 + h * 32 + eg * 4;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll 8
     for (int i = 0; i < per; ++i) {
-        const float* row = base + (size_t)i * 384;
-        const float p = expf(row[128 + h * 32 + d] - M) * inv;
-        const float4 v = *reinterpret_cast<const float4*>(row + 256 + h * 32 + eg * 4);
-        c0 += p * (v.x * invn); c1 += p * (v.y * invn); c2 += p * (v.z * invn); c3 += p * (v.w * invn);
+        const float p = P[i * 32 + d];
+        const float4 v = *reinterpret_cast<const float4*>(vp + (size_t)i * 384);
+        c0 += p * v.x; c1 += p * v.y; c2 += p * v.z; c3 += p * v.w;
     }
     float* o = ctxp + (((size_t)ih * LA_SPLIT + split) * 32 + d) * 32 + eg * 4;
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
-// Kernel 3: out[pixel][h*32 + e] = sum_d ctx[d][e] * softmax_d(q[pixel][h*32 + :])[d] * 32^-1/2 ; one thread per (pixel, head).
-__global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctxp,
-                                                       float* __restrict__ att, int n) {
+// Kernel 2: out[pixel][h*32 + e] = sum_d ctx[d][e] * softmax_d(q[pixel][h*32 + :])[d] * 32^-1/2 ; one thread per (pixel, head).
+__global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ kst,
+                                                       const float* __restrict__ ctxp, float* __restrict__ att, int n) {
     __shared__ float ctx[32 * 33];
+    __shared__ float wgt[LA_SPLIT * 32];
     const int ih = blockIdx.y, img = ih >> 2, h = ih & 3;
+    if (threadIdx.x < 32) {
+        // merge the slices' softmax statistics of column d: weight of slice s = exp(M_s - M) / (S * n)
+        const int d = threadIdx.x;
+        const float* st = kst + ((size_t)ih * LA_SPLIT * 32 + d) * 2;
+        float M = st[0];
+        for (int sp = 1; sp < LA_SPLIT; ++sp) M = fmaxf(M, st[sp * 64]);
+        float S = 0.f;
+        for (int sp = 0; sp < LA_SPLIT; ++sp) { const float e = expf(st[sp * 64] - M); wgt[sp * 32 + d] = e; S += st[sp * 64 + 1] * e; }
+        const float inv = 1.0f / (S * (float)n);
+        for (int sp = 0; sp < LA_SPLIT; ++sp) wgt[sp * 32 + d] *= inv;
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < 1024; i += 256) {
         float s = 0.f;
-        for (int sp = 0; sp < LA_SPLIT; ++sp) s += ctxp[((size_t)ih * LA_SPLIT + sp) * 1024 + i];
+        for (int sp = 0; sp < LA_SPLIT; ++sp) s += ctxp[((size_t)ih * LA_SPLIT + sp) * 1024 + i] * wgt[sp * 32 + (i >> 5)];
         ctx[(i >> 5) * 33 + (i & 31)] = s;
     }
     __syncthreads();
