@@ -6,7 +6,7 @@ batch of 256 nbody-2 designs through TemporalUnet1D(dim=64, horizon=24) (BASELIN
 synthetic generator-defined weights, x_T and per-step noise from the in-kernel counter-based generator.
 Inputs (weights, state) are resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (--workload cfg5: the 2-D airfoil configuration)
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank samples its own 256 designs
 (weak scaling, no communication inside the loop) and the final designs are all-gathered over RCCL.
 Prints ONE JSON line on rank 0.
@@ -58,14 +58,151 @@ def cpu_baseline(sd, budget_s=20.0):
             "sample": f"{n} reverse steps of batch {BATCH} ({dt * 1e3:.1f} ms/step), extrapolated x{TIMESTEPS}"}
 
 
+FLOP_PER_IMAGE_2D = 10.467e9       # per Unet evaluation of one 64x64 image
+
+
+def pmc_traffic(fname, substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*.json, produced by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs); None if absent."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+    except Exception:
+        return None
+    n = b = 0
+    for k, v in ks.items():
+        if substr in k:
+            n += v["launches"]; b += v["launches"] * v["hbm_bytes_per_launch"]
+    return int(b / n) if n else None
+
+
+def cpu_baseline_2d(sd, budget_s=20.0):
+    """The oracle's 2-D reverse step (torch-CPU port of the reference) on a bounded sample: steps of 4 designs x 2
+    boundaries, extrapolated to 1000 steps."""
+    import cindm_oracle as O
+    od = O.Diffusion2D(sd, image_size=64, frames=6)
+    Bc, nb = 4, 2
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((Bc * nb, 21, 64, 64), generator=g)
+    nz = O.sample_noise_2d(torch.randn((Bc, 1, 18, 64, 64), generator=g), torch.randn((Bc, nb, 3, 64, 64), generator=g)).reshape(Bc * nb, 21, 64, 64)
+    shape = (Bc, nb, 21, 64, 64)
+    with torch.no_grad():
+        O.p_sample_2d(od, shape, x, 500, nz)
+        n, t0 = 0, time.time()
+        while True:
+            x, _ = O.p_sample_2d(od, shape, x, 500 - n, nz)
+            n += 1
+            if time.time() - t0 > budget_s or n >= 50:
+                break
+        dt = (time.time() - t0) / n
+    return {"value": Bc / (dt * TIMESTEPS), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} reverse steps of {Bc} designs x {nb} boundaries ({dt * 1e3:.0f} ms/step), extrapolated x{TIMESTEPS}"}
+
+
+def main_cfg5(args):
+    """BASELINE configs[4]: airfoil 2-D, Unet(dim=64, dim_mults=(1,2), channels=21) on 64x64, 2-boundary composition,
+    batch 64 designs per GPU (128 images per reverse step), 1000 DDPM steps per design."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    import cindm_amd
+    from cindm_amd import dist as cdist
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cindm_oracle as O
+    sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
+    model = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64)
+    model.load_state_dict(sd, strict=True)
+    diffusion = cindm_amd.GaussianDiffusion(model, image_size=64, frames=6, cond_frames=2, timesteps=TIMESTEPS,
+                                            sampling_timesteps=TIMESTEPS, loss_type="l2").to(dev)
+    B, nb = (args.batch or 64), 2
+    total = B * world
+    stream = torch.cuda.Stream(device=dev)
+
+    def one_chain(i):
+        local = diffusion.sample(batch_size=B, num_boundaries=nb, seed=1234 + i, sample_offset=rank * B)
+        return cdist.all_gather_designs(local, total) if distributed else local
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            out = one_chain(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = one_chain(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert tuple(out.shape) == (total, nb, 21, 64, 64) and bool(torch.isfinite(out).all())
+        roof = None
+        if rank == 0:
+            x = torch.randn((B * nb, 64 * 64, model.padded_channels), device=dev)
+            x[:, :, 21:] = 0
+            model.profile(x, 500)
+            acc = {}
+            reps = 5
+            for _ in range(reps):
+                for k, (n, ms, fl) in model.profile(x, 500).items():
+                    a = acc.setdefault(k, [0, 0.0, 0.0])
+                    a[0] += n; a[1] += ms; a[2] += fl
+            k3 = acc["conv3x3"]
+            tot_ms = sum(v[1] for v in acc.values())
+            achieved = k3[2] / (k3[1] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv2d_tile_kernel<3x3 / upsampled 3x3> (fp32 MFMA)", "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
+                    "traffic": pmc_traffic("r01_pmc_traffic_cfg5.json", "conv2d_tile_kernel<0"),
+                    "launches_per_forward": k3[0] // reps, "avg_launch_us": round(k3[1] / k3[0] * 1e3, 2),
+                    "share_of_forward_time": round(k3[1] / tot_ms, 3),
+                    "forward_ms_sum_of_kernels": round(tot_ms / reps, 3),
+                    "per_kind_us": {k: round(v[1] / reps * 1e3, 1) for k, v in acc.items()}}
+    if rank == 0:
+        value = total * args.steps / elapsed
+        flop_design = nb * FLOP_PER_IMAGE_2D * TIMESTEPS
+        line = {
+            "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"airfoil 2-D: Unet dim=64 mults (1,2) channels=21 on 64x64, {nb}-boundary composition, "
+                                   f"batch {B} designs/GPU ({B * nb} images per reverse step), {TIMESTEPS} DDPM steps (BASELINE configs[4])",
+                       "designs_per_step": total, "unet_evals_per_design": TIMESTEPS * nb,
+                       "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
+            "model_tflops": round(value * flop_design / 1e12, 2),
+            "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline_2d(sd)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH, help="designs per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2, 64 for cfg5)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg5 = the 2-D airfoil configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "cfg5":
+        return main_cfg5(args)
+    args.batch = args.batch or BATCH
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,7 +272,7 @@ def main():
                 "conv_gemm_h3_kernel<5,48,*> (k=5 conv; fp32 products as 3 fp16 MFMAs, fp32 accumulate)"
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
                     "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
-                    "traffic": None,
+                    "traffic": pmc_traffic("r01_pmc_traffic_cfg2.json", "conv_gemm_h3_kernel<5" if "h3" in kname else "conv_gemm_kernel<5"),
                     "launches_per_forward": k5[0] // reps, "avg_launch_us": round(k5[1] / k5[0] * 1e3, 2),
                     "share_of_forward_time": round(k5[1] / tot_ms, 3),
                     "forward_ms_sum_of_kernels": round(tot_ms / reps, 3),

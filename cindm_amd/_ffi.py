@@ -90,6 +90,8 @@ SIGNATURES = {
     "cindm_unet2d_workspace_bytes": (_sz, [_vp, _i64]),
     "cindm_unet2d_launches_per_forward": (C.c_int, [_vp]),
     "cindm_unet2d_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "cindm_unet2d_profile": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp, C.POINTER(_i32 * 7),
+                                       C.POINTER(C.c_float * 7), C.POINTER(C.c_double * 7)]),
     "cindm_unet2d_tap": (C.c_int, [_vp, C.c_char_p, _i64, _vp, _vp, _i64, C.POINTER(_i64 * 3), _vp]),
     "cindm_ddpm2d_workspace_bytes": (_sz, [_vp, _i64]),
     "cindm_ddpm2d_step": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _vp, _vp, _vp,

@@ -54,3 +54,16 @@ def sample_multibodies_sharded(diffusion, cond, N, L, n_bodies, *, seed, group=N
     lo, hi = shard_bounds(total, rank, world)
     local = diffusion.sample_compose_multibodies(cond[lo:hi].contiguous(), N, L, n_bodies, seed=seed, sample_offset=lo)
     return all_gather_designs(local, total, group) if gather else local
+
+
+def sample2d_sharded(diffusion, batch_size, *, seed, num_boundaries=1, group=None, gather=True, **sample_kw):
+    """2-D ``GaussianDiffusion.sample(batch_size=..., num_boundaries=...)`` with the DESIGNS partitioned over the
+    process group (the boundary copies of a design stay on one rank: they share noise and predicted states).
+    Returns [batch_size, num_boundaries, C, H, W] on every rank."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_bounds(batch_size, rank, world)
+    local = diffusion.sample(batch_size=hi - lo, num_boundaries=num_boundaries, seed=seed, sample_offset=lo, **sample_kw)
+    return all_gather_designs(local, batch_size, group) if gather else local

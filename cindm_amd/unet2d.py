@@ -169,6 +169,22 @@ class Unet(nn.Module):
         out = self.forward_device_layout(xd, self._t_int(time))
         return from_device_layout(out, self.channels, S, S)
 
+    KERNEL_KINDS = ("conv3x3", "conv1x1", "stem7x7", "qkv1x1", "linear_attention", "full_attention", "stats_ln")
+
+    @torch.no_grad()
+    def profile(self, x, t):
+        """One forward (x in the library layout [images, H*W, CP]) with every launch bracketed by HIP events on the
+        current stream.  Returns {kernel kind: (launches, total ms, total algorithmic FLOPs)}."""
+        self.sync_weights()
+        out = torch.zeros_like(x)
+        ws = self.workspace(x.shape[0], x.device)
+        cnt, ms, fl = (C.c_int32 * 7)(), (C.c_float * 7)(), (C.c_double * 7)()
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().cindm_unet2d_profile(self._h, _ffi.ptr(x), int(t), _ffi.ptr(out), x.shape[0], _ffi.ptr(ws),
+                                                       ws.numel(), _ffi.current_stream(x.device), C.byref(cnt), C.byref(ms),
+                                                       C.byref(fl)))
+        return {k: (cnt[i], ms[i], fl[i]) for i, k in enumerate(self.KERNEL_KINDS)}
+
     def tap(self, name, images):
         """Intermediate activation of the last forward as [images, C, H, W] (the reference's layout)."""
         shape = (C.c_int64 * 3)()

@@ -241,6 +241,12 @@ int  cindm_unet2d_launches_per_forward(const cindm_unet2d* h);
 /* eps[images, H*W, CP] = Unet(x[images, H*W, CP], t); t_dev (device int32) wins over t. */
 int  cindm_unet2d_forward(cindm_unet2d* h, const float* x, int32_t t, const int32_t* t_dev,
                           float* eps, int64_t images, void* ws, size_t ws_bytes, void* stream);
+/* Measurement hook for bench.py: one forward with every launch bracketed by HIP events on
+ * `stream`; per kernel kind (0 conv3x3, 1 conv1x1, 2 stem 7x7, 3 qkv 1x1, 4 linear attention,
+ * 5 full attention, 6 statistics / LayerNorm-residual): launches, total ms, algorithmic FLOPs. */
+int  cindm_unet2d_profile(cindm_unet2d* h, const float* x, int32_t t, float* eps, int64_t images,
+                          void* ws, size_t ws_bytes, void* stream, int32_t counts[7], float ms[7],
+                          double flops[7]);
 /* Test hook: copy the intermediate activation `name` of the last forward into dst as
  * [images, H*W, C]; shape receives (images, H*W, C). */
 int  cindm_unet2d_tap(cindm_unet2d* h, const char* name, int64_t images, void* ws, float* dst,

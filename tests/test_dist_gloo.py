@@ -26,6 +26,15 @@ class _FakeDiffusion:
         return cond[:, :2, :3] * 2 + sample_offset
 
 
+class _FakeDiffusion2D:
+    """Stands in for the 2-D GaussianDiffusion.sample: [B, nb, C, H, W], a pure function of (seed, global design)."""
+
+    def sample(self, batch_size, num_boundaries=1, seed=0, sample_offset=0, **kw):
+        idx = torch.arange(sample_offset, sample_offset + batch_size, dtype=torch.float32)
+        base = torch.arange(num_boundaries * 3 * 2 * 2, dtype=torch.float32).reshape(1, num_boundaries, 3, 2, 2)
+        return idx[:, None, None, None, None] * 100 + base + seed
+
+
 def _worker(rank, world, port, total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,6 +48,9 @@ def _worker(rank, world, port, total, q):
         lo_hi = [cdist.shard_bounds(total, r, world) for r in range(world)]
         ref2 = torch.cat([cond[lo:hi, :2, :3] * 2 + lo for lo, hi in lo_hi], 0)
         ok2 = torch.equal(out2, ref2)
+        d2 = _FakeDiffusion2D()
+        out3 = cdist.sample2d_sharded(d2, total, seed=3, num_boundaries=2)
+        ok2 = ok2 and torch.equal(out3, d2.sample(total, num_boundaries=2, seed=3)) and tuple(out3.shape) == (total, 2, 3, 2, 2)
         q.put((rank, ok1, ok2, tuple(out.shape)))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,39 @@
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --output-format csv), as
+MI355X_MICROARCH.md's HBM section prescribes: the counters are in KiB per dispatch; on gfx950 FETCH_SIZE reports half
+of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is (uncalibrated per the guide).
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def collect(d, name):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != name:
+                continue
+            k = row["Kernel_Name"]
+            acc[k][0] += 1
+            acc[k][1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        n, tot = fetch[k]
+        wn, wtot = write.get(k, [0, 0.0])
+        rd = 2.0 * tot * 1024 / n                      # gfx950 correction: x2
+        wr = wtot * 1024 / wn if wn else 0.0
+        out[k] = {"launches": n, "fetch_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                  "hbm_bytes_per_launch": round(rd + wr)}
+    json.dump({"note": "FETCH_SIZE (KiB) x2 (gfx950: reports half of wide coalesced reads) + WRITE_SIZE (KiB), mean per launch; "
+                       "Infinity-Cache hits are included in these memory-side counters", "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
