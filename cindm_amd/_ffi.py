@@ -77,6 +77,8 @@ SIGNATURES = {
                                     _vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "cindm_ddpm1d_sample": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc), _vp, _vp, _vp, _u64, _i64,
                                       _vp, _i32, _vp, _i32, _i32, _i64, _vp, _sz, _vp, _i32]),
+    "cindm_ddpm1d_sample_ddim": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc), _vp, _vp, _i32, _vp, _vp, _vp, _u64, _i64,
+                                           _vp, _i32, _vp, _i64, _vp, _sz, _vp, _i32]),
     "cindm_fill_normal": (C.c_int, [_vp, _i64, _i64, _u64, _i64, _i32, _vp]),
     "cindm_ddpm1d_launches_per_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc)]),
     "cindm_unet2d_create": (C.c_int, [C.POINTER(Unet2dDesc), C.POINTER(_vp)]),

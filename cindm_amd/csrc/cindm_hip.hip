@@ -769,8 +769,9 @@ extern "C" int cindm_unet1d_tap(cindm_unet1d* h, const char* name, int64_t rows,
 struct cindm_ddpm1d {
     int T = 0;
     float* tab = nullptr;        // 13 tables, each [T]
-    int* t_dev = nullptr;        // device step counter used by cindm_ddpm1d_sample
+    int* t_dev = nullptr;        // device step state used by the sample loops: [0] = t, [1] = block counter, [2] = DDIM step index
     hipStream_t own = nullptr;   // capture stream used when the caller passes the legacy default stream
+    float* ddim_buf = nullptr; int ddim_cap = 0;      // DDIM tables: [cap][4] floats then [cap] ints
 };
 
 extern "C" int cindm_ddpm1d_create(const cindm_sched_desc* d, cindm_ddpm1d** out) {
@@ -798,6 +799,7 @@ extern "C" void cindm_ddpm1d_destroy(cindm_ddpm1d* h) {
     if (h->tab) (void)hipFree(h->tab);
     if (h->t_dev) (void)hipFree(h->t_dev);
     if (h->own) (void)hipStreamDestroy(h->own);
+    if (h->ddim_buf) (void)hipFree(h->ddim_buf);
     delete h;
 }
 
@@ -878,6 +880,7 @@ struct StepIO {
     const float* noise; int64_t noise_t_stride; uint64_t seed; int64_t sample_off; int add_noise;
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
     int dec_t;              // sample loop: decrement the device step counter at the end of the step
+    const float* ddim_tab; const int* ddim_tnext;      // DDIM loop: per-step coefficient / time_next tables (device)
 };
 
 static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -910,6 +913,7 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.noise = io.noise; a.noise_t_stride = io.noise_t_stride; a.seed = io.seed; a.sample_off = io.sample_off; a.add_noise = io.add_noise;
     a.inp_cond = io.inp_cond; a.inp_steps = io.inp_steps; a.inp_noise = io.inp_noise; a.inp_noise_t_stride = io.inp_noise_t_stride;
     if (io.dec_t) { a.t_dec = h->t_dev; a.done = reinterpret_cast<unsigned*>(h->t_dev + 1); }
+    if (io.ddim_tab) { a.ddim_tab = io.ddim_tab; a.ddim_tnext = io.ddim_tnext; a.step_idx = h->t_dev + 2; }
 
     const float* unet_in = io.x;
     if (!s.direct) {
@@ -949,7 +953,7 @@ extern "C" int cindm_ddpm1d_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet
     return run_step(h, pair, uncond, c, io, t, t_dev, B, ws, ws_bytes, (hipStream_t)stream);
 }
 
-__global__ void set_counter_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = v; p[1] = 0; } }
+__global__ void set_counter_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = v; p[1] = 0; p[2] = 0; } }
 
 extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
                                    float* x, const float* cond, const float* noise_steps, uint64_t seed, int64_t sample_offset,
@@ -1001,6 +1005,75 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     if (le != hipSuccess) return fail(std::string("hipGraphLaunch: ") + hipGetErrorString(le));
     if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
     return 0;
+}
+
+// run one captured step n times (graph) or launch it n times (stream); shared tail of the sample loops
+template <typename StepFn>
+static int replay_steps(hipStream_t stream, int nsteps, int use_graph, StepFn step) {
+    if (!use_graph) {
+        for (int i = 0; i < nsteps; ++i) if (step() != 0) return -1;
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    int rc = step();
+    hipError_t ce = hipStreamEndCapture(stream, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
+    if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < nsteps && le == hipSuccess; ++i) le = hipGraphLaunch(exec, stream);
+    hipError_t se = hipStreamSynchronize(stream);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    if (le != hipSuccess) return fail(std::string("hipGraphLaunch: ") + hipGetErrorString(le));
+    if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
+    return 0;
+}
+
+extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
+                                        float* x, const float* cond, int32_t n_steps, const int32_t* times,
+                                        const float* coefs, const float* noise_steps, uint64_t seed, int64_t sample_offset,
+                                        const float* inpaint_cond, int32_t inpaint_steps, const float* inpaint_noise_steps,
+                                        int64_t B, void* ws, size_t ws_bytes, void* stream_, int32_t use_graph) {
+    REQUIRE(h && pair && c && x && times && coefs, "null argument");
+    REQUIRE(n_steps >= 1, "n_steps must be >= 1");
+    for (int i = 0; i < n_steps; ++i) REQUIRE(times[i] >= 0 && times[i] < h->T && times[i + 1] < times[i] && times[i + 1] >= -1, "bad DDIM time schedule");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (use_graph && stream == nullptr) {
+        if (!h->own) HIPCHK(hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking));
+        HIPCHK(hipDeviceSynchronize());
+        stream = h->own;
+    }
+    if (h->ddim_cap < n_steps) {
+        if (h->ddim_buf) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(h->ddim_buf); h->ddim_buf = nullptr; }
+        HIPCHK(hipMalloc((void**)&h->ddim_buf, (size_t)n_steps * 5 * sizeof(float)));
+        h->ddim_cap = n_steps;
+    }
+    std::vector<float> tabv((size_t)n_steps * 4, 0.f);
+    std::vector<int> tnv(n_steps);
+    for (int i = 0; i < n_steps; ++i) {
+        tabv[4 * i] = coefs[3 * i]; tabv[4 * i + 1] = coefs[3 * i + 1]; tabv[4 * i + 2] = coefs[3 * i + 2];
+        tnv[i] = times[i + 1];
+    }
+    int* tn_dev = reinterpret_cast<int*>(h->ddim_buf + (size_t)h->ddim_cap * 4);
+    HIPCHK(hipMemcpyAsync(h->ddim_buf, tabv.data(), tabv.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(tn_dev, tnv.data(), tnv.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));            // the host vectors go out of scope
+    const int Ltot = state_len(pair, c);
+    const int F = c->n_bodies * 4;
+    StepIO io{};
+    io.x = x; io.cond = cond; io.x_out = x;
+    io.noise = noise_steps; io.noise_t_stride = (int64_t)B * Ltot * F; io.seed = seed; io.sample_off = sample_offset; io.add_noise = 1;
+    io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
+    io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
+    io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)times[0]);
+    return replay_steps(stream, n_steps, use_graph,
+                        [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
 }
 
 extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed, int64_t sample_offset,

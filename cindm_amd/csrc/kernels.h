@@ -833,6 +833,9 @@ struct ComposeArgs {
     uint64_t seed; int64_t sample_off; int add_noise;
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
     int* t_dec; unsigned* done;     // sample loop: the last block to finish decrements the device step counter
+    // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
+    // device step index; noise tapes are then indexed by the step index instead of t
+    const float* ddim_tab; const int* ddim_tnext; int* step_idx;
 };
 
 __device__ __forceinline__ int pair_index(int i, int j, int nb) {   // i < j, order (0,1),(0,2),..,(1,2),..
@@ -886,6 +889,7 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
     const int Lfull = a.Ltot + a.cond_steps;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int sidx = a.ddim_tab ? *a.step_idx : 0;
     if (i < a.B * (int64_t)a.Ltot * a.F) {
     const int f = (int)(i % a.F);
     const int lx = (int)((i / a.F) % a.Ltot);
@@ -972,7 +976,25 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
     if (a.mean_out) a.mean_out[i] = mean;
     if (a.x0_out) a.x0_out[i] = x0;
     if (a.eps_out) a.eps_out[i] = eps;
-    if (a.x_out) {
+    if (a.x_out && a.ddim_tab) {
+        // x_{next} = x0 * sqrt(alpha_next) + c * eps + sigma * z (:1781-1783); the last step returns x0 (:1784-1789)
+        const int tn = a.ddim_tnext[sidx];
+        const uint32_t el = (uint32_t)(lx * a.F + f);
+        float v = x0;
+        if (tn >= 0) {
+            const float san = a.ddim_tab[4 * sidx], cc = a.ddim_tab[4 * sidx + 1], sg = a.ddim_tab[4 * sidx + 2];
+            const float z = a.noise ? a.noise[(size_t)sidx * a.noise_t_stride + i]
+                            : (sg != 0.f ? counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, el) : 0.f);
+            v = __fadd_rn(__fadd_rn(__fmul_rn(x0, san), __fmul_rn(cc, eps)), __fmul_rn(sg, z));
+            if (a.inp_cond && lx < a.inp_steps) {      // inpainting overwrite with q_sample(cond, time) (:1790-1793)
+                const size_t ci = ((size_t)b * a.inp_steps + lx) * a.F + f;
+                const float z2 = a.inp_noise ? a.inp_noise[(size_t)sidx * a.inp_noise_t_stride + ci]
+                                             : counter_normal(a.seed ^ 0x5bd1e995u, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z2;
+            }
+        }
+        a.x_out[i] = v;
+    } else if (a.x_out) {
         float v = mean;
         const uint32_t el = (uint32_t)(lx * a.F + f);
         if (a.add_noise && t > 0) {
@@ -994,7 +1016,11 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
-            if (atomicAdd(a.done, 1u) == gridDim.x - 1) { *a.done = 0u; *a.t_dec = t - 1; }
+            if (atomicAdd(a.done, 1u) == gridDim.x - 1) {
+                *a.done = 0u;
+                if (a.ddim_tab) { *a.t_dec = max(a.ddim_tnext[sidx], 0); *a.step_idx = sidx + 1; }
+                else *a.t_dec = t - 1;
+            }
         }
     }
 }

@@ -725,21 +725,19 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
         for (int ks = 0; ks < 8; ++ks) qb[ks] = qp[ks * 4] * sc;
     }
     const int sr = tid >> 3, sc4 = tid & 7;
-    float4 kreg[2], vreg[2];
+    float4 kr0, kr1, vr0, vr1;
     auto load_kv = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float* rp = base + (size_t)(k0 + sr + 32 * p) * 384 + h * 32 + sc4 * 4;
-            kreg[p] = *reinterpret_cast<const float4*>(rp + 128);
-            vreg[p] = *reinterpret_cast<const float4*>(rp + 256);
-        }
+        const float* rp = base + (size_t)(k0 + sr) * 384 + h * 32 + sc4 * 4;
+        kr0 = *reinterpret_cast<const float4*>(rp + 128);
+        vr0 = *reinterpret_cast<const float4*>(rp + 256);
+        kr1 = *reinterpret_cast<const float4*>(rp + 32 * 384 + 128);
+        vr1 = *reinterpret_cast<const float4*>(rp + 32 * 384 + 256);
     };
     auto store_kv = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<float4*>(&Ks[buf][(sr + 32 * p) * LDK + sc4 * 4]) = kreg[p];
-            *reinterpret_cast<float4*>(&Vs[buf][(sr + 32 * p) * LDK + sc4 * 4]) = vreg[p];
-        }
+        *reinterpret_cast<float4*>(&Ks[buf][sr * LDK + sc4 * 4]) = kr0;
+        *reinterpret_cast<float4*>(&Vs[buf][sr * LDK + sc4 * 4]) = vr0;
+        *reinterpret_cast<float4*>(&Ks[buf][(sr + 32) * LDK + sc4 * 4]) = kr1;
+        *reinterpret_cast<float4*>(&Vs[buf][(sr + 32) * LDK + sc4 * 4]) = vr1;
     };
     load_kv(0);
     store_kv(0);
@@ -760,11 +758,14 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
             for (int ks = 0; ks < 8; ++ks)
                 s[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Kb[mb * 16 * LDK + ks * 4], qb[ks], s[mb], 0, 0, 0);
         }
-        float mx = s[0][0];
+        float pr[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { pr[mb][0] = s[mb][0]; pr[mb][1] = s[mb][1]; pr[mb][2] = s[mb][2]; pr[mb][3] = s[mb][3]; }
+        float mx = pr[0][0];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, s[mb][rg]);
+            for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, pr[mb][rg]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) { s[mb][rg] = __builtin_amdgcn_exp2f(s[mb][rg] - mn); ps += s[mb][rg]; }
+            for (int rg = 0; rg < 4; ++rg) { pr[mb][rg] = __builtin_amdgcn_exp2f(pr[mb][rg] - mn); ps += pr[mb][rg]; }
         l = l * corr + ps;
 #pragma unroll
         for (int db = 0; db < 2; ++db) { o[db][0] *= corr; o[db][1] *= corr; o[db][2] *= corr; o[db][3] *= corr; }
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
             for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vb[(mb * 16 + rg) * LDK + db * 16], s[mb][rg], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vb[(mb * 16 + rg) * LDK + db * 16], pr[mb][rg], o[db], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         store_kv(buf ^ 1);
         __syncthreads();

@@ -8,8 +8,11 @@ What runs where
     (``cindm_ddpm1d_sample``: one hipGraph-captured step replayed per timestep);
   * ``design_fn`` guidance is a user Python callable: its gradient is taken by PyTorch autograd
     between two library calls per step, exactly where the reference takes it.
-Training (``forward`` / ``p_losses``), DDIM and the unreachable ULA/UHMC samplers of the reference
-are out of this build's scope and raise NotImplementedError.
+  * DDIM (``sampling_timesteps < timesteps``, ``ddim_sample`` :1724-1804): unguided = ONE library call
+    (``cindm_ddpm1d_sample_ddim``, same captured-step replay with per-step coefficient tables); guided (recurrence
+    guidance) = library predictions + the user's gradient per step.
+Training (``forward`` / ``p_losses``) and the unreachable ULA/UHMC samplers of the reference are out of this build's
+scope and raise NotImplementedError.
 """
 import ctypes as C
 from collections import namedtuple
@@ -262,17 +265,22 @@ class GaussianDiffusion1D(nn.Module):
         raise ValueError(g)
 
     @torch.no_grad()
-    def _guided_step(self, x, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise):
-        """Shared body of p_sample / p_sample_compose_inside / p_sample_compose_outside."""
+    def _guided_step(self, x, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise,
+                     ddim_return=False):
+        """Shared body of p_sample / p_sample_compose_inside / p_sample_compose_outside.  ``ddim_return``: the
+        sampling_timesteps != timesteps convention of the recurrence branch (:1372-1376): returns
+        (pred_noise + grad_design_final, x_start) of the last iteration."""
         R = int(design_guidance.split("-")[-1]) if "recurrence" in design_guidance else 0
         x = self._f32(x)
         logvar = self.posterior_log_variance_clipped[t]
         x_start = None
+        eps = shift = None
         for r in range(max(R, 1)):
-            mean, x_start, _ = self._predict(x, cond, t, desc)
+            mean, x_start, eps = self._predict(x, cond, t, desc)
             pred = mean
             if design_fn is not None:
-                pred = mean - self._design_shift(design_fn, design_guidance, x, x_start, t)
+                shift = self._design_shift(design_fn, design_guidance, x, x_start, t)
+                pred = mean - shift
             if initial_state_overwrite is not None:
                 k = initial_state_overwrite.shape[1]
                 pred = torch.cat([initial_state_overwrite.to(pred), pred[:, k:]], 1)
@@ -280,6 +288,8 @@ class GaussianDiffusion1D(nn.Module):
                 ratio = self.alphas_cumprod / self.alphas_cumprod_prev
                 z = recur_noise[r] if recur_noise is not None else torch.randn_like(pred)
                 x = torch.sqrt(ratio)[t] * pred + torch.sqrt(1 - ratio)[t] * z
+        if ddim_return:
+            return eps + shift, x_start
         if t > 0:
             z = noise if noise is not None else torch.randn_like(x)
             pred = pred + (0.5 * logvar).exp() * z
@@ -298,12 +308,12 @@ class GaussianDiffusion1D(nn.Module):
                                 n_composed=0, compose_start_step=4, single_model_step=-1, compose_n_bodies=2,
                                 *, noise=None, recur_noise=None):
         """:1190-1376."""
-        if self.sampling_timesteps != self.num_timesteps and "recurrence" in design_guidance:
-            raise NotImplementedError("DDIM return convention (:1372-1376) is out of scope")
+        ddim = self.sampling_timesteps != self.num_timesteps and "recurrence" in design_guidance     # :1372-1376
         assert "inside" not in compose_mode or single_model_step > 0
         desc = self._desc_for(x.shape, compose_mode, n_composed, compose_start_step, single_model_step, compose_n_bodies,
                               clip=clip_denoised)
-        return self._guided_step(x, cond, int(t), desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise)
+        return self._guided_step(x, cond, int(t), desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise,
+                                 ddim_return=ddim)
 
     @torch.no_grad()
     def p_sample_compose_outside(self, x, cond, t: int, x_self_cond=None, clip_denoised=True, design_fn=None,
@@ -394,8 +404,14 @@ class GaussianDiffusion1D(nn.Module):
                initial_state_overwrite=None, initialization_mode=0, initialization_img=None, **build_kw):
         """:2330-2376.  ``build_kw``: noise=, seed=, sample_offset=, use_graph=, t_stop= (see p_sample_loop)."""
         self.is_ddim_sampling = self.sampling_timesteps < self.num_timesteps
-        if self.is_ddim_sampling:
-            raise NotImplementedError("ddim_sample (:1724) is out of this build's scope; set sampling_timesteps == timesteps")
+        if self.is_ddim_sampling:               # :2348-2363
+            build_kw.pop("t_stop", None)
+            return self.ddim_sample((batch_size, self.image_size, self.channels), cond=cond, n_composed=n_composed,
+                                    compose_start_step=compose_start_step, compose_n_bodies=compose_n_bodies,
+                                    compose_mode=compose_mode, design_fn=design_fn, design_guidance=design_guidance,
+                                    initial_state_overwrite=initial_state_overwrite,
+                                    initialization_mode=initialization_mode, initialization_img=initialization_img,
+                                    **build_kw)
         return self.p_sample_loop((batch_size, self.image_size, self.channels), cond=cond, n_composed=n_composed,
                                   compose_start_step=compose_start_step, compose_n_bodies=compose_n_bodies,
                                   compose_mode=compose_mode, design_fn=design_fn, design_guidance=design_guidance,
@@ -430,5 +446,88 @@ class GaussianDiffusion1D(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("training loss (p_losses, :2438-2501) is out of this build's scope")
 
-    def ddim_sample(self, *a, **k):
-        raise NotImplementedError("ddim_sample (:1724) is out of this build's scope")
+    # ------------------------------------------------------------------ DDIM
+    def ddim_schedule(self):
+        """(times [S+1] descending to -1, coefs [S,3] = (sqrt(alpha_next), c, sigma)) of ddim_sample (:1743-1777), in the
+        reference's fp32 tensor arithmetic (time_next = -1 indexes the last table entry, as the reference's negative
+        index does; that step returns x_start and its coefficients are not used)."""
+        T, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        times = torch.linspace(-1, T - 1, steps=S + 1)
+        times = list(reversed(times.int().tolist()))
+        ac = self.alphas_cumprod.detach().to("cpu", torch.float32)
+        coefs = torch.zeros((S, 3), dtype=torch.float32)
+        for i, (time, time_next) in enumerate(zip(times[:-1], times[1:])):
+            alpha, alpha_next = ac[time], ac[time_next]
+            sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            coefs[i, 0], coefs[i, 1], coefs[i, 2] = alpha_next.sqrt(), c, sigma
+        return times, torch.nan_to_num(coefs, nan=0.0)
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, cond, n_composed=None, clip_denoised=True, compose_start_step=4, compose_n_bodies=2,
+                    compose_mode="mean", design_fn=None, design_guidance="standard", initial_state_overwrite=None,
+                    initialization_mode=0, initialization_img=None, *, noise=None, seed=None, sample_offset=0,
+                    use_graph=True, init_img=None, step_range=None):
+        """:1724-1804.  Build-only keywords: ``init_img`` + ``step_range=(i0, i1)`` run DDIM steps i0 .. i1-1 from a given
+        state (teacher-forced segments for parity tests: the deterministic sampler amplifies a 1e-6 perturbation of the
+        U-Net to 1e-3 .. 1e-2 over 50 .. 250 steps with random-init weights -- measured on the CPU reference itself).
+        ``noise``: a NoiseTape whose ``step`` / ``recur`` / ``cond`` rows are indexed by the DDIM STEP index.
+        Without ``design_fn`` the whole loop is one library call (``cindm_ddpm1d_sample_ddim``); as in the reference the
+        prediction then ignores the compose keywords (:1755).  With ``design_fn`` (recurrence guidance only -- the
+        reference's non-recurrence branch does not return a noise prediction, :1283) each step is ``recurrence``
+        library predictions + the user's autograd gradient, and the DDIM update of the tiny state runs in torch."""
+        device = self.betas.device
+        if device.type != "cuda":
+            raise _ffi.CindmError("GaussianDiffusion1D is on the CPU: move it to a ROCm device; there is no CPU execution path")
+        if seed is None and noise is None:
+            seed = self._draw_seed()
+        seed = 0 if seed is None else int(seed)
+        if noise is not None:
+            noise = noise.to(device)
+        B = shape[0]
+        if init_img is not None:
+            img = self._f32(init_img, device).clone()
+        else:
+            img = self._init_state(tuple(shape), device, noise, seed, sample_offset, self.num_timesteps)
+        times, coefs = self.ddim_schedule()
+        i0, i1 = (0, len(times) - 1) if step_range is None else step_range
+        times, coefs = times[i0:i1 + 1], coefs[i0:i1].contiguous()
+        if noise is not None:
+            sl = lambda v: None if v is None else v[i0:i1].contiguous()
+            noise = NoiseTape(noise.init, sl(noise.step), sl(noise.recur), sl(noise.cond))
+        S = len(times) - 1
+        inpaint = cond if (self.conditioned_steps == 0 and cond is not None) else None
+        if design_fn is None:
+            desc = self._desc_for(shape, None, clip=clip_denoised)
+            h, un, ws = self._prepare(desc, B, device)
+            cond_d = self._f32(cond, device) if (cond is not None and self.conditioned_steps != 0) else None
+            inp = self._f32(inpaint, device)
+            tarr = (C.c_int32 * (S + 1))(*times)
+            carr = coefs.contiguous()
+            with torch.cuda.device(device):
+                _ffi.check(_ffi.lib().cindm_ddpm1d_sample_ddim(
+                    h, self.model._h, un, C.byref(desc), _ffi.ptr(img), _ffi.ptr(cond_d), S, tarr, _ffi.ptr(carr),
+                    _ffi.ptr(None if noise is None else noise.step), C.c_uint64(seed), sample_offset, _ffi.ptr(inp),
+                    0 if inp is None else inp.shape[1], _ffi.ptr(None if noise is None else noise.cond), B,
+                    _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+            return img
+        if "recurrence" not in design_guidance:
+            raise NotImplementedError("DDIM with design_fn needs a '-recurrence-N' guidance (the reference's other branch "
+                                      "returns x_{t-1}, not a noise prediction, :1283)")
+        n_composed = 0 if n_composed is None else n_composed
+        desc = self._desc_for(shape, compose_mode, n_composed, compose_start_step, shape[1], compose_n_bodies,
+                              clip=True)     # p_sample_compose_inside's own default: clip_denoised is not forwarded (:1758-1770)
+        coefs = coefs.to(device)
+        for i, (t, tn) in enumerate(zip(times[:-1], times[1:])):
+            rn = None if (noise is None or noise.recur is None) else noise.recur[i]
+            eps, x_start = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite,
+                                             None, rn, ddim_return=True)
+            if tn < 0:
+                img = x_start
+                continue
+            z = noise.step[i] if noise is not None else torch.randn_like(img)
+            img = x_start * coefs[i, 0] + coefs[i, 1] * eps + coefs[i, 2] * z
+            if inpaint is not None:
+                zc = noise.cond[i] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
+                img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
+        return img

@@ -191,6 +191,21 @@ int  cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* unco
                          int32_t t_start, int32_t t_end, int64_t B,
                          void* ws, size_t ws_bytes, void* stream, int32_t use_graph);
 
+/* DDIM loop (ddim_sample, model/diffusion_1d.py:1724-1804, design_fn == None): n_steps updates
+ * x <- x0 * sqrt(alpha_next) + c * eps + sigma * z at times[0] > times[1] > ... > times[n_steps]
+ * (times[n_steps] == -1: the last update returns x0); times [n_steps + 1] and coefs [n_steps][3] =
+ * (sqrt(alpha_next), c, sigma) are HOST arrays computed by the caller in the reference's tensor
+ * arithmetic (:1743-1777).  x0 is clamped when c->clip_denoised, eps is the model's (composed)
+ * prediction, not re-derived (:1755).  noise_steps / inpaint_noise_steps, when given, are indexed
+ * by the STEP index: [n_steps, B, L, F] / [n_steps, B, inpaint_steps, F]. */
+int  cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond,
+                              const cindm_compose_desc* c, float* x, const float* cond,
+                              int32_t n_steps, const int32_t* times, const float* coefs,
+                              const float* noise_steps, uint64_t seed, int64_t sample_offset,
+                              const float* inpaint_cond, int32_t inpaint_steps,
+                              const float* inpaint_noise_steps, int64_t B,
+                              void* ws, size_t ws_bytes, void* stream, int32_t use_graph);
+
 /* out[n] ~ N(0,1): the library's counter-based Gaussian (Philox4x32-10 + Box-Muller) for the
  * initial state x_T (:1673), keyed by (seed, sample_offset + b, step_tag, element);
  * out is [B, per_sample]. */

@@ -335,9 +335,9 @@ def compose_inside_eps(d, x, t, *, compose_mode, n_composed, compose_start_step,
     raise ValueError(compose_mode)
 
 
-def model_predictions(d, x, cond, t, **kw):
-    """model_predictions, model/diffusion_1d.py:951-1031 (clip_x_start=False as every caller
-    on the path leaves it).  Returns (pred_noise, x_start)."""
+def model_predictions(d, x, cond, t, clip_x_start=False, **kw):
+    """model_predictions, model/diffusion_1d.py:951-1031 (clip_x_start=False for the DDPM callers; ddim_sample passes
+    clip_denoised, :1755; rederive_pred_noise is never set on the path).  Returns (pred_noise, x_start)."""
     if d.conditioned_steps != 0:
         x = torch.cat([cond, x], dim=1)
     if "compose_mode" in kw and "inside" in kw["compose_mode"]:
@@ -350,14 +350,15 @@ def model_predictions(d, x, cond, t, **kw):
     else:
         out = d.model(x, torch.full((x.shape[0],), t, dtype=torch.long))
     T = d.tab
+    clipf = (lambda v: v.clamp(-1.0, 1.0)) if clip_x_start else (lambda v: v)
     if d.objective == "pred_noise":
         pred_noise = out
-        x_start = _ext(T["sqrt_recip_alphas_cumprod"], t) * x - _ext(T["sqrt_recipm1_alphas_cumprod"], t) * out
+        x_start = clipf(_ext(T["sqrt_recip_alphas_cumprod"], t) * x - _ext(T["sqrt_recipm1_alphas_cumprod"], t) * out)
     elif d.objective == "pred_x0":
-        x_start = out
+        x_start = clipf(out)
         pred_noise = (_ext(T["sqrt_recip_alphas_cumprod"], t) * x - x_start) / _ext(T["sqrt_recipm1_alphas_cumprod"], t)
     else:
-        x_start = _ext(T["sqrt_alphas_cumprod"], t) * x - _ext(T["sqrt_one_minus_alphas_cumprod"], t) * out
+        x_start = clipf(_ext(T["sqrt_alphas_cumprod"], t) * x - _ext(T["sqrt_one_minus_alphas_cumprod"], t) * out)
         pred_noise = (_ext(T["sqrt_recip_alphas_cumprod"], t) * x - x_start) / _ext(T["sqrt_recipm1_alphas_cumprod"], t)
     if d.conditioned_steps != 0:
         pred_noise = pred_noise[:, cond.size(1):]
@@ -427,7 +428,7 @@ def _relax_coefs(d, t):
 
 
 def p_sample(d, x, cond, t, noise, *, design_fn=None, design_guidance="standard",
-             initial_state_overwrite=None, recur_noise=None, clip_denoised=True, pmv_kwargs=None):
+             initial_state_overwrite=None, recur_noise=None, clip_denoised=True, pmv_kwargs=None, ddim_return=False):
     """p_sample (model/diffusion_1d.py:1047-1186) and, with ``pmv_kwargs`` holding the compose
     arguments, p_sample_compose_inside (:1190-1376): they differ only in what is forwarded to
     p_mean_variance.  ``noise`` replaces ``torch.randn_like(x)`` (ignored at t == 0);
@@ -445,15 +446,20 @@ def p_sample(d, x, cond, t, noise, *, design_fn=None, design_guidance="standard"
             pred = torch.cat([initial_state_overwrite, pred[:, k:]], 1)
     else:
         for r in range(R):
-            mean, logvar, x_start, _ = p_mean_variance(d, x, cond, t, clip_denoised, **kw)
+            mean, logvar, x_start, eps = p_mean_variance(d, x, cond, t, clip_denoised, **kw)
             pred = mean
+            shift = None
             if design_fn is not None:
-                pred = mean - _design_shift(d, design_fn, design_guidance, x, x_start, t)
+                shift = _design_shift(d, design_fn, design_guidance, x, x_start, t)
+                pred = mean - shift
             if initial_state_overwrite is not None:
                 k = initial_state_overwrite.shape[1]
                 pred = torch.cat([initial_state_overwrite, pred[:, k:]], 1)
             a, b = _relax_coefs(d, t)
             x = a * pred + b * recur_noise[r]
+        if ddim_return:
+            # sampling_timesteps != 1000 (:1372-1376): (pred_noise + grad_design_final, x_start) of the LAST iteration
+            return eps + shift, x_start
     if t > 0:
         pred = pred + (0.5 * logvar).exp() * noise
     return pred, x_start
@@ -623,6 +629,52 @@ def sample(d, batch_size, tape, cond=None, n_composed=2, compose_start_step=4, c
     return p_sample_loop(d, (batch_size, d.image_size, d.channels), cond, tape, n_composed=n_composed,
                          compose_start_step=compose_start_step, compose_n_bodies=compose_n_bodies,
                          compose_mode=compose_mode, **kw)
+
+
+def ddim_time_pairs(num_timesteps, sampling_timesteps):
+    """The (time, time_next) schedule of ddim_sample, model/diffusion_1d.py:1743-1745."""
+    times = torch.linspace(-1, num_timesteps - 1, steps=sampling_timesteps + 1)
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def ddim_coefs(d, time, time_next, eta):
+    """(sqrt(alpha_next), c, sigma) of one DDIM update, :1773-1777, in the reference's fp32 tensor arithmetic
+    (time_next = -1 indexes the LAST table entry, as the reference's negative index does; that step's img is
+    replaced by x_start anyway)."""
+    ac = d.tab["alphas_cumprod"]
+    alpha, alpha_next = ac[time], ac[time_next]
+    sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+    c = (1 - alpha_next - sigma ** 2).sqrt()
+    return alpha_next.sqrt(), c, sigma
+
+
+def ddim_sample(d, shape, cond, tape, *, sampling_timesteps, eta=0.0, clip_denoised=True, n_composed=0,
+                compose_start_step=4, compose_n_bodies=2, compose_mode="mean", design_fn=None,
+                design_guidance="standard", initial_state_overwrite=None, record=None):
+    """ddim_sample, model/diffusion_1d.py:1724-1804.  ``tape``: dict with ``init`` [B,L,F] (x_T, :1749), ``step`` [S,B,L,F]
+    (the randn_like(img) of step i, :1779, drawn even when sigma == 0) and, when inpainting, ``cond`` [S,B,Lc,F] (:1792);
+    with ``design_fn`` also ``recur`` [S,R,B,L,F] (:1365).  Returns the final img [B,L,F]."""
+    img = tape["init"].clone()
+    for i, (time, time_next) in enumerate(ddim_time_pairs(d.num_timesteps, sampling_timesteps)):
+        if design_fn is None:
+            pred_noise, x_start = model_predictions(d, img, cond, time, clip_x_start=clip_denoised)
+        else:
+            pred_noise, x_start = p_sample_compose_inside(
+                d, img, cond, time, None, design_fn=design_fn, design_guidance=design_guidance, compose_mode=compose_mode,
+                n_composed=n_composed, compose_start_step=compose_start_step, single_model_step=shape[1],
+                compose_n_bodies=compose_n_bodies, initial_state_overwrite=initial_state_overwrite,
+                recur_noise=tape["recur"][i], ddim_return=True)
+        san, c, sigma = ddim_coefs(d, time, time_next, eta)
+        img = x_start * san + c * pred_noise + sigma * tape["step"][i]
+        if time_next < 0:
+            img = x_start
+        elif d.conditioned_steps == 0 and cond is not None:
+            img = img.clone()
+            img[:, :cond.shape[1], :] = q_sample(d, cond, time, tape["cond"][i])
+        if record is not None:
+            record(i, img)
+    return img
 
 
 def sample_compose_multibodies(d, cond, N, tape, t_stop=0, record=None, resume=None):

@@ -13,7 +13,7 @@ import torch
 
 import cindm_amd
 import cindm_oracle as O
-from test_oracle_golden import STEP_CASES, point_objective
+from test_oracle_golden import DDIM_CASES, STEP_CASES, ddim_tape, point_objective
 
 pytestmark = pytest.mark.gpu
 
@@ -317,3 +317,48 @@ def test_counter_noise(device):
     assert float(a.abs().max()) < 7.0
     flat = a.flatten()
     assert abs(float((flat[:-1] * flat[1:]).mean())) < 0.01
+
+
+# ------------------------------------------------------------------ DDIM (sampling_timesteps < timesteps)
+@pytest.mark.parametrize("tag", sorted(DDIM_CASES))
+def test_ddim_golden(gold_dir, device, unet8, tag):
+    """sample() with sampling_timesteps < timesteps against the reference's ddim_sample (same noise draws)."""
+    g = np.load(os.path.join(gold_dir, "ddim_1d.npz"))
+    S, eta, B, seed, guid, R = DDIM_CASES[tag]
+    cond = torch.from_numpy(g[tag + ".cond"]).to(device) if (tag + ".cond") in g.files else None
+    d = cindm_amd.GaussianDiffusion1D(unet8[0], image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=S,
+                                      loss_type="l1", ddim_sampling_eta=eta).to(device)
+    tp = ddim_tape(seed, (B, 24, 8), S, R=R, cond_shape=None if cond is None else tuple(cond.shape))
+    tape = cindm_amd.NoiseTape(tp["init"], tp["step"], tp.get("recur"), tp.get("cond"))
+    kw = dict(n_composed=0, compose_n_bodies=2)
+    if guid:
+        kw.update(design_fn=point_objective, design_guidance=guid, compose_mode="mean-inside")
+    out = d.sample(batch_size=B, cond=cond, noise=tape, **kw)
+    assert out.shape == (B, 24, 8)
+    if S <= 20:
+        assert rel(out, g[tag + ".final"]) < TOL_CHAIN, tag
+        return
+    # Long deterministic chains: with random-init weights the DDIM map amplifies a 1e-6 relative perturbation of the
+    # U-Net output to 9e-4 (S = 50) / 2e-2 (S = 250) -- measured by perturbing the CPU reference itself -- so the
+    # end-to-end result is only held to that scale, and parity proper is teacher-forced: every segment between two
+    # reference checkpoints is run from the reference's state and compared at the chain tolerance.
+    assert rel(out, g[tag + ".final"]) < 5e-2, tag
+    ck_i = [int(i) for i in g[tag + ".ckpt_i"]]
+    for k, i in enumerate(ck_i):
+        i_next = ck_i[k + 1] if k + 1 < len(ck_i) else S - 1
+        want = g[tag + ".ckpt"][k + 1] if k + 1 < len(ck_i) else g[tag + ".final"]
+        seg = d.ddim_sample((B, 24, 8), cond, n_composed=0, noise=tape, init_img=torch.from_numpy(g[tag + ".ckpt"][k]).to(device),
+                            step_range=(i + 1, i_next + 1))
+        assert rel(seg, want) < TOL_CHAIN, (tag, i, i_next)
+
+
+def test_ddim_graph_equals_stream_and_shards(device, unet8):
+    d = cindm_amd.GaussianDiffusion1D(unet8[0], image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=25,
+                                      loss_type="l1", ddim_sampling_eta=1.0).to(device)
+    a = d.sample(batch_size=64, n_composed=0, seed=7)
+    b = d.sample(batch_size=64, n_composed=0, seed=7, use_graph=False)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    lo = d.sample(batch_size=32, n_composed=0, seed=7, sample_offset=0)
+    hi = d.sample(batch_size=32, n_composed=0, seed=7, sample_offset=32)
+    assert torch.equal(a[:32], lo) and torch.equal(a[32:], hi)
+    assert float(a.abs().max()) <= 1.0 + 1e-5            # the last DDIM step returns the clamped x_start

@@ -139,9 +139,13 @@ def test_no_cpu_fallback():
         d.p_sample_compose_inside(torch.zeros(2, 24, 8), None, 5, single_model_step=24)
     with pytest.raises(NotImplementedError):
         d(torch.zeros(2, 24, 8))
-    d.sampling_timesteps = 250
-    with pytest.raises(NotImplementedError):
+    d.sampling_timesteps = 250                     # DDIM dispatch (:2348): same rule, no CPU path
+    with pytest.raises(_ffi.CindmError, match="no CPU execution path"):
         d.sample(batch_size=2)
+    times, coefs = d.ddim_schedule()
+    assert times[0] == 999 and times[-1] == -1 and len(times) == 251 and coefs.shape == (250, 3)
+    assert all(a > b for a, b in zip(times[:-1], times[1:])) and bool(torch.isfinite(coefs).all())
+    assert float(coefs[:, 2].abs().max()) == 0.0     # eta = 0: sigma = 0
 
 
 def test_product_does_not_import_oracle():

@@ -252,3 +252,47 @@ def test_chain_2d_head(gold_dir, sd2d):
     out = O.p_sample_loop_2d(od, (1, 2, 21, 64, 64), init, steps, t_stop=750)
     i = list(g["cfg5.ckpt_t"]).index(750)
     assert rel(out[:, :, :, 16:32, 16:32], g["cfg5.ckpt_crop"][i]) < TOL
+
+
+# ====================================================================== DDIM (sampling_timesteps < timesteps)
+def ddim_tape(seed, shape, S, R=0, cond_shape=None):
+    """The noise tape the DDIM goldens were captured with (oracle/make_golden_ddim.py), rows indexed by STEP index."""
+    g = torch.Generator().manual_seed(seed)
+    t = {"init": torch.randn(shape, generator=g), "step": torch.randn((S,) + tuple(shape), generator=g)}
+    if R:
+        t["recur"] = torch.randn((S, R) + tuple(shape), generator=g)
+        t["pnoise"] = torch.randn((S,) + tuple(shape), generator=g)
+    if cond_shape:
+        t["cond"] = torch.randn((S,) + tuple(cond_shape), generator=g)
+    return t
+
+
+# tag -> (sampling_timesteps, eta, batch, tape seed, guidance or None, recurrence count)
+DDIM_CASES = {"s50": (50, 0.0, 4, 3101, None, 0), "s20_eta05": (20, 0.5, 2, 3102, None, 0), "s250": (250, 0.0, 2, 3103, None, 0),
+              "s20_inpaint": (20, 0.0, 2, 3104, None, 0), "s10_guided_r2": (10, 0.0, 2, 3105, "standard-recurrence-2", 2),
+              "s10_guided_alpha_r1": (10, 0.3, 2, 3106, "standard-alpha-recurrence-1", 1)}
+
+
+@pytest.mark.parametrize("tag", sorted(DDIM_CASES))
+def test_ddim_chains(gold_dir, sd8, tag):
+    g = np.load(os.path.join(gold_dir, "ddim_1d.npz"))
+    S, eta, B, seed, guid, R = DDIM_CASES[tag]
+    cond = torch.from_numpy(g[tag + ".cond"]) if (tag + ".cond") in g.files else None
+    d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0)
+    tape = ddim_tape(seed, (B, 24, 8), S, R=R, cond_shape=None if cond is None else tuple(cond.shape))
+    kw = dict(n_composed=0, compose_n_bodies=2)
+    if guid:
+        kw.update(design_fn=point_objective, design_guidance=guid, compose_mode="mean-inside")
+    rec = {}
+    out = O.ddim_sample(d, (B, 24, 8), cond, tape, sampling_timesteps=S, eta=eta,
+                        record=lambda i, img: rec.__setitem__(i, img.clone()), **kw)
+    assert rel(out, g[tag + ".final"]) < TOL
+    for i, ck in zip(g[tag + ".ckpt_i"], g[tag + ".ckpt"]):
+        assert rel(rec[int(i)], ck) < TOL, (tag, i)
+
+
+def test_ddim_schedule_landmarks():
+    pairs = O.ddim_time_pairs(1000, 250)
+    assert len(pairs) == 250 and pairs[0][0] == 999 and pairs[-1] == (3, -1) or pairs[-1][1] == -1
+    assert all(a > b for a, b in pairs)
+    assert O.ddim_time_pairs(1000, 1000)[-1] == (0, -1)
