@@ -20,6 +20,7 @@ namespace cindm {
 
 enum SrcMode2d { SRC2_PLAIN = 0, SRC2_GN_SS_SILU = 4, SRC2_LN = 2 };
 enum ConvKind { CONV_3X3 = 0, CONV_1X1 = 1, CONV_UP2 = 2, CONV_UNSHUF = 3, CONV_STEM7 = 4, CONV_1X1_WIDE = 5 };
+// Packed2::h3: 3x3 weights packed as split fp16 for conv2d_h3_kernel
 
 constexpr int T2Y = 4, T2X = 16, T2M = T2Y * T2X;    // output pixel tile 4 x 16
 constexpr int T2N = 64;                               // output channels per workgroup
@@ -390,6 +391,193 @@ __global__ __launch_bounds__(256, 2) void conv2d_tile_kernel(const Conv2dArgs a)
         }
     }
     conv2d_epilogue(a, acc, Red, tabE, img, ti, ty0, tx0);
+}
+
+// conv2d_h3_kernel<KIND, MODE>: the 3x3 convolutions (KIND = CONV_3X3 / CONV_UP2) with every fp32 product evaluated on
+// the fp16 matrix cores as the 3-term split of kernels.h (a = ah + 2^-11 al', b likewise; a.b ~ ah.bh + 2^-11 (ah.bl' +
+// al'.bh), fp32 accumulation in two accumulator sets) -- fp32-faithful at 16/3 x the fp32 MFMA rate.  Same 4 x 16 pixel
+// x 64 channel output tile and zero-filled halo staging as conv2d_tile_kernel; a pipeline chunk is 64 input channels;
+// the 4 waves split the chunk's two 32-channel k-groups (kg = w & 1) and the two 32-column halves (nh = w >> 1), so a
+// wave feeds v_mfma_f32_16x16x32_f16 with A fragments of 8 consecutive channels per lane (one ds_read_b128 per pixel
+// block and plane, at constant offsets) and B fragments straight from L2 (ring of 3 tap slots, re-loaded right after
+// use).  A is normalised in fp32 and split into hi / scaled-lo fp16 planes while it is staged.  The reduce tile aliases
+// the A planes (62 KB of LDS per workgroup -> two workgroups per CU).
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
+    constexpr int KC = 64, SW = 18, R = 108, PITCH = 144, PLANE = R * PITCH, F4 = 16, RPP = 16, NP = (R + RPP - 1) / RPP;
+    static_assert(4 * PLANE >= 4 * T2M * LDR2 * 4, "reduce tile must fit into the A planes");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * PLANE];       // [buffer][plane hi/lo][R][PITCH]
+    __shared__ float tabA[16];
+    __shared__ float tabE[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int kg = w & 1, nh = w >> 1;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int img = mt / a.tpi, ti = mt - img * a.tpi;
+    const int tyi = ti / a.tiles_x;
+    const int ty0 = tyi * T2Y, tx0 = (ti - tyi * a.tiles_x) * T2X;
+    const int HWi = a.Hin * a.Win;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+
+    f32x4 accM[4][2], accL[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int c4 = tid % F4, r0 = tid / F4;
+    size_t goff[NP];
+    bool rok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = r0 + RPP * p;
+        const int hy = r / SW, hx = r - hy * SW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = (r < R) && (y >= 0) && (y < a.Hout) && (x >= 0) && (x < a.Wout);
+        const int srcpix = (KIND == CONV_UP2) ? (y >> 1) * a.Win + (x >> 1) : y * a.Win + x;
+        rok[p] = ok;
+        goff[p] = (size_t)img * HWi + (ok ? srcpix : 0);
+    }
+    const int nch0 = (a.src[0].C + KC - 1) / KC;
+    const int nch = a.CinP / KC;
+    const int ntap = nch * 9;
+
+    // B: [n-tile][chunk][tap][q = nb*2 + plane][thread][8 halfs]
+    half8 breg[3][2][2];
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)nt * ntap * 4 * 256 + tid;
+    auto load_b = [&](int g, int slot) {                 // g = chunk * 9 + tap (clamped by the caller)
+        const uint4* wp = wbase + (size_t)g * 4 * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[slot][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+    };
+    float4 areg[NP];
+    float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), psc = pb, psh = pb;
+    auto src_ptr = [&](int cc, int& cl, int& Cc, int& ld) -> const float* {
+        const bool first = (cc < nch0) || (a.nsrc == 1);
+        cl = (first ? cc : cc - nch0) * KC + c4 * 4;
+        Cc = first ? a.src[0].C : a.src[1].C;
+        ld = first ? a.src[0].ld : a.src[1].ld;
+        return first ? a.src[0].p : a.src[1].p;
+    };
+    auto load_a = [&](int cc) {
+        int cl, Cc, ld;
+        const float* base = src_ptr(cc, cl, Cc, ld);
+        const int clc = min(cl, Cc - 4);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            areg[p] = *reinterpret_cast<const float4*>(base + goff[p] * ld + clc);
+        if constexpr (MODE == SRC2_GN_SS_SILU) {
+            const Src& s = a.src[0];
+            pg = *reinterpret_cast<const float4*>(s.gamma + clc);
+            pb = *reinterpret_cast<const float4*>(s.beta + clc);
+            if (s.tb) {
+                psc = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + clc);
+                psh = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + s.C + clc);
+            }
+        }
+    };
+    load_b(0, 0); load_b(min(1, ntap - 1), 1); load_b(min(2, ntap - 1), 2);
+    load_a(0);
+    if constexpr (MODE == SRC2_GN_SS_SILU) {
+        const Src& s = a.src[0];
+        if (tid < 8) {
+            float m, r;
+            merge_stats(s.stats + ((size_t)img * 8 + tid) * 2, 1, s.cnt, 1e-5f, m, r);
+            tabA[2 * tid] = m; tabA[2 * tid + 1] = r;
+        }
+    }
+    if (a.e_y && tid >= 64 && tid < 72) {
+        float m, r;
+        merge_stats(a.e_stats + ((size_t)img * 8 + (tid - 64)) * 2, 1, a.e_cnt, 1e-5f, m, r);
+        tabE[2 * (tid - 64)] = m; tabE[2 * (tid - 64) + 1] = r;
+    }
+    const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
+
+    auto store_a = [&](int cc, int buf) {
+        int cl, Cc, ld;
+        (void)src_ptr(cc, cl, Cc, ld);
+        const bool cok = cl < Cc;
+        const int clc = min(cl, Cc - 4);
+        unsigned char* P0 = smem + (size_t)(buf * 2) * PLANE;
+        unsigned char* P1 = P0 + PLANE;
+        float gm = 0.f, gr = 1.f;
+        if constexpr (MODE == SRC2_GN_SS_SILU) { const int ti2 = (clc >> gw_shift) * 2; gm = tabA[ti2]; gr = tabA[ti2 + 1]; }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + RPP * p;
+            float4 v = areg[p];
+            if constexpr (MODE == SRC2_GN_SS_SILU) {
+                v.x = silu_f(((v.x - gm) * gr * pg.x + pb.x) * (psc.x + 1.0f) + psh.x);
+                v.y = silu_f(((v.y - gm) * gr * pg.y + pb.y) * (psc.y + 1.0f) + psh.y);
+                v.z = silu_f(((v.z - gm) * gr * pg.z + pb.z) * (psc.z + 1.0f) + psh.z);
+                v.w = silu_f(((v.w - gm) * gr * pg.w + pb.w) * (psc.w + 1.0f) + psh.w);
+            }
+            const bool ok = rok[p] && cok;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            if (r < R) {
+                *reinterpret_cast<half4v*>(P0 + r * PITCH + c4 * 8) = hi;
+                *reinterpret_cast<half4v*>(P1 + r * PITCH + c4 * 8) = lo;
+            }
+        }
+    };
+    // per-lane fragment byte offset inside a plane: pixel column (lane & 15), this wave's k-group, 8 channels at (lane >> 4) * 8
+    const int abase = (lane & 15) * PITCH + kg * 64 + (lane >> 4) * 16;
+
+    __syncthreads();
+    store_a(0, 0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nch; ++ch) {
+        const int chn = min(ch + 1, nch - 1);
+        load_a(chn);
+        const unsigned char* P0 = smem + (size_t)((ch & 1) * 2) * PLANE + abase;
+        const unsigned char* P1 = P0 + PLANE;
+        half8 fh[2][4], fl[2][4];
+        auto read_frags = [&](int tap, half8 (&ah)[4], half8 (&al)[4]) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                ah[mb] = *reinterpret_cast<const half8*>(P0 + ((mb + dy) * SW + dx) * PITCH);
+                al[mb] = *reinterpret_cast<const half8*>(P1 + ((mb + dy) * SW + dx) * PITCH);
+            }
+        };
+        read_frags(0, fh[0], fl[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) read_frags(tap + 1, fh[(tap + 1) & 1], fl[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 (&ah)[4] = fh[tap & 1];
+            const half8 (&al)[4] = fl[tap & 1];
+            const int slot = tap % 3;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], breg[slot][nb][0], accM[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], breg[slot][nb][1], accL[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], breg[slot][nb][0], accL[mb][nb], 0, 0, 0);
+                }
+            load_b(min(ch * 9 + tap + 3, ntap - 1), slot);       // this slot's next tap, two taps ahead of its use
+        }
+        store_a(chn, (ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // combine the two accumulator sets into the wave's 64 x 32 part of a 64 x 64 tile (other half zero) and reuse the
+    // shared epilogue; the reduce tile aliases the A planes (everyone is past the last __syncthreads of the loop)
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4 v = accM[mb][nb & 1] + accL[mb][nb & 1] * H3_INV;
+            acc[mb][nb] = ((nb >> 1) == nh) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    conv2d_epilogue(a, acc, reinterpret_cast<float (*)[T2M * LDR2]>(smem), tabE, img, ti, ty0, tx0);
 }
 
 // 7x7 stem (init_conv, :303): input = the padded state (CP = 24 channels, 21 real).  Halo tile 10 x 22 pixels x 24
