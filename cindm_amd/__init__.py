@@ -6,9 +6,10 @@ There is no CPU execution path: a missing / unloadable library raises on first u
 from ._ffi import CindmError
 from .diffusion1d import GaussianDiffusion1D, NoiseTape
 from .diffusion2d import GaussianDiffusion, NoiseTape2D
+from .objectives import PointObjective
 from .schedule import make_schedule
 from .unet1d import TemporalUnet1D
 from .unet2d import Unet
 
 __all__ = ["TemporalUnet1D", "GaussianDiffusion1D", "NoiseTape", "Unet", "GaussianDiffusion", "NoiseTape2D",
-           "make_schedule", "CindmError"]
+           "PointObjective", "make_schedule", "CindmError"]

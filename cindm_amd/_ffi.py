@@ -44,6 +44,11 @@ class ComposeDesc(C.Structure):
                 ("objective", C.c_int32), ("clip_denoised", C.c_int32), ("uncond_coef", C.c_float)]
 
 
+class DesignDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("alpha", C.c_int32), ("recurrence", C.c_int32), ("last_n_step", C.c_int32),
+                ("coef", C.c_float), ("time_consistency_coef", C.c_float), ("pos_target", C.c_float * 2)]
+
+
 COMPOSE_PLAIN, COMPOSE_MEAN_INSIDE, COMPOSE_SUM_INSIDE, COMPOSE_MEAN_OUTSIDE, COMPOSE_NOISESUM_OUTSIDE, \
     COMPOSE_MULTIBODY = range(6)
 OBJECTIVES = {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}
@@ -79,6 +84,8 @@ SIGNATURES = {
                                       _vp, _i32, _vp, _i32, _i32, _i64, _vp, _sz, _vp, _i32]),
     "cindm_ddpm1d_sample_ddim": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc), _vp, _vp, _i32, _vp, _vp, _vp, _u64, _i64,
                                            _vp, _i32, _vp, _i64, _vp, _sz, _vp, _i32]),
+    "cindm_ddpm1d_sample_guided": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc), C.POINTER(DesignDesc), _vp, _vp, _vp, _vp,
+                                             _u64, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _sz, _vp, _i32]),
     "cindm_fill_normal": (C.c_int, [_vp, _i64, _i64, _u64, _i64, _i32, _vp]),
     "cindm_ddpm1d_launches_per_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc)]),
     "cindm_unet2d_create": (C.c_int, [C.POINTER(Unet2dDesc), C.POINTER(_vp)]),

@@ -806,7 +806,7 @@ extern "C" void cindm_ddpm1d_destroy(cindm_ddpm1d* h) {
 struct StepLayout {
     int64_t pair_rows = 0, single_rows = 0;
     int pair_F = 0, Tw = 0, Lfull = 0;
-    size_t off_pair_in = 0, off_pair_eps = 0, off_single_in = 0, off_single_eps = 0, off_ws_pair = 0, off_ws_single = 0, total = 0;
+    size_t off_pair_in = 0, off_pair_eps = 0, off_single_in = 0, off_single_eps = 0, off_ws_pair = 0, off_ws_single = 0, off_tmp = 0, total = 0;
     bool direct = false;     // plain mode, no cond: U-Net reads x directly
 };
 
@@ -845,6 +845,7 @@ static int step_layout(const cindm_unet1d* pair, const cindm_unet1d* uncond, con
     s.off_single_eps = o; o += al((size_t)s.single_rows * s.Tw * 4 * 4);
     s.off_ws_pair = o; o += al(cindm_unet1d_workspace_bytes(pair, s.pair_rows));
     s.off_ws_single = o; if (s.single_rows) o += al(cindm_unet1d_workspace_bytes(uncond, s.single_rows));
+    s.off_tmp = o; o += al((size_t)B * Ltot * c->n_bodies * 4 * 4);       // guided steps: x_out staging (the gradient reads neighbours of x)
     s.total = o + 256;
     return 0;
 }
@@ -881,6 +882,9 @@ struct StepIO {
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
     int dec_t;              // sample loop: decrement the device step counter at the end of the step
     const float* ddim_tab; const int* ddim_tnext;      // DDIM loop: per-step coefficient / time_next tables (device)
+    const cindm_design_desc* dz;                       // built-in design objective (guided loop) or null
+    int relax; const float* recur_noise; int64_t recur_t_stride; uint32_t recur_tag;
+    const float* iso; int iso_steps;
 };
 
 static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -914,6 +918,15 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.inp_cond = io.inp_cond; a.inp_steps = io.inp_steps; a.inp_noise = io.inp_noise; a.inp_noise_t_stride = io.inp_noise_t_stride;
     if (io.dec_t) { a.t_dec = h->t_dev; a.done = reinterpret_cast<unsigned*>(h->t_dev + 1); }
     if (io.ddim_tab) { a.ddim_tab = io.ddim_tab; a.ddim_tnext = io.ddim_tnext; a.step_idx = h->t_dev + 2; }
+    const bool guided = io.dz && io.x_out;
+    if (guided) {
+        a.dz_mode = io.dz->mode; a.dz_alpha = io.dz->alpha; a.dz_last_n = io.dz->last_n_step; a.dz_coef = io.dz->coef;
+        a.dz_tc = io.dz->time_consistency_coef; a.dz_tx = io.dz->pos_target[0]; a.dz_ty = io.dz->pos_target[1];
+        a.relax = io.relax; a.recur_noise = io.recur_noise; a.recur_t_stride = io.recur_t_stride; a.recur_tag = io.recur_tag;
+        a.iso = io.iso; a.iso_steps = io.iso_steps;
+        a.betas = tb; a.ac = tb + 1 * T; a.acp = tb + 2 * T;
+        a.x_out = (float*)(w + s.off_tmp);
+    }
 
     const float* unet_in = io.x;
     if (!s.direct) {
@@ -930,6 +943,7 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     const int64_t ne = B * (int64_t)Ltot * a.F;
     hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);
     HIPCHK(hipGetLastError());
+    if (guided) HIPCHK(hipMemcpyAsync(io.x_out, a.x_out, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 
@@ -1074,6 +1088,53 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)times[0]);
     return replay_steps(stream, n_steps, use_graph,
                         [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
+}
+
+extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
+                                          const cindm_design_desc* dz, float* x, const float* cond, const float* noise_steps,
+                                          const float* recur_noise_steps, uint64_t seed, int64_t sample_offset,
+                                          const float* inpaint_cond, int32_t inpaint_steps, const float* inpaint_noise_steps,
+                                          const float* initial_state_overwrite, int32_t overwrite_steps,
+                                          int32_t t_start, int32_t t_end, int64_t B, void* ws, size_t ws_bytes, void* stream_,
+                                          int32_t use_graph) {
+    REQUIRE(h && pair && c && dz && x, "null argument");
+    REQUIRE(t_start < h->T && t_end >= 0 && t_end <= t_start, "bad timestep range");
+    REQUIRE(dz->mode == 1 || dz->mode == 2, "design objective mode must be 1 (L2) or 2 (L2square)");
+    REQUIRE(dz->recurrence >= 0 && dz->recurrence <= 64, "recurrence count out of range");
+    const int Ltot = state_len(pair, c);
+    REQUIRE(dz->last_n_step >= 1 && dz->last_n_step <= Ltot, "last_n_step out of range");
+    REQUIRE(!initial_state_overwrite || (overwrite_steps >= 1 && overwrite_steps <= Ltot), "bad overwrite_steps");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (use_graph && stream == nullptr) {
+        if (!h->own) HIPCHK(hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking));
+        HIPCHK(hipDeviceSynchronize());
+        stream = h->own;
+    }
+    const int F = c->n_bodies * 4;
+    const int R = dz->recurrence;
+    StepIO io{};
+    io.x = x; io.cond = cond; io.x_out = x;
+    io.noise = noise_steps; io.noise_t_stride = (int64_t)B * Ltot * F; io.seed = seed; io.sample_off = sample_offset; io.add_noise = 1;
+    io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
+    io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
+    io.dz = dz; io.iso = initial_state_overwrite; io.iso_steps = initial_state_overwrite ? overwrite_steps : 0;
+    io.recur_t_stride = (int64_t)(R > 0 ? R : 1) * B * Ltot * F;
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)t_start);
+    // one reverse step (:1286-1370): R x [p_mean_variance, mean - grad, overwrite, relaxation]; the last iteration's
+    // relaxation is never used by the reference, its pred + sigma z is the step's result
+    auto step = [&]() -> int {
+        const int iters = R > 0 ? R : 1;
+        for (int r = 0; r < iters; ++r) {
+            StepIO it = io;
+            it.relax = (r < iters - 1) ? 1 : 0;
+            it.dec_t = it.relax ? 0 : 1;
+            it.recur_noise = recur_noise_steps ? recur_noise_steps + (size_t)r * B * Ltot * F : nullptr;
+            it.recur_tag = 0x10000u * (uint32_t)(r + 1);
+            if (run_step(h, pair, uncond, c, it, 0, h->t_dev, B, ws, ws_bytes, stream) != 0) return -1;
+        }
+        return 0;
+    };
+    return replay_steps(stream, t_start - t_end + 1, use_graph, step);
 }
 
 extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed, int64_t sample_offset,

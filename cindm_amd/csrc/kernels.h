@@ -836,6 +836,16 @@ struct ComposeArgs {
     // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
     // device step index; noise tapes are then indexed by the step index instead of t
     const float* ddim_tab; const int* ddim_tnext; int* step_idx;
+    // built-in design objective (the paper's point objective, inference/inverse_design_diffusion_1d.py:211-229) with
+    // "standard" / "standard-alpha" (-recurrence-N) guidance: pred = mean - [eta_t] * grad_x objective(x)
+    int dz_mode;                 // 0 off, 1 "L2", 2 "L2square"
+    int dz_alpha;                // 1: scale the gradient by eta_t = beta_t / sqrt(alphas_cumprod_prev_t) (standard-alpha)
+    int dz_last_n; float dz_coef, dz_tc, dz_tx, dz_ty;
+    int relax;                   // this launch is a relaxation iteration (:1365-1367): x <- a_t pred + b_t z'
+    const float* recur_noise;    // explicit z' of this iteration (+ t * recur_t_stride), or null (counter-based, tag below)
+    int64_t recur_t_stride; uint32_t recur_tag;
+    const float* iso; int iso_steps;     // initial_state_overwrite [B, iso_steps, F] (:1352-1361) or null
+    const float* betas; const float* ac; const float* acp;     // schedule tables for eta_t and the relaxation
 };
 
 __device__ __forceinline__ int pair_index(int i, int j, int nb) {   // i < j, order (0,1),(0,2),..,(1,2),..
@@ -976,7 +986,53 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
     if (a.mean_out) a.mean_out[i] = mean;
     if (a.x0_out) a.x0_out[i] = x0;
     if (a.eps_out) a.eps_out[i] = eps;
-    if (a.x_out && a.ddim_tab) {
+    if (a.x_out && a.dz_mode) {
+        // guided update with the built-in objective (x_out never aliases x here: the gradient reads neighbours)
+        float g = 0.f;
+        if (comp < 2) {
+            if (lx >= a.Ltot - a.dz_last_n) {
+                const float d = xv - (comp == 0 ? a.dz_tx : a.dz_ty);
+                const float scale = a.dz_coef / (float)a.dz_last_n;
+                if (a.dz_mode == 1) {
+                    const float dother = a.x[i ^ 1] - (comp == 0 ? a.dz_ty : a.dz_tx);
+                    g = scale * d / sqrtf(d * d + dother * dother);
+                } else {
+                    g = scale * 2.0f * d;
+                }
+            }
+            if (a.dz_tc > 0.f && a.Ltot > 1) {
+                float lap = 0.f;
+                if (lx >= 1) lap += xv - a.x[i - a.F];
+                if (lx + 1 < a.Ltot) lap -= a.x[i + a.F] - xv;
+                g += a.dz_tc * 2.0f * lap / (float)(a.Ltot - 1);
+            }
+        }
+        if (a.dz_alpha) g *= a.betas[t] / sqrtf(a.acp[t]);
+        float pred = mean - g;
+        if (a.iso && lx < a.iso_steps) pred = a.iso[((size_t)b * a.iso_steps + lx) * a.F + f];
+        const uint32_t el = (uint32_t)(lx * a.F + f);
+        float v;
+        if (a.relax) {
+            const float ratio = a.ac[t] / a.acp[t];
+            const float z = a.recur_noise ? a.recur_noise[(size_t)t * a.recur_t_stride + i]
+                                          : counter_normal(a.seed ^ 0x7f4a7c15u, (uint64_t)(a.sample_off + b), a.recur_tag + (uint32_t)t, el);
+            v = sqrtf(ratio) * pred + sqrtf(1.0f - ratio) * z;
+        } else {
+            v = pred;
+            if (a.add_noise && t > 0) {
+                const float z = a.noise ? a.noise[(size_t)t * a.noise_t_stride + i]
+                                        : counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                v += expf(0.5f * a.logvar[t]) * z;
+            }
+            if (a.inp_cond && lx < a.inp_steps) {
+                const size_t ci = ((size_t)b * a.inp_steps + lx) * a.F + f;
+                const float z = a.inp_noise ? a.inp_noise[(size_t)t * a.inp_noise_t_stride + ci]
+                                            : counter_normal(a.seed ^ 0x5bd1e995u, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z;
+            }
+        }
+        a.x_out[i] = v;
+    } else if (a.x_out && a.ddim_tab) {
         // x_{next} = x0 * sqrt(alpha_next) + c * eps + sigma * z (:1781-1783); the last step returns x0 (:1784-1789)
         const int tn = a.ddim_tnext[sidx];
         const uint32_t el = (uint32_t)(lx * a.F + f);

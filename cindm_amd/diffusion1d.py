@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from . import _ffi
+from .objectives import PointObjective
 from .schedule import make_schedule
 
 ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
@@ -343,6 +344,25 @@ class GaussianDiffusion1D(nn.Module):
                 _ffi.current_stream(img.device), int(use_graph)))
         return img
 
+    @torch.no_grad()
+    def _run_guided_loop(self, img, cond, desc, dz, t_start, t_end, *, noise, seed, sample_offset, inpaint_cond,
+                         initial_state_overwrite, use_graph=True):
+        """Reverse steps t_start .. t_end guided by the built-in objective as one library call
+        (cindm_ddpm1d_sample_guided); ``noise`` rows (step / recur / cond) are indexed by t."""
+        device, B = img.device, img.shape[0]
+        h, un, ws = self._prepare(desc, B, device)
+        cond_d = self._f32(cond, device) if (cond is not None and self.conditioned_steps != 0) else None
+        inp = self._f32(inpaint_cond, device)
+        iso = self._f32(initial_state_overwrite, device)
+        with torch.cuda.device(device):
+            _ffi.check(_ffi.lib().cindm_ddpm1d_sample_guided(
+                h, self.model._h, un, C.byref(desc), C.byref(dz), _ffi.ptr(img), _ffi.ptr(cond_d),
+                _ffi.ptr(None if noise is None else noise.step), _ffi.ptr(None if noise is None else noise.recur),
+                C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
+                _ffi.ptr(None if noise is None else noise.cond), _ffi.ptr(iso), 0 if iso is None else iso.shape[1],
+                int(t_start), int(t_end), B, _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+        return img
+
     def _init_state(self, shape, device, noise, seed, sample_offset, tag):
         if noise is not None:
             return self._f32(noise.init, device).clone()
@@ -384,6 +404,12 @@ class GaussianDiffusion1D(nn.Module):
         desc = self._desc_for(full, compose_mode, n_composed, compose_start_step, T1, compose_n_bodies, outside=not inside)
         inpaint = cond if (self.conditioned_steps == 0 and cond is not None) else None
         fast = design_fn is None and "recurrence" not in design_guidance and initial_state_overwrite is None
+        dz = design_fn.descriptor(design_guidance) if isinstance(design_fn, PointObjective) else None
+        if dz is not None and design_fn.last_n_step <= full[1]:
+            # built-in objective: the guided loop (gradient, overwrite, relaxations) stays inside the captured step
+            return self._run_guided_loop(img, cond, desc, dz, self.num_timesteps - 1, t_stop, noise=noise, seed=seed,
+                                         sample_offset=sample_offset, inpaint_cond=inpaint,
+                                         initial_state_overwrite=initial_state_overwrite, use_graph=use_graph)
         if fast:
             return self._run_loop(img, cond, desc, self.num_timesteps - 1, t_stop,
                                   noise_steps=None if noise is None else noise.step, seed=seed, sample_offset=sample_offset,

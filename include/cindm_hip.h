@@ -191,6 +191,38 @@ int  cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* unco
                          int32_t t_start, int32_t t_end, int64_t B,
                          void* ws, size_t ws_bytes, void* stream, int32_t use_graph);
 
+/* Built-in design objective: the paper's point objective (inference/inverse_design_diffusion_1d.py:211-229),
+ *   "L2":       coef * sum_bodies sum_b mean_{last n steps} || pos - target ||_2
+ *   "L2square": coef * sum_bodies sum_b mean_{last n steps} || pos - target ||_2^2
+ *   (+ time_consistency_coef * sum_b mean_l || pos[l+1] - pos[l] ||^2 over the position channels),
+ * whose gradient with respect to the state is evaluated in closed form inside the update kernel. */
+typedef struct {
+    int32_t mode;               /* 1 = "L2", 2 = "L2square" */
+    int32_t alpha;              /* 0: "standard" (gradient as is), 1: "standard-alpha" (x eta_t)   :1243-1248 */
+    int32_t recurrence;         /* 0: non-recurrence branch; N >= 1: "-recurrence-N"                :1284-1370 */
+    int32_t last_n_step;
+    float   coef;
+    float   time_consistency_coef;
+    float   pos_target[2];
+} cindm_design_desc;
+
+/* The reverse loop WITH design guidance by the built-in objective ("standard" / "standard-alpha", optionally
+ * "-recurrence-N"; p_sample :1061-1186, p_sample_compose_inside :1209-1370, p_sample_compose_outside :1406-1652):
+ * per step, max(N, 1) x [ p_mean_variance; pred = mean - [eta_t] grad objective(x); overwrite the first
+ * overwrite_steps rows with initial_state_overwrite [B, overwrite_steps, F] if given; relaxation
+ * x <- sqrt(abar_t/abar_{t-1}) pred + sqrt(1 - abar_t/abar_{t-1}) z' ] with the last iteration's
+ * pred + sigma_t z as the result -- all inside the captured step, no host code in the loop.
+ * recur_noise_steps: NULL (counter-based) or [timesteps, max(N,1), B, L_tot, F] indexed by t. */
+int  cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond,
+                                const cindm_compose_desc* c, const cindm_design_desc* dz, float* x,
+                                const float* cond, const float* noise_steps,
+                                const float* recur_noise_steps, uint64_t seed, int64_t sample_offset,
+                                const float* inpaint_cond, int32_t inpaint_steps,
+                                const float* inpaint_noise_steps,
+                                const float* initial_state_overwrite, int32_t overwrite_steps,
+                                int32_t t_start, int32_t t_end, int64_t B,
+                                void* ws, size_t ws_bytes, void* stream, int32_t use_graph);
+
 /* DDIM loop (ddim_sample, model/diffusion_1d.py:1724-1804, design_fn == None): n_steps updates
  * x <- x0 * sqrt(alpha_next) + c * eps + sigma * z at times[0] > times[1] > ... > times[n_steps]
  * (times[n_steps] == -1: the last update returns x0); times [n_steps + 1] and coefs [n_steps][3] =

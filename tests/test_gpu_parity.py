@@ -362,3 +362,58 @@ def test_ddim_graph_equals_stream_and_shards(device, unet8):
     hi = d.sample(batch_size=32, n_composed=0, seed=7, sample_offset=32)
     assert torch.equal(a[:32], lo) and torch.equal(a[32:], hi)
     assert float(a.abs().max()) <= 1.0 + 1e-5            # the last DDIM step returns the clamped x_start
+
+
+# ------------------------------------------------------------------ built-in design objective (guided loop in the graph)
+BUILTIN_CASES = [("standard", "L2", 0.0, 1, False), ("standard-alpha", "L2square", 0.0, 3, False),
+                 ("standard-recurrence-2", "L2", 0.5, 2, True), ("standard-alpha-recurrence-3", "L2square", 0.0, 1, False),
+                 ("standard-recurrence-1", "L2", 0.0, 1, True)]
+
+
+@pytest.mark.parametrize("guid,mode,tc,n,use_iso", BUILTIN_CASES)
+def test_builtin_objective_step_vs_oracle(device, unet8, diff8, guid, mode, tc, n, use_iso):
+    """One guided reverse step (3 windows, mean-inside) with the built-in objective's closed-form gradient inside the
+    update kernel, against the oracle differentiating the same objective with autograd."""
+    _, sd = unet8
+    od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+    obj = cindm_amd.PointObjective([0.25, -0.5], n, coef=20.0, time_consistency_coef=tc, design_fn_mode=mode)
+    R = int(guid.split("-")[-1]) if "recurrence" in guid else 0
+    g = torch.Generator().manual_seed(21)
+    kw = dict(compose_mode="mean-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2)
+    desc = diff8._desc_for((2, 56, 8), "mean-inside", 2, 16, 24, 2)
+    for t in (600, 30, 0):
+        x = torch.randn((2, 56, 8), generator=g) * 0.7
+        nz = torch.randn((2, 56, 8), generator=g)
+        rn = torch.randn((max(R, 1), 2, 56, 8), generator=g)
+        iso = torch.randn((2, 4, 8), generator=g) * 0.3 if use_iso else None
+        ref, _ = O.p_sample_compose_inside(od, x.clone(), None, t, nz, design_fn=obj, design_guidance=guid,
+                                           recur_noise=rn, initial_state_overwrite=iso, **kw)
+        T = 1000
+        step = torch.zeros((T, 2, 56, 8)); step[t] = nz
+        rec = torch.zeros((T, max(R, 1), 2, 56, 8)); rec[t] = rn
+        tape = cindm_amd.NoiseTape(None, step, rec).to(device)
+        img = x.clone().to(device)
+        out = diff8._run_guided_loop(img, None, desc, obj.descriptor(guid), t, t, noise=tape, seed=0, sample_offset=0,
+                                     inpaint_cond=None, initial_state_overwrite=None if iso is None else iso.to(device))
+        assert rel(out, ref) < TOL_STEP, (guid, t)
+
+
+def test_builtin_objective_chain_equals_autograd_path(device, diff8):
+    """The fast path (closed-form gradient in the graph) and the generic path (PyTorch autograd of the same callable
+    between library calls) produce the same chain."""
+    obj = cindm_amd.PointObjective([0.1, 0.2], 2, coef=5.0, design_fn_mode="L2")
+    tape = O.NoiseTape.make(91, (3, 40, 8), 1000, recur=2)
+    tp = cindm_amd.NoiseTape(tape.init, tape.step, tape.recur)
+    kw = dict(batch_size=3, n_composed=1, compose_start_step=16, compose_mode="mean-inside", design_guidance="standard-recurrence-2",
+              noise=tp, t_stop=985)
+    fast = diff8.sample(design_fn=obj, **kw)
+    slow = diff8.sample(design_fn=lambda x: obj(x), **kw)
+    assert fast.shape == (3, 40, 8)
+    assert rel(fast, slow) < TOL_CHAIN
+    # counter-based noise: graph == stream, and shard independence
+    a = diff8.sample(batch_size=8, n_composed=0, design_fn=obj, design_guidance="standard-alpha-recurrence-2", seed=3, t_stop=990)
+    b = diff8.sample(batch_size=8, n_composed=0, design_fn=obj, design_guidance="standard-alpha-recurrence-2", seed=3, t_stop=990,
+                     use_graph=False)
+    lo = diff8.sample(batch_size=4, n_composed=0, design_fn=obj, design_guidance="standard-alpha-recurrence-2", seed=3, t_stop=990,
+                      sample_offset=4)
+    assert torch.equal(a, b) and torch.equal(a[4:], lo)

@@ -185,3 +185,31 @@ def test_shard_bounds():
                 assert b == c
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_point_objective_closed_form_gradient():
+    """The closed form the update kernel evaluates (built-in objective) against autograd of the callable."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((3, 24, 8), generator=g)
+    for mode, tc, n in (("L2", 0.0, 1), ("L2", 0.7, 4), ("L2square", 0.0, 3), ("L2square", 1.5, 24)):
+        obj = cindm_amd.PointObjective([0.25, -0.5], n, coef=100, time_consistency_coef=tc, design_fn_mode=mode)
+        xc = x.clone().requires_grad_()
+        auto = torch.autograd.grad(obj(xc), xc)[0]
+        want = torch.zeros_like(x)
+        tgt = torch.tensor([0.25, -0.5])
+        for body in range(2):
+            d = x[:, -n:, body * 4:body * 4 + 2] - tgt
+            if mode == "L2":
+                want[:, -n:, body * 4:body * 4 + 2] += 100.0 / n * d / d.norm(dim=-1, keepdim=True)
+            else:
+                want[:, -n:, body * 4:body * 4 + 2] += 100.0 / n * 2 * d
+            if tc > 0:
+                p = x[:, :, body * 4:body * 4 + 2]
+                lap = torch.zeros_like(p)
+                lap[:, 1:] += p[:, 1:] - p[:, :-1]
+                lap[:, :-1] -= p[:, 1:] - p[:, :-1]
+                want[:, :, body * 4:body * 4 + 2] += tc * 2 * lap / 23
+        assert float((auto - want).abs().max()) < 1e-4 * float(want.abs().max()), (mode, tc, n)
+    d = obj.descriptor("standard-alpha-recurrence-5")
+    assert (d.mode, d.alpha, d.recurrence, d.last_n_step) == (2, 1, 5, 24)
+    assert obj.descriptor("universal-forward") is None and obj.descriptor("standard").recurrence == 0
