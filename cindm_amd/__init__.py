@@ -4,6 +4,7 @@ Python face = the reference's class surface (``TemporalUnet1D``, ``GaussianDiffu
 arithmetic runs in ``libcindm_hip.so`` (hand-written HIP kernels, C ABI in include/cindm_hip.h).
 There is no CPU execution path: a missing / unloadable library raises on first use."""
 from ._ffi import CindmError
+from .checkpoint import Trainer
 from .diffusion1d import GaussianDiffusion1D, NoiseTape
 from .diffusion2d import GaussianDiffusion, NoiseTape2D
 from .objectives import PointObjective
@@ -12,4 +13,4 @@ from .unet1d import TemporalUnet1D
 from .unet2d import Unet
 
 __all__ = ["TemporalUnet1D", "GaussianDiffusion1D", "NoiseTape", "Unet", "GaussianDiffusion", "NoiseTape2D",
-           "PointObjective", "make_schedule", "CindmError"]
+           "PointObjective", "Trainer", "make_schedule", "CindmError"]

@@ -213,3 +213,25 @@ def test_point_objective_closed_form_gradient():
     d = obj.descriptor("standard-alpha-recurrence-5")
     assert (d.mode, d.alpha, d.recurrence, d.last_n_step) == (2, 1, 5, 24)
     assert obj.descriptor("universal-forward") is None and obj.descriptor("standard").recurrence == 0
+
+
+def test_trainer_load_shim(tmp_path):
+    """inverse_design_2d.py's Trainer(diffusion, ...).load(milestone) flow (model/diffusion_2d.py:1213-1231)."""
+    m = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21)
+    d = cindm_amd.GaussianDiffusion(m, image_size=64, frames=6, timesteps=1000)
+    sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 5)
+    full = {("model." + k): v for k, v in sd.items()}
+    full.update({k: v.clone() for k, v in d.state_dict().items() if not k.startswith("model.")})
+    assert set(full) == set(d.state_dict())
+    ema = {("ema_model." + k): v * 2 for k, v in full.items()}
+    ema["initted"] = torch.tensor(True)
+    torch.save({"step": 7, "model": full, "ema": ema, "opt": {}, "scaler": None}, tmp_path / "model-3.pt")
+    tr = cindm_amd.Trainer(d, "naca_ellipse", 2, 4, 4, train_batch_size=48, results_folder=str(tmp_path), amp=False)
+    tr.load(3)
+    assert tr.step == 7 and torch.equal(m.state_dict()["init_conv.weight"], sd["init_conv.weight"])
+    tr.load(3, use_ema=True)
+    assert torch.equal(m.state_dict()["init_conv.weight"], sd["init_conv.weight"] * 2)
+    bad = dict(full); bad.pop("model.init_conv.bias")
+    torch.save({"step": 1, "model": bad}, tmp_path / "model-4.pt")
+    with pytest.raises(RuntimeError):
+        tr.load(4)
