@@ -40,6 +40,7 @@ struct Conv2dArgs {
     float* stats_out; int so_gw;        // GroupNorm (mean, M2) partials per tile: [NI][8][tpi][2]
     float* ln_out;                      // LayerNorm partials per pixel and 32-column block: [rows][Npad/32][2]
     const int* t_ptr; int t_imm;
+    int dbg;                            // timing ablations (CINDM_DBG2; results are wrong when set)
 };
 
 __device__ __forceinline__ float silu_f(float x) {
@@ -393,6 +394,63 @@ __global__ __launch_bounds__(256, 2) void conv2d_tile_kernel(const Conv2dArgs a)
     conv2d_epilogue(a, acc, Red, tabE, img, ti, ty0, tx0);
 }
 
+// Epilogue of conv2d_h3_kernel: wave (kg, nh) holds the partial 64 x 32 tile of column half nh over k-group kg.  One
+// LDS round trip: every wave writes its tile, then all 256 threads sum the two k-group partials of BOTH halves (16
+// outputs per thread), add the bias, store, and (optionally) reduce the GroupNorm (mean, M2) partial of the tile.  The
+// 3x3 convolutions never carry the "+ SiLU(GN(y))" / residual / LayerNorm epilogue terms (those ride on 1x1 launches).
+__device__ __forceinline__ void conv2d_h3_epilogue(const Conv2dArgs& a, f32x4 (&acc)[4][2], float (*Red)[T2M * LDR2],
+                                                   int img, int ti, int ty0, int tx0) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR2 + nb * 16 + (lane & 15)] = acc[mb][nb][rg];
+    const int h = tid >> 7, n = tid & 31, rq = (tid >> 5) & 3;          // column half, column, row phase
+    const int gn = nt * T2N + h * 32 + n;
+    const bool nok = gn < a.N;
+    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+    const size_t img_base = (size_t)img * a.Hout * a.Wout;
+    __syncthreads();
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = rq + 4 * q;
+        const float x = (Red[2 * h][r * LDR2 + n] + Red[2 * h + 1][r * LDR2 + n]) + bias;
+        if (nok) a.out[(img_base + (size_t)(ty0 + (r >> 4)) * a.Wout + tx0 + (r & 15)) * a.ldo + gn] = x;
+        v[q] = nok ? x : 0.f;
+    }
+    if (!a.stats_out) return;
+    // GroupNorm partial of the tile per group: shifted sums about a pivot of the group (row 0 of its first column)
+    const int gwt = a.so_gw;                               // 8 or 16
+    __syncthreads();                                       // everyone is done reading the partial tiles
+    if (rq == 0) Red[0][h * 32 + n] = v[0];                // row 0 of every column: the pivots
+    __syncthreads();
+    const float K = Red[0][h * 32 + (n & ~(gwt - 1))];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const float d = v[q] - K; s1 += d; s2 += d * d; }
+    Red[1][(h * 4 + rq) * 32 + n] = s1; Red[2][(h * 4 + rq) * 32 + n] = s2;
+    __syncthreads();
+    if (rq == 0) {
+        s1 = 0.f; s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1 += Red[1][(h * 4 + j) * 32 + n]; s2 += Red[2][(h * 4 + j) * 32 + n]; }
+        s1 = seg_total(s1, gwt);
+        s2 = seg_total(s2, gwt);
+        if ((n & (gwt - 1)) == gwt - 1 && nok) {
+            const float ne = (float)(T2M * gwt);
+            const int g = gn >> (31 - __builtin_clz(gwt));
+            float* o = a.stats_out + (((size_t)img * 8 + g) * a.tpi + ti) * 2;
+            o[0] = K + s1 / ne;
+            o[1] = fmaxf(s2 - s1 * s1 / ne, 0.f);
+        }
+    }
+}
+
 // conv2d_h3_kernel<KIND, MODE>: the 3x3 convolutions (KIND = CONV_3X3 / CONV_UP2) with every fp32 product evaluated on
 // the fp16 matrix cores as the 3-term split of kernels.h (a = ah + 2^-11 al', b likewise; a.b ~ ah.bh + 2^-11 (ah.bl' +
 // al'.bh), fp32 accumulation in two accumulator sets) -- fp32-faithful at 16/3 x the fp32 MFMA rate.  Same 4 x 16 pixel
@@ -527,11 +585,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
     // per-lane fragment byte offset inside a plane: pixel column (lane & 15), this wave's k-group, 8 channels at (lane >> 4) * 8
     const int abase = (lane & 15) * PITCH + kg * 64 + (lane >> 4) * 16;
 
+    if (a.dbg == 1) return;
     __syncthreads();
     store_a(0, 0);
     __syncthreads();
+    if (a.dbg == 2) return;
 
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = 0; ch < (a.dbg == 3 ? 0 : nch); ++ch) {
         const int chn = min(ch + 1, nch - 1);
         load_a(chn);
         const unsigned char* P0 = smem + (size_t)((ch & 1) * 2) * PLANE + abase;
@@ -567,17 +627,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
         __syncthreads();
     }
 
-    // combine the two accumulator sets into the wave's 64 x 32 part of a 64 x 64 tile (other half zero) and reuse the
-    // shared epilogue; the reduce tile aliases the A planes (everyone is past the last __syncthreads of the loop)
-    f32x4 acc[4][4];
+    // combine the two accumulator sets; the reduce tile aliases the A planes (everyone is past the last barrier of the loop)
+    f32x4 acc[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const f32x4 v = accM[mb][nb & 1] + accL[mb][nb & 1] * H3_INV;
-            acc[mb][nb] = ((nb >> 1) == nh) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    conv2d_epilogue(a, acc, reinterpret_cast<float (*)[T2M * LDR2]>(smem), tabE, img, ti, ty0, tx0);
+        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = accM[mb][nb] + accL[mb][nb] * H3_INV;
+    if (a.dbg == 4) { if (acc[0][0][0] == 123.456f) a.out[0] = 1.f; return; }
+    conv2d_h3_epilogue(a, acc, reinterpret_cast<float (*)[T2M * LDR2]>(smem), img, ti, ty0, tx0);
 }
 
 // 7x7 stem (init_conv, :303): input = the padded state (CP = 24 channels, 21 real).  Halo tile 10 x 22 pixels x 24
