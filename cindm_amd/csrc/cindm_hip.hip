@@ -58,6 +58,7 @@ struct cindm_unet1d {
     std::unordered_map<std::string, int> tb_off;        // RTB prefix -> column offset
     bool finalized = false;
     bool use_h3 = true;                    // k=5 convolutions on the fp16 matrix cores (3-term split); CINDM_MFMA=f32 disables
+    bool use_local_gn = true;              // producer-side GroupNorm + Mish where groups are tile-local (CINDM_LOCAL_GN=0 disables)
     int launches = 0;
     // taps of the last forward
     struct Tap { size_t off; int L, C, ld; };
@@ -435,23 +436,47 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
     float* st0 = E.alloc((size_t)Bp * 8 * Pn * 2);
     float* st1 = E.alloc((size_t)Bp * 8 * Pn * 2);
     GemmArgs a;
+    // GroupNorm groups inside one 32-column tile (cout <= 256): the producers normalise + activate their own output
+    const bool local_gn = gw <= TN && h->use_local_gn;
+    auto rc = h->packed.find(p + ".residual_conv");
+    const bool identity = rc == h->packed.end();
     // A
     E.base(a, w0, Bp, L, L);
     Emitter::plain(a.src[0], x0);
     if (x1) { Emitter::plain(a.src[1], *x1); a.nsrc = 2; }
-    a.out = y0.p; a.ldo = y0.ld; a.stats_out = st0; a.so_gw = gw;
+    a.out = y0.p; a.ldo = y0.ld; a.so_gw = gw;
+    if (local_gn) {          // y0 <- Mish(GN(conv(x))) + tbias_t
+        a.act_gamma = E.V(p + ".blocks.0.block.2.weight"); a.act_beta = E.V(p + ".blocks.0.block.2.bias");
+        a.act_tb = h->ttable + h->tb_off.at(p); a.act_tb_ld = h->tb_ld;
+    } else {
+        a.stats_out = st0;
+    }
     E.launch(5, a);
     // B
     E.base(a, w1, Bp, L, L);
     Src& s = a.src[0];
-    s.p = y0.p; s.ld = y0.ld; s.C = cout; s.mode = SRC_GN_MISH; s.stats = st0; s.P = Pn; s.gw = gw; s.cnt = cnt;
-    s.gamma = E.V(p + ".blocks.0.block.2.weight"); s.beta = E.V(p + ".blocks.0.block.2.bias");
-    s.tb = h->ttable + h->tb_off.at(p); s.tb_ld = h->tb_ld;
-    a.out = y1.p; a.ldo = y1.ld; a.stats_out = st1; a.so_gw = gw;
+    if (local_gn) {
+        Emitter::plain(s, y0);
+    } else {
+        s.p = y0.p; s.ld = y0.ld; s.C = cout; s.mode = SRC_GN_MISH; s.stats = st0; s.P = Pn; s.gw = gw; s.cnt = cnt;
+        s.gamma = E.V(p + ".blocks.0.block.2.weight"); s.beta = E.V(p + ".blocks.0.block.2.bias");
+        s.tb = h->ttable + h->tb_off.at(p); s.tb_ld = h->tb_ld;
+    }
+    a.so_gw = gw;
+    if (local_gn && identity) {
+        // out <- Mish(GN(conv(h))) + x: the whole tail of the block in B's epilogue, no third launch
+        a.act_gamma = E.V(p + ".blocks.1.block.2.weight"); a.act_beta = E.V(p + ".blocks.1.block.2.bias");
+        a.res = x0.p; a.ldres = x0.ld;
+        a.out = out.p; a.ldo = out.ld;
+        if (want_ln) { *ln_out = E.alloc((size_t)Bp * L * (ceil_to(cout, TN) / TN) * 2); a.ln_out = *ln_out; }
+        E.launch(5, a);
+        E.tap(p, out);
+        return out;
+    }
+    a.out = y1.p; a.ldo = y1.ld; a.stats_out = st1;
     E.launch(5, a);
     // C
-    auto rc = h->packed.find(p + ".residual_conv");
-    if (rc != h->packed.end()) {
+    if (!identity) {
         E.base(a, rc->second, Bp, L, L);
         Emitter::plain(a.src[0], x0);
         if (x1) { Emitter::plain(a.src[1], *x1); a.nsrc = 2; }
@@ -466,7 +491,7 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
     a.e_gamma = E.V(p + ".blocks.1.block.2.weight"); a.e_beta = E.V(p + ".blocks.1.block.2.bias");
     a.out = out.p; a.ldo = out.ld;
     if (want_ln) { *ln_out = E.alloc((size_t)Bp * L * (ceil_to(cout, TN) / TN) * 2); a.ln_out = *ln_out; }
-    E.launch(rc != h->packed.end() ? 1 : 0, a);
+    E.launch(identity ? 0 : 1, a);
     E.tap(p, out);
     return out;
 }
@@ -602,6 +627,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     {
         const char* e = getenv("CINDM_MFMA");
         h->use_h3 = !(e && std::strcmp(e, "f32") == 0);
+        const char* g = getenv("CINDM_LOCAL_GN");
+        h->use_local_gn = !(g && std::strcmp(g, "0") == 0);
     }
     h->packed.clear(); h->vec_off.clear(); h->tb_off.clear();
     std::vector<RtbDesc> rtbs;

@@ -70,6 +70,10 @@ struct GemmArgs {
     float* stats_out; int so_gw;                         // GN (mean,M2) partials of the output
     float* ln_out;                                       // LN (mean,M2) partials per row & 32-col tile
     const int* t_ptr; int t_imm;                         // timestep (device pointer wins)
+    // producer-side activation (GroupNorm groups that lie inside one 32-column tile, i.e. gw <= 32): the epilogue
+    // normalises its own output tile and stores out = Mish(GN(v) * gamma + beta) [+ tb_t] [+ res] instead of v, so the
+    // consumer stages a plain tensor (the Mish is evaluated once per element, not once per consumer n-tile)
+    const float* act_gamma; const float* act_beta; const float* act_tb; int act_tb_ld;
 };
 
 __device__ __forceinline__ float mish_f(float x) {
@@ -176,18 +180,62 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3]
                 const int ti = (s * 8 + (gn >> (31 - __builtin_clz(a.e_gw)))) * 2;
                 v += mish_f((ey[q] - tabE[ti]) * tabE[ti + 1] * eg + eb);
             }
-            if (a.res) v += rs[q];
-            a.out[grow * a.ldo + gn] = v;
+            if (!a.act_gamma) {
+                if (a.res) v += rs[q];
+                a.out[grow * a.ldo + gn] = v;
+            }
         } else {
             v = 0.f;
         }
         Red[0][r * LDR + n] = v;     // finished tile kept for the statistics passes (own slot only)
     }
 
-    if (skip_stats) return;                     // DBG 8: no statistics passes
-    if (a.stats_out || a.ln_out) __syncthreads();
+    if (a.act_gamma) {
+        // ---- producer-side GroupNorm + Mish on the tile (whole (sample, group) sets are inside it) ----
+        __syncthreads();
+        const int gwt = a.so_gw;                       // <= 32 (host guarantees)
+        const int gpt = TN / gwt;                      // groups per tile
+        float* tabS = &Red[1][0];                      // [sample in tile][group in tile] (mean, rstd)
+        const float ne = (float)(a.Lout * gwt), inv_ne = 1.0f / ne;
+        for (int sidx = rq; sidx < a.spt; sidx += 8) {
+            const float* col = &Red[0][sidx * a.Lout * LDR + n];
+            const float K = Red[0][sidx * a.Lout * LDR + (n & ~(gwt - 1))];
+            float s1 = 0.f, s2 = 0.f;
+            for (int l = 0; l < a.Lout; ++l) { const float d = col[l * LDR] - K; s1 += d; s2 += d * d; }
+            s1 = seg_total(s1, gwt);
+            s2 = seg_total(s2, gwt);
+            if ((n & (gwt - 1)) == gwt - 1) {
+                const float mean = K + s1 * inv_ne;
+                const float M2 = fmaxf(s2 - s1 * s1 * inv_ne, 0.f);
+                float* o = tabS + (sidx * gpt + (n >> (31 - __builtin_clz(gwt)))) * 2;
+                o[0] = mean; o[1] = 1.0f / sqrtf(M2 / ne + 1e-5f);
+            }
+        }
+        __syncthreads();
+        const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+        const float ag = nok ? a.act_gamma[gn] : 1.f, ab = nok ? a.act_beta[gn] : 0.f;
+        const float atb = (a.act_tb && nok) ? a.act_tb[(size_t)t_now * a.act_tb_ld + gn] : 0.f;
+        const int gi = n >> (31 - __builtin_clz(gwt));
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int r = rq + 8 * q;
+            float y = 0.f;
+            if (r < rows_out && nok) {
+                const int sl = (r * a.lout_magic) >> 16;
+                const float m = tabS[(sl * gpt + gi) * 2], rs2 = tabS[(sl * gpt + gi) * 2 + 1];
+                y = mish_f((Red[0][r * LDR + n] - m) * rs2 * ag + ab) + atb;
+                if (a.res) y += rs[q];
+                a.out[((size_t)b0 * a.Lout + r) * a.ldo + gn] = y;
+            }
+            Red[0][r * LDR + n] = y;
+        }
+        if (a.ln_out) __syncthreads();
+    } else {
+        if (skip_stats) return;                     // DBG 8: no statistics passes
+        if (a.stats_out || a.ln_out) __syncthreads();
+    }
 
-    if (a.stats_out) {
+    if (a.stats_out && !a.act_gamma) {
         // GroupNorm partial statistics of the output tile: (mean, M2) per (sample, group or 32-column part of it).
         // Thread (n = tid & 31, rq = tid >> 5) accumulates column n over the rows of samples rq, rq + 8, ... as sums
         // of (x - K) and (x - K)^2 around a pivot K taken from the data (one pass, no cancellation); the gwt columns
