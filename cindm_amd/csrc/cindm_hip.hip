@@ -250,6 +250,43 @@ static void pack_weight_h3(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
     h->packed[prefix] = pk;
 }
 
+// residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
+// [q = nb*2 + plane][thread][8 halfs], channel mapping identical to the k=5 convolution that shares its staged rows
+static void pack_weight_h3_res(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int split) {
+    const Param& w = P(h, prefix + ".weight");
+    const int Co = (int)w.shape[0], Ci = (int)w.shape[1];
+    const int KC = 128;
+    const int C0 = split ? split : Ci, C1 = Ci - C0;
+    const int C0p = ceil_to(C0, KC), C1p = C1 ? ceil_to(C1, KC) : 0;
+    Packed pk; pk.T = 1; pk.CinP = C0p + C1p; pk.Npad = ceil_to(Co, TN); pk.N = Co; pk.KC = KC; pk.h3 = true;
+    const int nch = pk.CinP / KC;
+    const size_t halfs = (size_t)(pk.Npad / TN) * nch * 4 * 256 * 8;
+    pk.off = bb.alloc(halfs / 2);
+    uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
+    auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
+    for (int nt = 0; nt < pk.Npad / TN; ++nt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int nb = 0; nb < 2; ++nb)
+                for (int tid = 0; tid < 256; ++tid) {
+                    const int wv = tid >> 6, lane = tid & 63;
+                    const int n = nt * TN + nb * 16 + (lane & 15);
+                    for (int e = 0; e < 8; ++e) {
+                        const int cp = ch * KC + wv * 32 + (lane >> 4) * 8 + e;
+                        int c = -1;
+                        if (cp < C0) c = cp;
+                        else if (cp >= C0p && cp - C0p < C1) c = C0 + (cp - C0p);
+                        const float v = (c >= 0 && n < Co) ? w.host[(size_t)n * Ci + c] : 0.f;
+                        const _Float16 hv = (_Float16)v;
+                        const float lo = (v - (float)hv) * 2048.0f;
+                        const size_t q0 = ((size_t)(nt * nch + ch) * 4 + nb * 2) * 256;
+                        base[((q0 + tid) * 8) + e] = bits((float)hv);
+                        base[((q0 + 256 + tid) * 8) + e] = bits(lo);
+                    }
+                }
+    pack_bias(h, bb, prefix, pk, Co);
+    h->packed[prefix + "#h3"] = pk;
+}
+
 static void pack_weight(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int kind, int split) {
     const Param& w = P(h, prefix + ".weight");
     int Co, Ci, K;
@@ -373,7 +410,8 @@ struct Emitter {
         for (int rep = 0; rep < (prof ? prof_reps : 1); ++rep) {
         static const int dbg_h3 = getenv("CINDM_DBG") ? atoi(getenv("CINDM_DBG")) : 0;
         const_cast<GemmArgs&>(a).dbg = a.h3 ? dbg_h3 : 0;
-        if (a.h3 && T == 5 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
+        if (a.h3 && T == 5 && mode == SRC_PLAIN && a.W2) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, true>), grid, dim3(256), 0, stream, a);
+        else if (a.h3 && T == 5 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
         else if (a.h3 && T == 5 && mode == SRC_GN_MISH) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_GN_MISH>), grid, dim3(256), 0, stream, a);
         else if (a.h3) ok = false;
         else if (T == 0) CINDM_LAUNCH(0, 32, 48, SRC_PLAIN);
@@ -440,11 +478,19 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
     const bool local_gn = gw <= TN && h->use_local_gn;
     auto rc = h->packed.find(p + ".residual_conv");
     const bool identity = rc == h->packed.end();
+    // the 1x1 residual_conv rides on launch A's centre tap (split-fp16 kernel only): r = Wr . x + br
+    auto rc3 = h->packed.find(p + ".residual_conv#h3");
+    const bool fused_res = !identity && rc3 != h->packed.end() && w0.h3;
+    Ten r;
+    if (fused_res) r = E.ten(L, cout);
     // A
     E.base(a, w0, Bp, L, L);
     Emitter::plain(a.src[0], x0);
     if (x1) { Emitter::plain(a.src[1], *x1); a.nsrc = 2; }
     a.out = y0.p; a.ldo = y0.ld; a.so_gw = gw;
+    if (fused_res) {
+        a.W2 = E.W(rc3->second); a.bias2 = E.B(rc3->second); a.out2 = r.p; a.ldo2 = r.ld;
+    }
     if (local_gn) {          // y0 <- Mish(GN(conv(x))) + tbias_t
         a.act_gamma = E.V(p + ".blocks.0.block.2.weight"); a.act_beta = E.V(p + ".blocks.0.block.2.bias");
         a.act_tb = h->ttable + h->tb_off.at(p); a.act_tb_ld = h->tb_ld;
@@ -463,10 +509,10 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
         s.tb = h->ttable + h->tb_off.at(p); s.tb_ld = h->tb_ld;
     }
     a.so_gw = gw;
-    if (local_gn && identity) {
-        // out <- Mish(GN(conv(h))) + x: the whole tail of the block in B's epilogue, no third launch
+    if (local_gn && (identity || fused_res)) {
+        // out <- Mish(GN(conv(h))) + (x | r): the whole tail of the block in B's epilogue, no third launch
         a.act_gamma = E.V(p + ".blocks.1.block.2.weight"); a.act_beta = E.V(p + ".blocks.1.block.2.bias");
-        a.res = x0.p; a.ldres = x0.ld;
+        if (identity) { a.res = x0.p; a.ldres = x0.ld; } else { a.res = r.p; a.ldres = r.ld; }
         a.out = out.p; a.ldo = out.ld;
         if (want_ln) { *ln_out = E.alloc((size_t)Bp * L * (ceil_to(cout, TN) / TN) * 2); a.ln_out = *ln_out; }
         E.launch(5, a);
@@ -476,7 +522,7 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
     a.out = y1.p; a.ldo = y1.ld; a.stats_out = st1;
     E.launch(5, a);
     // C
-    if (!identity) {
+    if (!identity && !fused_res) {
         E.base(a, rc->second, Bp, L, L);
         Emitter::plain(a.src[0], x0);
         if (x1) { Emitter::plain(a.src[1], *x1); a.nsrc = 2; }
@@ -485,13 +531,13 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
         E.base(a, none, Bp, L, L);
         a.W = nullptr; a.bias = nullptr; a.pad = 0;
         Emitter::plain(a.src[0], x0);
-        a.res = x0.p; a.ldres = x0.ld;
+        if (identity) { a.res = x0.p; a.ldres = x0.ld; } else { a.res = r.p; a.ldres = r.ld; }
     }
     a.e_y = y1.p; a.e_ld = y1.ld; a.e_stats = st1; a.e_P = Pn; a.e_gw = gw; a.e_cnt = cnt;
     a.e_gamma = E.V(p + ".blocks.1.block.2.weight"); a.e_beta = E.V(p + ".blocks.1.block.2.bias");
     a.out = out.p; a.ldo = out.ld;
     if (want_ln) { *ln_out = E.alloc((size_t)Bp * L * (ceil_to(cout, TN) / TN) * 2); a.ln_out = *ln_out; }
-    E.launch(identity ? 0 : 1, a);
+    E.launch((identity || fused_res) ? 0 : 1, a);
     E.tap(p, out);
     return out;
 }
@@ -644,6 +690,7 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         } else if (ends(".residual_conv.weight")) {
             int split = (k.rfind("ups.", 0) == 0 && k.find(".0.residual_conv") != std::string::npos) ? (int)p.shape[1] / 2 : 0;
             pack_weight(h, bb, k.substr(0, k.size() - 7), 0, split);
+            if (h->use_h3 && h->use_local_gn) pack_weight_h3_res(h, bb, k.substr(0, k.size() - 7), split);
         } else if (ends(".3.conv.weight")) {
             pack_weight(h, bb, k.substr(0, k.size() - 7), k.rfind("ups.", 0) == 0 ? 1 : 0, 0);
         } else if (ends("to_qkv.weight") || ends("to_out.weight") || k == "final_conv.1.weight") {

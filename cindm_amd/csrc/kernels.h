@@ -74,6 +74,9 @@ struct GemmArgs {
     // normalises its own output tile and stores out = Mish(GN(v) * gamma + beta) [+ tb_t] [+ res] instead of v, so the
     // consumer stages a plain tensor (the Mish is evaluated once per element, not once per consumer n-tile)
     const float* act_gamma; const float* act_beta; const float* act_tb; int act_tb_ld;
+    // second GEMM riding on the centre tap of a k=5 convolution (the block's 1x1 residual_conv reads the same staged
+    // rows): out2 = W2 . x + bias2; W2 packed as split fp16 [n-tile][stage][q = nb*2 + plane][thread][8 halfs]
+    const float* W2; const float* bias2; float* out2; int ldo2;
 };
 
 __device__ __forceinline__ float mish_f(float x) {
@@ -532,7 +535,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
 
-template <int T, int ROWS, int MODE>
+template <int T, int ROWS, int MODE, bool RES = false>
 __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     constexpr int KC = 128;
     constexpr int PITCH = 272;              // bytes per LDS row per plane: 128 halfs + 16 B pad
@@ -612,6 +615,22 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     };
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
+    // optional second GEMM on the centre tap (residual_conv): its own fragments and accumulators
+    half8 rreg[2][2];
+    f32x4 accRM[3][2], accRL[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accRM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accRL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const uint4* rbase = reinterpret_cast<const uint4*>(a.W2) + (size_t)nt * nch * 4 * 256 + tid;
+    auto load_r = [&](int ch) {
+        if constexpr (RES) {
+            const uint4* wp = rbase + (size_t)ch * 4 * 256;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rreg[q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+        }
+    };
+    load_r(0);
     load_a(0);
 
     for (int i = tid; i < 4 * (PITCH / 4); i += 256)
@@ -730,6 +749,17 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
                     accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], breg[tap][nb][1], accL[mb][nb], 0, 0, 0);
                     accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], breg[tap][nb][0], accL[mb][nb], 0, 0, 0);
                 }
+            if constexpr (RES) if (tap == T / 2) {     // the 1x1 residual_conv on the same (centre-tap) rows
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        accRM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], rreg[nb][0], accRM[mb][nb], 0, 0, 0);
+                        accRL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], rreg[nb][1], accRL[mb][nb], 0, 0, 0);
+                        accRL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], rreg[nb][0], accRL[mb][nb], 0, 0, 0);
+                    }
+                load_r(chn);
+            }
             load_b_tap(chn, tap);          // next stage's fragments for this tap, T-1 taps ahead of their use
         }
         // (staging the next stage's rows in per-tap slices was measured: no faster, and one build of it was flaky)
@@ -744,6 +774,18 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
         for (int j = 0; j < 2; ++j) acc[i][j] = accM[i][j] + accL[i][j] * H3_INV;
     if (a.dbg == 9) { if (acc[0][0][0] == 123.456f) a.out[0] = 1.f; return; }      // no epilogue
     gemm_epilogue<true>(a, acc, Red, tabE, a.dbg == 8);
+    if constexpr (RES) {
+        // second output: out2 = W2 . x + bias2 (plain epilogue: reduce, bias, store)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = accRM[i][j] + accRL[i][j] * H3_INV;
+        GemmArgs a2 = a;
+        a2.out = a.out2; a2.ldo = a.ldo2; a2.bias = a.bias2;
+        a2.act_gamma = nullptr; a2.stats_out = nullptr; a2.ln_out = nullptr; a2.e_y = nullptr; a2.res = nullptr;
+        __syncthreads();
+        gemm_epilogue<true>(a2, acc, Red, tabE, true);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
