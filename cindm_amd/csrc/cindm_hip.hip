@@ -399,7 +399,8 @@ struct Emitter {
         {
             const double cin = (double)a.src[0].C + (a.nsrc > 1 ? (double)a.src[1].C : 0.0);
             const double taps = a.transposed ? T * 0.5 : (double)T;          // algorithmic: 2 of 4 taps hit per output
-            prof_begin(T == 0 ? 0 : T == 1 ? 1 : T == 3 ? 2 : T == 4 ? 3 : 4, 2.0 * a.Bp * a.Lout * a.N * cin * taps);
+            // (+ the residual_conv that rides on the centre tap of a k=5 launch: one more tap's worth of products)
+            prof_begin(T == 0 ? 0 : T == 1 ? 1 : T == 3 ? 2 : T == 4 ? 3 : 4, 2.0 * a.Bp * a.Lout * a.N * cin * (taps + (a.W2 ? 1.0 : 0.0)));
             if (prof && !dry) { prof->back().gx = grid.x; prof->back().gy = grid.y; prof->back().nstage = T ? a.CinP / a.KC : 0; }
         }
         const int mode = a.src[0].mode;
