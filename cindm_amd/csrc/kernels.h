@@ -804,22 +804,36 @@ __global__ __launch_bounds__(256) void linattn_core_kernel(const float* __restri
     const size_t row0 = (size_t)blockIdx.x * L;
     const int d = lane & 31, half = lane >> 5;
     const float scale = 0.17677669529663687f;      // 32 ** -0.5
-    for (int n = half; n < L; n += 2) {
-        const float* p = qkv + (row0 + n) * 384 + h * 32 + d;
-        q[n * 32 + d] = p[0] * scale;
-        k[n * 32 + d] = p[128];
-        v[n * 32 + d] = p[256];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __syncthreads();
-    // softmax over positions n for channel d (both halves compute redundantly -> no cross-lane traffic)
+    // each lane owns channel d of rows n = half, half + 2, ...: all loads issued up front, k kept in registers
+    constexpr int MAXH = ATT_MAXL / 2;
+    float kv[MAXH];
     float mx = -INFINITY;
-    for (int n = 0; n < L; ++n) mx = fmaxf(mx, k[n * 32 + d]);
+#pragma unroll
+    for (int j = 0; j < MAXH; ++j) {
+        const int n = half + 2 * j;
+        kv[j] = -INFINITY;
+        if (n < L) {
+            const float* p = qkv + (row0 + n) * 384 + h * 32 + d;
+            q[n * 32 + d] = p[0] * scale;
+            kv[j] = p[128];
+            v[n * 32 + d] = p[256];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXH; ++j) mx = fmaxf(mx, kv[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // softmax over positions: both halves of the wave hold channel d
     float sum = 0.f;
-    for (int n = 0; n < L; ++n) sum += expf(k[n * 32 + d] - mx);
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXH; ++j) {
+        const int n = half + 2 * j;
+        if (n < L) {
+            const float e = __builtin_amdgcn_exp2f((kv[j] - mx) * 1.4426950408889634f);
+            k[n * 32 + d] = e;                         // unnormalised; 1 / sum is folded into the context rows below
+            sum += e;
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    for (int n = half; n < L; n += 2) k[n * 32 + d] = expf(k[n * 32 + d] - mx) * inv;
     __syncthreads();
     // ctx[d][e], e in [half*16, half*16+16)
     float c[16];
@@ -830,6 +844,8 @@ __global__ __launch_bounds__(256) void linattn_core_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) c[j] += kk * v[n * 32 + half * 16 + j];
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] *= inv;
 #pragma unroll
     for (int j = 0; j < 16; ++j) ctx[d * 33 + half * 16 + j] = c[j];
     __syncthreads();
