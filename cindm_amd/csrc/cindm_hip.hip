@@ -59,6 +59,7 @@ struct cindm_unet1d {
     bool finalized = false;
     bool use_h3 = true;                    // k=5 convolutions on the fp16 matrix cores (3-term split); CINDM_MFMA=f32 disables
     bool use_local_gn = true;              // producer-side GroupNorm + Mish where groups are tile-local (CINDM_LOCAL_GN=0 disables)
+    bool use_wide_qkv = true;              // shallow-level qkv projections on conv1x1_wide_kernel (CINDM_WIDE_QKV=0 disables)
     int launches = 0;
     // taps of the last forward
     struct Tap { size_t off; int L, C, ld; };
@@ -248,6 +249,27 @@ static void pack_weight_h3(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
                     }
     pack_bias(h, bb, prefix, pk, Co);
     h->packed[prefix] = pk;
+}
+
+// to_qkv (1x1, no bias) of the shallow levels (C = 64 / 128) in conv1x1_wide_kernel's fragment layout:
+// [n-tile of 64][q = k-step / 4][thread = wave*64 + lane][4 k-steps], W[n = tile*64 + wave*16 + (lane & 15)][k = 4*(4q+j) + (lane >> 4)]
+static void pack_weight_wide(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix) {
+    const Param& w = P(h, prefix + ".weight");
+    const int Co = (int)w.shape[0], Ci = (int)w.shape[1];
+    if (Ci != 64 && Ci != 128) return;
+    Packed pk; pk.T = 1; pk.CinP = Ci; pk.Npad = ceil_to(Co, 64); pk.N = Co; pk.KC = Ci;
+    const int NQ = Ci / 16;
+    pk.off = bb.alloc((size_t)(pk.Npad / 64) * NQ * 256 * 4);
+    float* base = bb.data.data() + pk.off;
+    for (int it = 0; it < pk.Npad / 64; ++it)
+        for (int q = 0; q < NQ; ++q)
+            for (int tid = 0; tid < 256; ++tid)
+                for (int j = 0; j < 4; ++j) {
+                    const int wv = tid >> 6, lane = tid & 63;
+                    const int n = it * 64 + wv * 16 + (lane & 15), k = 4 * (4 * q + j) + (lane >> 4);
+                    base[(((size_t)it * NQ + q) * 256 + tid) * 4 + j] = (n < Co) ? w.host[(size_t)n * Ci + k] : 0.f;
+                }
+    h->packed[prefix + "#wide"] = pk;
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -554,12 +576,41 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
     const Packed& wo = h->packed.at(p + ".fn.fn.to_out");
     Ten qkv = E.ten(L, 384), att = E.ten(L, 128), out = E.ten(L, C);
     GemmArgs a;
-    E.base(a, wq, Bp, L, L);
-    Src& s = a.src[0];
-    s.p = x.p; s.ld = x.ld; s.C = C; s.mode = SRC_LN; s.stats = lnp; s.P = ceil_to(C, TN) / TN; s.cnt = (float)TN; s.gw = 1;
-    s.gamma = E.V(p + ".fn.norm.g");
-    a.out = qkv.p; a.ldo = qkv.ld;
-    E.launch(1, a);
+    auto wide = h->packed.find(p + ".fn.fn.to_qkv#wide");
+    if (wide != h->packed.end()) {
+        // shallow levels (C = 64 / 128): 64-row tiles, the LayerNorm-ed input tile staged once per workgroup and its
+        // fragments kept in registers over a group of output tiles (the 2-D path's projection kernel on [rows, C])
+        ++E.launches;
+        if (!E.dry) {
+            const int64_t rows = (int64_t)Bp * L;
+            Conv2dArgs c2;
+            std::memset(&c2, 0, sizeof(c2));
+            Src& s2 = c2.src[0];
+            s2.p = x.p; s2.ld = x.ld; s2.C = C; s2.mode = SRC2_LN; s2.stats = lnp; s2.P = ceil_to(C, TN) / TN; s2.cnt = (float)TN; s2.gw = 1;
+            s2.gamma = E.V(p + ".fn.norm.g");
+            c2.nsrc = 1; c2.W = E.W(wide->second); c2.CinP = C; c2.Npad = wide->second.Npad; c2.N = 384;
+            c2.out = qkv.p; c2.ldo = qkv.ld; c2.rows_total = rows;
+            const int mt = (int)((rows + 63) / 64);
+            const int ntile = c2.Npad / 64;                      // 6
+            int groups = 1;
+            for (int g : {1, 2, 3, 6}) { groups = g; if (mt * g >= 256) break; }       // enough workgroups to fill the chip
+            c2.tiles_per_group = ntile / groups;
+            const dim3 g1((unsigned)mt, (unsigned)groups);
+            E.prof_begin(1, 2.0 * rows * 384.0 * C);
+            for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
+                if (C == 64) hipLaunchKernelGGL((conv1x1_wide_kernel<64, SRC2_LN, true, false>), g1, dim3(256), 0, E.stream, c2);
+                else hipLaunchKernelGGL((conv1x1_wide_kernel<128, SRC2_LN, true, false>), g1, dim3(256), 0, E.stream, c2);
+            }
+            E.prof_end();
+        }
+    } else {
+        E.base(a, wq, Bp, L, L);
+        Src& s = a.src[0];
+        s.p = x.p; s.ld = x.ld; s.C = C; s.mode = SRC_LN; s.stats = lnp; s.P = ceil_to(C, TN) / TN; s.cnt = (float)TN; s.gw = 1;
+        s.gamma = E.V(p + ".fn.norm.g");
+        a.out = qkv.p; a.ldo = qkv.ld;
+        E.launch(1, a);
+    }
     ++E.launches;
     if (!E.dry) {
         const size_t shm = 4 * (size_t)(3 * L * 32 + 32 * 33) * sizeof(float);
@@ -676,6 +727,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         h->use_h3 = !(e && std::strcmp(e, "f32") == 0);
         const char* g = getenv("CINDM_LOCAL_GN");
         h->use_local_gn = !(g && std::strcmp(g, "0") == 0);
+        const char* wq = getenv("CINDM_WIDE_QKV");
+        h->use_wide_qkv = !(wq && std::strcmp(wq, "0") == 0);
     }
     h->packed.clear(); h->vec_off.clear(); h->tb_off.clear();
     std::vector<RtbDesc> rtbs;
@@ -696,6 +749,7 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
             pack_weight(h, bb, k.substr(0, k.size() - 7), k.rfind("ups.", 0) == 0 ? 1 : 0, 0);
         } else if (ends("to_qkv.weight") || ends("to_out.weight") || k == "final_conv.1.weight") {
             pack_weight(h, bb, k.substr(0, k.size() - 7), 0, 0);
+            if (ends("to_qkv.weight") && h->use_wide_qkv) pack_weight_wide(h, bb, k.substr(0, k.size() - 7));
         } else if (ends("time_mlp.1.weight") || k == "time_mlp.3.weight") {
             pack_weight(h, bb, k.substr(0, k.size() - 7), 2, 0);
             if (k != "time_mlp.1.weight" && k != "time_mlp.3.weight") {

@@ -41,6 +41,9 @@ struct Conv2dArgs {
     float* ln_out;                      // LayerNorm partials per pixel and 32-column block: [rows][Npad/32][2]
     const int* t_ptr; int t_imm;
     int dbg;                            // timing ablations (CINDM_DBG2; results are wrong when set)
+    // conv1x1_wide_kernel only: rows = pixels (2-D) or sequence positions (the 1-D path's qkv projections); blockIdx.y
+    // selects a group of tiles_per_group output tiles (0 = all tiles in one workgroup)
+    int64_t rows_total; int tiles_per_group;
 };
 
 __device__ __forceinline__ float silu_f(float x) {
@@ -737,6 +740,8 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
     const int img = (int)(row0 / HWo);
     const Src& s0 = a.src[0];
     const int ntile = a.Npad / T2N;
+    const int tpg = a.tiles_per_group > 0 ? a.tiles_per_group : ntile;
+    const int it_lo = blockIdx.y * tpg, it_hi = min(ntile, it_lo + tpg);
     const float4* wbase = reinterpret_cast<const float4*>(a.W) + tid;
     float4 wA[NQ], wB[NQ];
     auto load_w = [&](int it, float4 (&wv)[NQ]) {
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             for (int q = 0; q < NQ; ++q) wv[q] = wbase[((size_t)it * NQ + q) * 256];
         }
     };
-    load_w(0, wA);
+    load_w(it_lo, wA);
     if constexpr (EPI) {
         if (a.e_y && tid >= 64 && tid < 72) {
             float m, r;
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             const Src& s = first ? a.src[0] : a.src[1];
             const int cs = first ? cl : cl - s0.C;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cs < s.C) {
+            if (cs < s.C && (int64_t)(row0 + r) < a.rows_total) {
                 v = *reinterpret_cast<const float4*>(s.p + (row0 + r) * s.ld + cs);
                 if constexpr (MODE == SRC2_LN) {
                     const float4 pg = *reinterpret_cast<const float4*>(s.gamma + cs);
@@ -815,8 +820,9 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             if (a.dbg == 5) { if (acc[0][0] == 123.456f) a.out[0] = 1.f; return; }
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb)
-                *reinterpret_cast<float4*>(a.out + (row0 + pb * 16 + lq) * a.ldo + col) =
-                    make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]);
+                if ((int64_t)(row0 + pb * 16 + lq) < a.rows_total)
+                    *reinterpret_cast<float4*>(a.out + (row0 + pb * 16 + lq) * a.ldo + col) =
+                        make_float4(acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]);
             return;
         }
         float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -864,13 +870,13 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             }
         }
     };
-    for (int it = 0; it < ntile; it += 2) {
-        load_w(min(it + 1, ntile - 1), wB);
+    for (int it = it_lo; it < it_hi; it += 2) {
+        load_w(min(it + 1, it_hi - 1), wB);
         __builtin_amdgcn_sched_barrier(0);
         tile(it, wA);
-        load_w(min(it + 2, ntile - 1), wA);
+        load_w(min(it + 2, it_hi - 1), wA);
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < ntile) tile(it + 1, wB);
+        if (it + 1 < it_hi) tile(it + 1, wB);
     }
 }
 
