@@ -3,7 +3,8 @@
 //
 // Layout: channel-last fp32 [image, y, x, C] = rows (image*H*W + y*W + x) x C.
 //
-// conv2d_tile_kernel<KIND, MODE>: implicit-GEMM Conv2d on fp32 MFMA (v_mfma_f32_16x16x4_f32).  One workgroup =
+// conv2d_tile_kernel<KIND, MODE>: implicit-GEMM Conv2d on fp32 MFMA (v_mfma_f32_16x16x4_f32) -- the pixel-unshuffle
+// 1x1 and, with CINDM_MFMA=f32, the 3x3 convolutions (default: conv2d_h3_kernel below).  One workgroup =
 // a 4 x 16 pixel tile of one image x 64 output channels; K (input channels x taps) is split over the 4 waves inside
 // every 32/64-channel chunk and reduced through LDS once at the end; B fragments come straight from L2 in fragment
 // order; the A halo tile ((4+2) x (16+2) pixels for 3x3) is staged through LDS with normalise-on-load, image borders
