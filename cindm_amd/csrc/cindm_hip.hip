@@ -599,7 +599,8 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             E.prof_begin(1, 2.0 * rows * 384.0 * C);
             for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
                 if (C == 64) hipLaunchKernelGGL((conv1x1_wide_kernel<64, SRC2_LN, true, false>), g1, dim3(256), 0, E.stream, c2);
-                else hipLaunchKernelGGL((conv1x1_wide_kernel<128, SRC2_LN, true, false>), g1, dim3(256), 0, E.stream, c2);
+                else if (c2.tiles_per_group >= 3) hipLaunchKernelGGL((conv1x1_wide_kernel<128, SRC2_LN, true, false>), g1, dim3(256), 0, E.stream, c2);
+                else hipLaunchKernelGGL((conv1x1_wide_kernel<128, SRC2_LN, false, false>), g1, dim3(256), 0, E.stream, c2);
             }
             E.prof_end();
         }

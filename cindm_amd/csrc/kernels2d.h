@@ -759,22 +759,42 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             tabE[2 * (tid - 64)] = m; tabE[2 * (tid - 64) + 1] = r;
         }
     }
+    // staging: all global loads first (registers), then -- LayerNorm mode -- one statistics merge per row into an LDS
+    // table, then normalise + store
+    __shared__ float tabL[128];
+    float4 sv[NPASS];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int i = tid + 256 * p;
         const int r = i / F4, c4 = i - r * F4;
+        sv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < 64 * F4) {
             const int cl = c4 * 4;
             const bool first = cl < s0.C || a.nsrc == 1;
             const Src& s = first ? a.src[0] : a.src[1];
             const int cs = first ? cl : cl - s0.C;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cs < s.C && (int64_t)(row0 + r) < a.rows_total) {
-                v = *reinterpret_cast<const float4*>(s.p + (row0 + r) * s.ld + cs);
-                if constexpr (MODE == SRC2_LN) {
-                    const float4 pg = *reinterpret_cast<const float4*>(s.gamma + cs);
-                    float mean, rstd;
-                    merge_stats(s.stats + (row0 + r) * s.P * 2, s.P, s.cnt, 1e-5f, mean, rstd);
+            if (cs < s.C && (int64_t)(row0 + r) < a.rows_total) sv[p] = *reinterpret_cast<const float4*>(s.p + (row0 + r) * s.ld + cs);
+        }
+    }
+    if constexpr (MODE == SRC2_LN) {
+        if (tid < 64) {
+            float mean = 0.f, rstd = 0.f;
+            if ((int64_t)(row0 + tid) < a.rows_total) merge_stats(s0.stats + (row0 + tid) * s0.P * 2, s0.P, s0.cnt, 1e-5f, mean, rstd);
+            tabL[2 * tid] = mean; tabL[2 * tid + 1] = rstd;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int i = tid + 256 * p;
+        const int r = i / F4, c4 = i - r * F4;
+        if (i < 64 * F4) {
+            float4 v = sv[p];
+            if constexpr (MODE == SRC2_LN) {
+                const int cl = c4 * 4;
+                if (cl < s0.C) {
+                    const float4 pg = *reinterpret_cast<const float4*>(s0.gamma + cl);
+                    const float mean = tabL[2 * r], rstd = tabL[2 * r + 1];
                     v.x = (v.x - mean) * rstd * pg.x; v.y = (v.y - mean) * rstd * pg.y;
                     v.z = (v.z - mean) * rstd * pg.z; v.w = (v.w - mean) * rstd * pg.w;
                 }
