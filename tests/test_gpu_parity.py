@@ -417,3 +417,22 @@ def test_builtin_objective_chain_equals_autograd_path(device, diff8):
     lo = diff8.sample(batch_size=4, n_composed=0, design_fn=obj, design_guidance="standard-alpha-recurrence-2", seed=3, t_stop=990,
                       sample_offset=4)
     assert torch.equal(a, b) and torch.equal(a[4:], lo)
+
+
+def test_builtin_objective_paper_configuration(device, unet8, diff8):
+    """The shape scripts_paper/1D/cindm.sh runs (Table 2): 4 bodies, 3 windows (cs = 10), mean-inside, "L2" objective with a
+    time-consistency term, initial-state overwrite, standard-recurrence-N -- two reverse steps against the oracle."""
+    _, sd = unet8
+    od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+    obj = cindm_amd.PointObjective([0.3, -0.2], 1, coef=0.2, time_consistency_coef=0.2, design_fn_mode="L2")
+    g = torch.Generator().manual_seed(33)
+    B, Lt, F = 2, 44, 16
+    iso = torch.randn((B, 4, F), generator=g) * 0.2
+    tape = O.NoiseTape.make(44, (B, Lt, F), 1000, recur=2)
+    kw = dict(n_composed=2, compose_start_step=10, compose_n_bodies=4, compose_mode="mean-inside",
+              design_guidance="standard-recurrence-2", initial_state_overwrite=iso)
+    ref = O.p_sample_loop(od, (B, 24, F), None, tape, design_fn=obj, t_stop=998, **kw)
+    out = diff8.sample(batch_size=B, design_fn=obj, noise=cindm_amd.NoiseTape(tape.init, tape.step, tape.recur), t_stop=998,
+                       **{**kw, "initial_state_overwrite": iso.to(device)})
+    assert out.shape == (B, Lt, F)
+    assert rel(out, ref) < TOL_STEP * 2
