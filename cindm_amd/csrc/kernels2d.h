@@ -872,8 +872,12 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
                 const float4 r4 = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + col);
                 v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
             }
-            if (full) *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
-            else { a.out[prow * a.ldo + col] = v.x; if (col + 1 < a.N) a.out[prow * a.ldo + col + 1] = v.y; if (col + 2 < a.N) a.out[prow * a.ldo + col + 2] = v.z; }
+            if (!full) {          // the row pitch is N rounded up to 4 (host): the padding channels are written as zeros
+                if (col + 1 >= a.N) v.y = 0.f;
+                if (col + 2 >= a.N) v.z = 0.f;
+                v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
             if (a.ln_out) {
                 // LayerNorm partial of this pixel over the wave's 16 channels: 4 in this lane, 4 lanes (lg) per pixel
                 float sm = (v.x + v.y) + (v.z + v.w);
