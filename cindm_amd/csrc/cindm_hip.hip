@@ -60,6 +60,7 @@ struct cindm_unet1d {
     bool use_h3 = true;                    // k=5 convolutions on the fp16 matrix cores (3-term split); CINDM_MFMA=f32 disables
     bool use_local_gn = true;              // producer-side GroupNorm + Mish where groups are tile-local (CINDM_LOCAL_GN=0 disables)
     bool use_wide_qkv = true;              // shallow-level qkv projections on conv1x1_wide_kernel (CINDM_WIDE_QKV=0 disables)
+    bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
     // taps of the last forward
     struct Tap { size_t off; int L, C, ld; };
@@ -214,9 +215,10 @@ static void pack_bias(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefi
 // Split-fp16 packing for conv_gemm_h3_kernel: w = wh + 2^-11 * wl', wh = fp16(w), wl' = fp16((w - wh) * 2^11);
 // layout [n-tile][stage of 128 channels][q = (tap*2 + nb)*2 + plane][thread = wave*64 + lane][8 halfs], where the
 // 8 halfs are B[k = (lane>>4)*8 + e][j = lane&15] of v_mfma_f32_16x16x32_f16 for the wave's 32-channel k-group.
-static void pack_weight_h3(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int split) {
+static void pack_weight_h3(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int split, int kind = 0) {
     const Param& w = P(h, prefix + ".weight");
-    const int Co = (int)w.shape[0], Ci = (int)w.shape[1], K = (int)w.shape[2];
+    // kind 0: Conv1d weight [Co][Ci][K]; kind 1: ConvTranspose1d weight [Ci][Co][K]
+    const int Co = (int)w.shape[kind == 1 ? 1 : 0], Ci = (int)w.shape[kind == 1 ? 0 : 1], K = (int)w.shape[2];
     const int KC = 128;
     const int C0 = split ? split : Ci, C1 = Ci - C0;
     const int C0p = ceil_to(C0, KC), C1p = C1 ? ceil_to(C1, KC) : 0;
@@ -239,7 +241,7 @@ static void pack_weight_h3(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
                             if (cp < C0) c = cp;
                             else if (cp >= C0p && cp - C0p < C1) c = C0 + (cp - C0p);
                             float v = 0.f;
-                            if (c >= 0 && n < Co) v = w.host[((size_t)n * Ci + c) * K + tap];
+                            if (c >= 0 && n < Co) v = (kind == 1) ? w.host[((size_t)c * Co + n) * K + tap] : w.host[((size_t)n * Ci + c) * K + tap];
                             const _Float16 hv = (_Float16)v;
                             const float lo = (v - (float)hv) * 2048.0f;
                             const size_t q0 = ((size_t)(nt * nch + ch) * (K * 4) + (tap * 2 + nb) * 2) * 256;
@@ -316,6 +318,7 @@ static void pack_weight(cindm_unet1d* h, BlobBuilder& bb, const std::string& pre
     else if (kind == 1) { Ci = (int)w.shape[0]; Co = (int)w.shape[1]; K = (int)w.shape[2]; }
     else { Co = (int)w.shape[0]; Ci = (int)w.shape[1]; K = 1; }
     if (kind == 0 && K == 5 && h->use_h3) { pack_weight_h3(h, bb, prefix, split); return; }
+    if (h->use_h3 && h->use_h3_resample && ((kind == 0 && K == 3) || (kind == 1 && K == 4))) { pack_weight_h3(h, bb, prefix, split, kind); return; }
     const int C0 = split ? split : Ci, C1 = Ci - C0;
     // stage width: tap-ful convolutions stage 32 channels x T taps; 1x1 layers stage 64 or 128 channels
     const int KC = (K > 1) ? 32 : ((C0 % 128 == 0 && C1 % 128 == 0) ? 128 : 64);
@@ -436,6 +439,8 @@ struct Emitter {
         if (a.h3 && T == 5 && mode == SRC_PLAIN && a.W2) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, true>), grid, dim3(256), 0, stream, a);
         else if (a.h3 && T == 5 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
         else if (a.h3 && T == 5 && mode == SRC_GN_MISH) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_GN_MISH>), grid, dim3(256), 0, stream, a);
+        else if (a.h3 && T == 3 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<3, 96, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
+        else if (a.h3 && T == 4 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<4, 48, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
         else if (a.h3) ok = false;
         else if (T == 0) CINDM_LAUNCH(0, 32, 48, SRC_PLAIN);
         else if (T == 5 && mode == SRC_PLAIN) {
@@ -730,6 +735,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         h->use_local_gn = !(g && std::strcmp(g, "0") == 0);
         const char* wq = getenv("CINDM_WIDE_QKV");
         h->use_wide_qkv = !(wq && std::strcmp(wq, "0") == 0);
+        const char* hr = getenv("CINDM_H3_RESAMPLE");
+        h->use_h3_resample = !(hr && std::strcmp(hr, "0") == 0);
     }
     h->packed.clear(); h->vec_off.clear(); h->tb_off.clear();
     std::vector<RtbDesc> rtbs;
