@@ -198,11 +198,36 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_sample(self, shape, x, t: int, x_self_cond=None, clip_denoised=True, design_fn=None, design_guidance="standard",
-                 *, noise=None):
-        """:788-845 (the non-recurrence guidance modes).  x [B*nb, C, H, W]; returns (x_{t-1}, x_start)."""
-        if "recurrence" in design_guidance:
-            raise NotImplementedError("the 2-D recurrence branch (:846-889) is not built")
+                 *, noise=None, recur_noise=None):
+        """:788-889.  x [B*nb, C, H, W]; returns (x_{t-1}, x_start).  ``recur_noise`` [R, B*nb, C, H, W]: the relaxation
+        draws of the "-recurrence-N" branch (else ``sample_noise``)."""
         t = int(t)
+        if "recurrence" in design_guidance:
+            # :846-889, literally: the posterior mean is computed once; every iteration subtracts the raw design gradient
+            # taken at the current relaxed x (model_mean - grad_design) and re-noises; design_fn is required there
+            if design_fn is None:
+                raise ValueError("the 2-D recurrence guidance needs design_fn (the reference dereferences its gradient)")
+            R = int(design_guidance.split("-")[-1])
+            _, x_start, mean = self._step(shape, x, t, clip_denoised, None, add_noise=False)
+            ratio = self.alphas_cumprod / self.alphas_cumprod_prev
+            pred = mean
+            xc = x.float()
+            for r in range(R):
+                with torch.enable_grad():
+                    if design_guidance.startswith("standard"):
+                        g = design_fn(xc.clone().detach().requires_grad_()).detach()
+                    elif design_guidance.startswith("universal-forward-recurrence"):
+                        g = design_fn(x_start.clone().detach().requires_grad_()).detach()
+                    else:
+                        raise NotImplementedError(design_guidance)
+                pred = mean - g
+                z = recur_noise[r].to(x.device) if recur_noise is not None else \
+                    self.sample_noise(shape, x.device).view(-1, shape[2], shape[3], shape[4])
+                xc = torch.sqrt(ratio)[t] * pred + torch.sqrt(1 - ratio)[t] * z
+            if t > 0:
+                z = noise.to(x.device) if noise is not None else self.sample_noise(shape, x.device).view(-1, shape[2], shape[3], shape[4])
+                pred = pred + (0.5 * self.posterior_log_variance_clipped[t]).exp() * z
+            return pred, x_start
         pred, x_start, _ = self._step(shape, x, t, clip_denoised, noise)
         if design_fn is None:
             return pred, x_start

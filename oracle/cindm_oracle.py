@@ -1032,10 +1032,13 @@ def sample_noise_2d(state, boundary):
     return torch.cat([state.expand(-1, nb, -1, -1, -1), boundary], dim=2)
 
 
-def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard", clip_denoised=True):
-    """GaussianDiffusion.p_sample, non-recurrence branch, model/diffusion_2d.py:788-845 (objective pred_noise,
-    share_noise True).  x [B*nb, C, H, W]; noise [B*nb, C, H, W] (= sample_noise(...).view) or None at t == 0;
-    design_fn returns a GRADIENT tensor (:813).  Returns (x_{t-1}, x_start)."""
+def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard", clip_denoised=True, recur_noise=None):
+    """GaussianDiffusion.p_sample, model/diffusion_2d.py:788-889 (objective pred_noise, share_noise True).
+    x [B*nb, C, H, W]; noise [B*nb, C, H, W] (= sample_noise(...).view) or None at t == 0; design_fn returns a GRADIENT
+    tensor (:813).  "-recurrence-N" guidance (:846-889, needs design_fn) follows the reference literally: the posterior
+    mean is computed ONCE, every iteration subtracts the raw design gradient taken at the current relaxed x
+    (``model_mean - grad_design``, not the scaled ``grad_design_final``) and re-noises with ``recur_noise[r]``
+    [B*nb, C, H, W].  Returns (x_{t-1}, x_start)."""
     assert d.objective == "pred_noise" and d.share_noise
     B, nb = shape[0], shape[1]
     T = d.tab
@@ -1046,6 +1049,21 @@ def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard
     if clip_denoised:
         x_start = x_start.clamp(-1.0, 1.0)
     mean = T["posterior_mean_coef1"][t] * x_start + T["posterior_mean_coef2"][t] * x
+    if "recurrence" in design_guidance:
+        R = int(design_guidance.split("-")[-1])
+        ratio = T["alphas_cumprod"] / T["alphas_cumprod_prev"]
+        for r in range(R):
+            if design_guidance.startswith("standard"):
+                g = design_fn(x.clone())
+            elif design_guidance.startswith("universal-forward-recurrence"):
+                g = design_fn(x_start.clone())
+            else:
+                raise ValueError(design_guidance)
+            pred = mean - g
+            x = torch.sqrt(ratio)[t] * pred + torch.sqrt(1 - ratio)[t] * recur_noise[r]
+        if t > 0:
+            pred = pred + (0.5 * T["posterior_log_variance_clipped"][t]).exp() * noise
+        return pred, x_start
     pred = mean
     if t > 0:
         pred = mean + (0.5 * T["posterior_log_variance_clipped"][t]).exp() * noise

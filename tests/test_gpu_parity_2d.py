@@ -202,3 +202,16 @@ def test_guided_chain2d_vs_oracle_short(device, unet2d, diff2d):
     out = diff2d.sample(batch_size=1, num_boundaries=2, design_fn=design_grad, design_guidance="standard-alpha",
                         noise=tape, t_stop=994)
     assert rel(out, ref) < TOL_STEP * 3
+
+
+@pytest.mark.parametrize("tag,guid,t", [("std_r2", "standard-recurrence-2", 500), ("alpha_r3", "standard-alpha-recurrence-3", 20),
+                                        ("std_r1_t0", "standard-recurrence-1", 0)])
+def test_step2d_recurrence_golden(gold_dir, device, tag, guid, t):
+    """The 2-D "-recurrence-N" guidance branch (:846-889) against the reference's outputs (32x32 images)."""
+    g = np.load(os.path.join(gold_dir, "steps_2d_recur.npz"))
+    m, _ = build_unet2d(device, image_size=32, seed=0)
+    d = cindm_amd.GaussianDiffusion(m, image_size=32, frames=6, cond_frames=2, timesteps=1000, loss_type="l2").to(device)
+    nz = torch.from_numpy(g[tag + ".noise"]).to(device) if (tag + ".noise") in g.files else None
+    out, x0 = d.p_sample((1, 2, 21, 32, 32), torch.from_numpy(g[tag + ".x"]).to(device), t, None, design_fn=design_grad,
+                         design_guidance=guid, noise=nz, recur_noise=torch.from_numpy(g[tag + ".recur"]).to(device))
+    assert rel(out, g[tag + ".out"]) < TOL_STEP and rel(x0, g[tag + ".x0"]) < TOL_STEP

@@ -296,3 +296,17 @@ def test_ddim_schedule_landmarks():
     assert len(pairs) == 250 and pairs[0][0] == 999 and pairs[-1] == (3, -1) or pairs[-1][1] == -1
     assert all(a > b for a, b in pairs)
     assert O.ddim_time_pairs(1000, 1000)[-1] == (0, -1)
+
+
+RECUR_2D = {"std_r2": ("standard-recurrence-2", 500), "alpha_r3": ("standard-alpha-recurrence-3", 20), "std_r1_t0": ("standard-recurrence-1", 0)}
+
+
+@pytest.mark.parametrize("tag", sorted(RECUR_2D))
+def test_steps_2d_recurrence(gold_dir, sd2d, tag):
+    g = np.load(os.path.join(gold_dir, "steps_2d_recur.npz"))
+    guid, t = RECUR_2D[tag]
+    od = O.Diffusion2D(sd2d, image_size=32, frames=6)
+    nz = torch.from_numpy(g[tag + ".noise"]) if (tag + ".noise") in g.files else None
+    out, x0 = O.p_sample_2d(od, (1, 2, 21, 32, 32), torch.from_numpy(g[tag + ".x"]), t, nz, design_grad_2d, guid,
+                            recur_noise=torch.from_numpy(g[tag + ".recur"]))
+    assert rel(out, g[tag + ".out"]) < TOL and rel(x0, g[tag + ".x0"]) < TOL
