@@ -118,11 +118,19 @@ def lib():
         return _lib
     path = _build.lib_path()
     if _build.needs_build():
-        try:
-            _build.build()
-        except Exception as e:  # no hipcc on this box: fall through to whatever is on disk
-            if not os.path.isfile(path):
-                raise CindmError(f"libcindm_hip.so is missing and could not be built: {e}") from e
+        if os.environ.get("LOCAL_RANK", "0") not in ("0", ""):
+            # multi-process launch (torchrun): local rank 0 builds, the others wait for its library
+            import time
+            for _ in range(600):
+                if not _build.needs_build():
+                    break
+                time.sleep(0.5)
+        else:
+            try:
+                _build.build()
+            except Exception as e:  # no hipcc on this box: fall through to whatever is on disk
+                if not os.path.isfile(path):
+                    raise CindmError(f"libcindm_hip.so is missing and could not be built: {e}") from e
     try:
         L = C.CDLL(path)
     except OSError as e:

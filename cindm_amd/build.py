@@ -6,7 +6,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "cindm_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "cindm_hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))] + \
+       [os.path.join(os.path.dirname(HERE), "include", "cindm_hip.h")]
 LIB = os.path.join(HERE, "libcindm_hip.so")
 
 
@@ -30,12 +32,16 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc not found; cannot build libcindm_hip.so")
     # -ffp-contract=off: elementwise expressions keep the reference's separate roundings (PyTorch evaluates them
     # as distinct ops) and the step identities between compose modes stay bitwise; MFMA builtins are unaffected
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o",
-           LIB + ".tmp", SRC]
+    tmp = f"{LIB}.tmp{os.getpid()}"          # per-process name + atomic replace: concurrent builders cannot corrupt the library
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
