@@ -3,7 +3,7 @@
 
 One "step" = one pass of the hot path over one batch: a complete 1000-step DDPM reverse chain for a
 batch of 256 nbody-2 designs through TemporalUnet1D(dim=64, horizon=24) (BASELINE config 2), with
-synthetic generator-defined weights, x_T and per-step noise from the in-kernel counter-based generator.
+synthetic generator-defined weights (cindm_amd.synthetic), x_T and per-step noise from the in-kernel counter-based generator.
 Inputs (weights, state) are resident in HBM when the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W            (--workload cfg5: the 2-D airfoil configuration)
@@ -29,17 +29,16 @@ BATCH = 256
 TIMESTEPS = 1000
 
 
-def synth_weights(hz, F):
-    """Generator-defined random-init weights shared with the CPU baseline (oracle/ is test infrastructure;
-    here it only supplies the weight generator and, in cpu_baseline(), the timed CPU port)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cindm_oracle as O
-    return O.synth_state_dict(O.unet1d_param_shapes(hz, F, attention=True), seed=0)
+def cpu_state_dict(model):
+    """The product model's (generator-defined, cindm_amd.synthetic) weights as a CPU state_dict for the CPU baseline."""
+    return {k: v.detach().to("cpu", torch.float32).clone() for k, v in model.state_dict().items()}
 
 
 def cpu_baseline(sd, budget_s=20.0):
-    """The oracle (a torch-CPU port of the reference's path) timed on this box's host cores on a bounded
-    sample of the same workload: reverse steps of the batch-256 config, extrapolated to 1000 steps."""
+    """The oracle (a torch-CPU port of the reference's path; oracle/ is test infrastructure and is imported ONLY in the
+    two cpu_baseline legs) timed on this box's host cores on a bounded sample of the same workload: reverse steps of
+    the batch-256 config, extrapolated to 1000 steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cindm_oracle as O
     d = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
     g = torch.Generator().manual_seed(0)
@@ -79,6 +78,7 @@ def pmc_traffic(fname, substr):
 def cpu_baseline_2d(sd, budget_s=20.0):
     """The oracle's 2-D reverse step (torch-CPU port of the reference) on a bounded sample: steps of 4 designs x 2
     boundaries, extrapolated to 1000 steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cindm_oracle as O
     od = O.Diffusion2D(sd, image_size=64, frames=6)
     Bc, nb = 4, 2
@@ -113,11 +113,8 @@ def main_cfg5(args):
         dist.init_process_group("nccl", device_id=dev)
     import cindm_amd
     from cindm_amd import dist as cdist
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cindm_oracle as O
-    sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
-    model = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64)
-    model.load_state_dict(sd, strict=True)
+    from cindm_amd.synthetic import synthetic_init_
+    model = synthetic_init_(cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64), seed=0)
     diffusion = cindm_amd.GaussianDiffusion(model, image_size=64, frames=6, cond_frames=2, timesteps=TIMESTEPS,
                                             sampling_timesteps=TIMESTEPS, loss_type="l2").to(dev)
     B, nb = (args.batch or 64), 2
@@ -191,7 +188,7 @@ def main_cfg5(args):
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline_2d(sd)
+            line["cpu_baseline"] = cpu_baseline_2d(cpu_state_dict(model))
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
@@ -224,10 +221,9 @@ def main():
     import cindm_amd
     from cindm_amd import dist as cdist
 
-    sd = synth_weights(24, 8)
-    model = cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64, dim_mults=(1, 2, 4, 8),
-                                     attention=True)
-    model.load_state_dict(sd, strict=True)
+    from cindm_amd.synthetic import synthetic_init_
+    model = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64,
+                                                     dim_mults=(1, 2, 4, 8), attention=True), seed=0)
     diffusion = cindm_amd.GaussianDiffusion1D(model, image_size=24, conditioned_steps=0, timesteps=TIMESTEPS,
                                               sampling_timesteps=TIMESTEPS, loss_type="l1").to(dev)
     B = args.batch
@@ -306,7 +302,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(sd)
+            line["cpu_baseline"] = cpu_baseline(cpu_state_dict(model))
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

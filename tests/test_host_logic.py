@@ -235,3 +235,29 @@ def test_trainer_load_shim(tmp_path):
     torch.save({"step": 1, "model": bad}, tmp_path / "model-4.pt")
     with pytest.raises(RuntimeError):
         tr.load(4)
+
+
+def test_oracle_is_only_used_as_checker():
+    """oracle/ is test infrastructure: besides tests/ and __graft_entry__.smoke(), only bench.py's cpu_baseline legs may
+    touch it; tools/ and the product package must not."""
+    import ast
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "cindm_amd", "*.py")):
+        assert "oracle" not in open(f).read(), f
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef):
+            src = ast.get_source_segment(open(os.path.join(ROOT, "bench.py")).read(), node)
+            if "cindm_oracle" in src:
+                assert node.name.startswith("cpu_baseline"), node.name
+
+
+def test_synthetic_init_is_a_function_of_seed_and_name():
+    from cindm_amd.synthetic import synthetic_init_
+    a = synthetic_init_(cindm_amd.TemporalUnet1D(24, 8, False, attention=True), 3).state_dict()
+    b = synthetic_init_(cindm_amd.TemporalUnet1D(24, 8, False, attention=True), 3).state_dict()
+    c = synthetic_init_(cindm_amd.TemporalUnet1D(24, 8, False, attention=True), 4).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a) and not torch.equal(a["final_conv.1.weight"], c["final_conv.1.weight"])
+    w = a["downs.1.0.blocks.0.block.0.weight"]
+    assert float(w.abs().max()) <= 1.0 / (w.shape[1] * w.shape[2]) ** 0.5 + 1e-6
+    assert abs(float(a["downs.0.0.blocks.0.block.2.weight"].mean()) - 1.0) < 0.05

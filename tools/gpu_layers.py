@@ -2,13 +2,11 @@
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import cindm_oracle as O
-import cindm_amd
+sys.path.insert(0, ROOT); import cindm_amd
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-sd = O.synth_state_dict(O.unet1d_param_shapes(24, 8), seed=0)
-m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True); m.load_state_dict(sd); m = m.to(dev)
+from cindm_amd.synthetic import synthetic_init_
+m = synthetic_init_(cindm_amd.TemporalUnet1D(24, 8, False, attention=True), 0).to(dev)
 x = torch.randn((B, 24, 8), device=dev)
 for _ in range(3):
     m.profile_detail(x, 500)

@@ -8,17 +8,14 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import cindm_oracle as O          # noqa: E402  (weight generator only)
 import cindm_amd                   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 use_graph = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda:0")
-sd = O.synth_state_dict(O.unet1d_param_shapes(24, 8, attention=True), seed=0)
-m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
-m.load_state_dict(sd, strict=True)
+from cindm_amd.synthetic import synthetic_init_  # noqa: E402
+m = synthetic_init_(cindm_amd.TemporalUnet1D(24, 8, False, attention=True), 0)
 m = m.to(dev)
 d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(dev)
 kw = dict(batch_size=B, cond=None, n_composed=0, compose_n_bodies=2, seed=1, use_graph=bool(use_graph))

@@ -8,17 +8,14 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import cindm_oracle as O          # noqa: E402  (weight generator only)
 import cindm_amd                   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda:0")
-sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
-m = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64)
-m.load_state_dict(sd, strict=True)
+from cindm_amd.synthetic import synthetic_init_  # noqa: E402
+m = synthetic_init_(cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64), 0)
 m = m.to(dev)
 d = cindm_amd.GaussianDiffusion(m, image_size=64, frames=6, timesteps=1000).to(dev)
 d.sample(batch_size=B, num_boundaries=nb, seed=1, t_stop=998)

@@ -2,13 +2,11 @@
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import cindm_oracle as O
-import cindm_amd
+sys.path.insert(0, ROOT); import cindm_amd
 NI = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
-sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
-m = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64); m.load_state_dict(sd); m = m.to(dev)
+from cindm_amd.synthetic import synthetic_init_
+m = synthetic_init_(cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64), 0).to(dev)
 x = torch.randn((NI, 4096, 24), device=dev); x[:, :, 21:] = 0
 m.profile(x, 500)
 acc = {}
