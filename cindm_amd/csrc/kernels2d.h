@@ -641,6 +641,98 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
     conv2d_h3_epilogue(a, acc, reinterpret_cast<float (*)[T2M * LDR2]>(smem), img, ti, ty0, tx0);
 }
 
+// conv2d_stem7_h3_kernel: the 7x7 stem on the split-fp16 path.  Halo tile 10 x 22 pixels; the 24 state channels are
+// padded to one 32-channel k-step (hi / scaled-lo fp16 planes, 80 B per pixel), so a tap is ONE v_mfma_f32_16x16x32_f16
+// k-step.  The 49 taps are split over the two wave pairs (kg = w & 1 takes taps kg, kg+2, ...), the 64 output columns
+// over nh = w >> 1 -- the same (k-group, column half) structure and epilogue as conv2d_h3_kernel.
+constexpr int STEM3_NI = 25;             // tap slots per wave pair (the 25th of the odd pair is a zero pad)
+__global__ __launch_bounds__(256, 2) void conv2d_stem7_h3_kernel(const Conv2dArgs a) {
+    constexpr int SW = 22, SH = 10, R = SW * SH, PITCH = 80, PLANE = R * PITCH, NP = (R * 8 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2 * PLANE];
+    __shared__ __attribute__((aligned(16))) float Red[4][T2M * LDR2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int kg = w & 1, nh = w >> 1;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int img = mt / a.tpi, ti = mt - img * a.tpi;
+    const int tyi = ti / a.tiles_x;
+    const int ty0 = tyi * T2Y, tx0 = (ti - tyi * a.tiles_x) * T2X;
+    const int HWi = a.Hin * a.Win;
+
+    f32x4 accM[4][2], accL[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // B: [n-tile][tap slot i][q = nb*2 + plane][thread][8 halfs]; two register sets alternate over the tap slots
+    half8 bs[2][2][2];
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)nt * STEM3_NI * 4 * 256 + tid;
+    auto load_b = [&](int i, half8 (&b)[2][2]) {
+        const uint4* wp = wbase + (size_t)i * 4 * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+    };
+    load_b(0, bs[0]);
+    // stage the halo tile: R rows x 8 float4 (channels >= the source's pitch are zero)
+    const float* src = a.src[0].p;
+    const int ld = a.src[0].ld;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = tid + 256 * p;
+        const int r = i >> 3, c4 = i & 7;
+        const int hy = r / SW, hx = r - hy * SW;
+        const int y = ty0 - 3 + hy, x = tx0 - 3 + hx;
+        const bool ok = (r < R) && (c4 * 4 < ld) && (y >= 0) && (y < a.Hin) && (x >= 0) && (x < a.Win);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(src + ((size_t)img * HWi + (size_t)y * a.Win + x) * ld + c4 * 4);
+        half4v hi, lo;
+        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+        lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+        if (r < R) {
+            *reinterpret_cast<half4v*>(planes + r * PITCH + c4 * 8) = hi;
+            *reinterpret_cast<half4v*>(planes + PLANE + r * PITCH + c4 * 8) = lo;
+        }
+    }
+    __syncthreads();
+    const unsigned char* P0 = planes + (lane & 15) * PITCH + (lane >> 4) * 16;
+    const unsigned char* P1 = P0 + PLANE;
+#pragma unroll 1
+    for (int i = 0; i < STEM3_NI; i += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ii = i + u;
+            if (ii < STEM3_NI) {
+                load_b(min(ii + 1, STEM3_NI - 1), bs[(u + 1) & 1]);
+                const int tap = min(2 * ii + kg, 48);                 // wave-uniform; the pad slot carries zero weights
+                const int dy = tap / 7, dx = tap - dy * 7;
+                const int o = (dy * SW + dx) * PITCH;
+                half8 ah[4], al[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    ah[mb] = *reinterpret_cast<const half8*>(P0 + o + mb * SW * PITCH);
+                    al[mb] = *reinterpret_cast<const half8*>(P1 + o + mb * SW * PITCH);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bs[u][nb][0], accM[mb][nb], 0, 0, 0);
+                        accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bs[u][nb][1], accL[mb][nb], 0, 0, 0);
+                        accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], bs[u][nb][0], accL[mb][nb], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = accM[mb][nb] + accL[mb][nb] * H3_INV;
+    conv2d_h3_epilogue(a, acc, Red, img, ti, ty0, tx0);
+}
+
 // 7x7 stem (init_conv, :303): input = the padded state (CP = 24 channels, 21 real).  Halo tile 10 x 22 pixels x 24
 // channels staged once; K = 49 taps x 6 channel-quads = 294 k-steps (padded to 320), k-step 4i + w belongs to wave w,
 // so no MFMA is spent on padding channels beyond 24.  8 k-steps per B stage, 10 stages.
