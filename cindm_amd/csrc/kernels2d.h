@@ -1063,12 +1063,20 @@ __global__ __launch_bounds__(256) void la_context_kernel(const float* __restrict
         float* o = kst + (((size_t)ih * LA_SPLIT + split) * 32 + d) * 2;
         o[0] = M; o[1] = S;
     }
-    const float* vp = base + 256 + h * 32 + eg * 4;
+    // v slice -> LDS with coalesced float4 loads (issued together), then the context loop runs out of LDS only
+    __shared__ __attribute__((aligned(16))) float V[256 * 32];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int i = threadIdx.x + 256 * p;                 // per x 8 float4
+        const int px = i >> 3, c4 = i & 7;
+        if (px < per) *reinterpret_cast<float4*>(&V[px * 32 + c4 * 4]) = *reinterpret_cast<const float4*>(base + (size_t)px * 384 + 256 + h * 32 + c4 * 4);
+    }
+    __syncthreads();
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll 8
     for (int i = 0; i < per; ++i) {
         const float p = P[i * 32 + d];
-        const float4 v = *reinterpret_cast<const float4*>(vp + (size_t)i * 384);
+        const float4 v = *reinterpret_cast<const float4*>(&V[i * 32 + eg * 4]);
         c0 += p * v.x; c1 += p * v.y; c2 += p * v.z; c3 += p * v.w;
     }
     float* o = ctxp + (((size_t)ih * LA_SPLIT + split) * 32 + d) * 32 + eg * 4;
