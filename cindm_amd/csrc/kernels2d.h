@@ -1106,34 +1106,50 @@ __global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__
         ctx[(i >> 5) * 33 + (i & 31)] = s;
     }
     __syncthreads();
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= n) return;
-    const float* qp = qkv + ((size_t)img * n + pix) * 384 + h * 32;
-    float q[32];
-    float mx = -INFINITY;
+    // out^T[e][px] = sum_d ctx[d][e] * qhat[px][d] on fp32 MFMA: A = ctx^T (resident fragments), B = the softmaxed q of 16
+    // pixels; lane (lq = lane & 15, lg = lane >> 4) owns pixel lq of the block and the 8 channels d = 8 lg .. 8 lg + 7
+    // (k-step j pairs d = 8 lg + j on both operands -- a contraction does not care about the order), so q is read with
+    // two float4 loads per lane and the result leaves as float4 runs of 4 consecutive channels.
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lq = lane & 15, lg = lane >> 4;
+    float cf[8][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(qp + 4 * j);
-        q[4 * j] = v.x; q[4 * j + 1] = v.y; q[4 * j + 2] = v.z; q[4 * j + 3] = v.w;
-        mx = fmaxf(fmaxf(fmaxf(mx, v.x), fmaxf(v.y, v.z)), v.w);
-    }
-    float sum = 0.f;
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int d = 0; d < 32; ++d) { q[d] = expf(q[d] - mx); sum += q[d]; }
-    const float sc = 0.17677669529663687f / sum;
-    float* op = att + ((size_t)img * n + pix) * 128 + h * 32;
+        for (int eb = 0; eb < 2; ++eb) cf[j][eb] = ctx[(lg * 8 + j) * 33 + eb * 16 + lq];
 #pragma unroll
-    for (int e4 = 0; e4 < 8; ++e4) {
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int blk = 0; blk < 4; ++blk) {
+        const int pix = blockIdx.x * 256 + (w * 4 + blk) * 16 + lq;
+        const bool ok = pix < n;
+        const float* qp = qkv + ((size_t)img * n + (ok ? pix : 0)) * 384 + h * 32 + lg * 8;
+        const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+        float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        float mx = q[0];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            const float qd = q[d] * sc;
-            o0 += ctx[d * 33 + e4 * 4] * qd; o1 += ctx[d * 33 + e4 * 4 + 1] * qd;
-            o2 += ctx[d * 33 + e4 * 4 + 2] * qd; o3 += ctx[d * 33 + e4 * 4 + 3] * qd;
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, q[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q[j] = expf(q[j] - mx); sum += q[j]; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float sc = 0.17677669529663687f / sum;
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float qv = q[j] * sc;
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) acc[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[j][eb], qv, acc[eb], 0, 0, 0);
         }
-        *reinterpret_cast<float4*>(op + e4 * 4) = make_float4(o0, o1, o2, o3);
+        if (ok) {
+            float* op = att + ((size_t)img * n + pix) * 128 + h * 32 + lg * 4;
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb)
+                *reinterpret_cast<float4*>(op + eb * 16) = make_float4(acc[eb][0], acc[eb][1], acc[eb][2], acc[eb][3]);
+        }
     }
 }
+
 // out = LayerNorm_channels(z) * g + x   (LinearAttention's to_out[1] and the Residual, :126-135, :96-97); one wave per pixel row.
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                           const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C) {
