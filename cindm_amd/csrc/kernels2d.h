@@ -45,6 +45,7 @@ struct Conv2dArgs {
     // conv1x1_wide_kernel only: rows = pixels (2-D) or sequence positions (the 1-D path's qkv projections); blockIdx.y
     // selects a group of tiles_per_group output tiles (0 = all tiles in one workgroup)
     int64_t rows_total; int tiles_per_group;
+    const float* lnr_g;                 // conv1x1_wide_kernel<.., LNR>: out = LayerNorm_channels(W x + bias) * lnr_g + res
 };
 
 __device__ __forceinline__ float silu_f(float x) {
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem7_kernel(const Conv2dArgs a
 // in registers for the whole loop when RES -- the wide qkv projections), so there is NO cross-wave reduction: the epilogue (EPI) runs on the
 // accumulators -- each lane holds 4 consecutive channels of pixel (lane & 15) + 16 pb -- with float4 loads of the
 // epilogue operands and float4 stores.  LayerNorm partials of the output are per pixel and per 16 channels.
-template <int KT, int MODE, bool RES, bool EPI>
+template <int KT, int MODE, bool RES, bool EPI, bool LNR = false>
 __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Conv2dArgs a) {
     constexpr int LDA = KT + 4, F4 = KT / 4, NKS = KT / 4, NQ = KT / 16;
     constexpr int NPASS = (64 * F4 + 255) / 256;
@@ -903,6 +904,76 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             for (int pb = 0; pb < 4; ++pb) xb[ks][pb] = As[(pb * 16 + lq) * LDA + ks * 4 + lg];
     }
 
+    if constexpr (LNR) {
+        // LinearAttention's to_out: Conv 1x1 (+bias) -> LayerNorm over ALL output channels -> * g -> + residual (:233-236,
+        // :96-97).  N <= 128: both output tiles stay in accumulators; the per-pixel statistics cross the four waves
+        // (16 channels each per tile) through a 2 KB LDS table, two-pass (mean, then centred squares).
+        __shared__ float psum[2][4][64];
+        f32x4 accs[2][4];
+        if (ntile > 1) load_w(1, wB);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < ntile) {
+                const float4 (&wv)[NQ] = t ? wB : wA;
+                const float4 bias = *reinterpret_cast<const float4*>(a.bias + t * T2N + w * 16 + lg * 4);
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) accs[t][pb] = (f32x4){bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float wq[4] = {wv[q].x, wv[q].y, wv[q].z, wv[q].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pb = 0; pb < 4; ++pb)
+                            accs[t][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[j], As[(pb * 16 + lq) * LDA + (q * 4 + j) * 4 + lg], accs[t][pb], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) accs[t][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float invn = 1.0f / (float)a.N;
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                float sm = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (t < ntile) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) { const float d = pass ? accs[t][pb][rg] - mean[pb] : accs[t][pb][rg]; sm += pass ? d * d : d; }
+                    }
+                sm += __shfl_xor(sm, 16, 64);
+                sm += __shfl_xor(sm, 32, 64);
+                if (lg == 0) psum[pass][w][pb * 16 + lq] = sm;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int px = pb * 16 + lq;
+                const float tot = (psum[pass][0][px] + psum[pass][1][px]) + (psum[pass][2][px] + psum[pass][3][px]);
+                if (pass == 0) mean[pb] = tot * invn; else rstd[pb] = 1.0f / sqrtf(tot * invn + 1e-5f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (t < ntile) {
+                const int col = t * T2N + w * 16 + lg * 4;
+                const float4 g = *reinterpret_cast<const float4*>(a.lnr_g + col);
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const size_t prow = row0 + pb * 16 + lq;
+                    const float4 r4 = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + col);
+                    float4 v;
+                    v.x = (accs[t][pb][0] - mean[pb]) * rstd[pb] * g.x + r4.x; v.y = (accs[t][pb][1] - mean[pb]) * rstd[pb] * g.y + r4.y;
+                    v.z = (accs[t][pb][2] - mean[pb]) * rstd[pb] * g.z + r4.z; v.w = (accs[t][pb][3] - mean[pb]) * rstd[pb] * g.w + r4.w;
+                    *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
+                }
+            }
+        return;
+    }
     auto tile = [&](int it, const float4 (&wv)[NQ]) {
         const int col = it * T2N + w * 16 + lg * 4;           // this lane's 4 consecutive output channels
         f32x4 acc[4];
