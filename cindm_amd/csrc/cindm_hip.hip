@@ -60,6 +60,7 @@ struct cindm_unet1d {
     bool use_h3 = true;                    // k=5 convolutions on the fp16 matrix cores (3-term split); CINDM_MFMA=f32 disables
     bool use_local_gn = true;              // producer-side GroupNorm + Mish where groups are tile-local (CINDM_LOCAL_GN=0 disables)
     bool use_wide_qkv = true;              // shallow-level qkv projections on conv1x1_wide_kernel (CINDM_WIDE_QKV=0 disables)
+    bool use_attn_site = true;             // one launch per attention site, attn1d_site_kernel (CINDM_ATTN_SITE=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
     // taps of the last forward
@@ -272,6 +273,31 @@ static void pack_weight_wide(cindm_unet1d* h, BlobBuilder& bb, const std::string
                     base[(((size_t)it * NQ + q) * 256 + tid) * 4 + j] = (n < Co) ? w.host[(size_t)n * Ci + k] : 0.f;
                 }
     h->packed[prefix + "#wide"] = pk;
+}
+
+// attn1d_site_kernel operands: to_qkv as 24 tiles of 16 channels, to_out as C/16 tiles over the 128 head channels;
+// fragment [tile][k16][lane][j] = W[tile*16 + lane%16][k16*16 + (lane/16)*4 + j]
+static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& attn_prefix) {
+    const Param& wq = P(h, attn_prefix + ".to_qkv.weight");
+    const Param& wo = P(h, attn_prefix + ".to_out.weight");
+    const int C = (int)wq.shape[1];
+    if ((int)wq.shape[0] != 384 || (int)wo.shape[1] != 128 || (int)wo.shape[0] != C) return;
+    if (C != 64 && C != 128 && C != 256 && C != 512) return;
+    auto frag = [&](const Param& w, int Co, int Ci, const std::string& name) {
+        Packed pk; pk.T = 1; pk.CinP = Ci; pk.Npad = Co; pk.N = Co; pk.KC = Ci;
+        const int K16 = Ci / 16;
+        pk.off = bb.alloc((size_t)(Co / 16) * K16 * 256);
+        float* base = bb.data.data() + pk.off;
+        for (int t = 0; t < Co / 16; ++t)
+            for (int k = 0; k < K16; ++k)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        base[(((size_t)t * K16 + k) * 64 + lane) * 4 + j] =
+                            w.host[(size_t)(t * 16 + (lane & 15)) * Ci + k * 16 + (lane >> 4) * 4 + j];
+        h->packed[name] = pk;
+    };
+    frag(wq, 384, C, attn_prefix + ".to_qkv#site");
+    frag(wo, C, 128, attn_prefix + ".to_out#site");
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -581,6 +607,34 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
     const Packed& wo = h->packed.at(p + ".fn.fn.to_out");
     Ten qkv = E.ten(L, 384), att = E.ten(L, 128), out = E.ten(L, C);
     GemmArgs a;
+    auto site = h->packed.find(p + ".fn.fn.to_qkv#site");
+    if (site != h->packed.end() && L <= 32) {
+        // the whole site in one launch: one sample per workgroup (attn1d_site_kernel)
+        Ten out = E.ten(L, C);
+        ++E.launches;
+        if (!E.dry) {
+            AttnSiteArgs s;
+            s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
+            s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
+            s.L = L;
+            const dim3 grid((unsigned)Bp);
+            E.prof_begin(5, 2.0 * Bp * L * 1024.0 * C + (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));
+            for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
+#define SITE_LAUNCH(C_, NT_, PF_) hipLaunchKernelGGL((attn1d_site_kernel<C_, NT_, PF_>), grid, dim3(256), 0, E.stream, s)
+                if (L > 16) {
+                    if (C == 64) SITE_LAUNCH(64, 2, 4); else if (C == 128) SITE_LAUNCH(128, 2, 4);
+                    else if (C == 256) SITE_LAUNCH(256, 2, 4); else SITE_LAUNCH(512, 2, 4);
+                } else {
+                    if (C == 64) SITE_LAUNCH(64, 1, 4); else if (C == 128) SITE_LAUNCH(128, 1, 4);
+                    else if (C == 256) SITE_LAUNCH(256, 1, 4); else SITE_LAUNCH(512, 1, 4);
+                }
+#undef SITE_LAUNCH
+            }
+            E.prof_end();
+        }
+        E.tap(p, out);
+        return out;
+    }
     auto wide = h->packed.find(p + ".fn.fn.to_qkv#wide");
     if (wide != h->packed.end()) {
         // shallow levels (C = 64 / 128): 64-row tiles, the LayerNorm-ed input tile staged once per workgroup and its
@@ -735,6 +789,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         h->use_local_gn = !(g && std::strcmp(g, "0") == 0);
         const char* wq = getenv("CINDM_WIDE_QKV");
         h->use_wide_qkv = !(wq && std::strcmp(wq, "0") == 0);
+        const char* as = getenv("CINDM_ATTN_SITE");
+        h->use_attn_site = !(as && std::strcmp(as, "0") == 0);
         const char* hr = getenv("CINDM_H3_RESAMPLE");
         h->use_h3_resample = !(hr && std::strcmp(hr, "0") == 0);
     }
@@ -758,6 +814,7 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         } else if (ends("to_qkv.weight") || ends("to_out.weight") || k == "final_conv.1.weight") {
             pack_weight(h, bb, k.substr(0, k.size() - 7), 0, 0);
             if (ends("to_qkv.weight") && h->use_wide_qkv) pack_weight_wide(h, bb, k.substr(0, k.size() - 7));
+            if (ends("to_out.weight") && h->use_attn_site) pack_attn_site(h, bb, k.substr(0, k.size() - std::strlen(".to_out.weight")));
         } else if (ends("time_mlp.1.weight") || k == "time_mlp.3.weight") {
             pack_weight(h, bb, k.substr(0, k.size() - 7), 2, 0);
             if (k != "time_mlp.1.weight" && k != "time_mlp.3.weight") {

@@ -860,6 +860,240 @@ __global__ __launch_bounds__(256) void linattn_core_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// One launch per Residual(PreNorm(LinearAttentionTemporal)) site (model/diffusion_1d.py:75-81, :123-142, :272-291):
+//   out = x + Wo * linattn(Wqkv * (LN(x) g)) + bo
+// one sample per workgroup, wave = head.  Every product runs on the fp32 MFMA with operands chosen so that the
+// accumulator layout of one product IS the operand layout of the next (no transposes through LDS):
+//   q  = Wq y^T      rows = channels, cols = positions        (A = weights, B = y)
+//   k,v = y Wk^T     rows = positions, cols = channels        (A = y, B = weights; the same LDS / weight fragments)
+//   ctx[d][e] = sum_n k^[d][n] v[e][n]        A = k^ accumulators, B = v accumulators (contraction index = rows)
+//   att[e][n] = sum_d ctx[d][e] q[d][n]       A = ctx accumulators, B = q accumulators
+// att goes through LDS once ([position][head*32 + e]) for the output projection, whose N (channels) is split over
+// the waves.  Weight fragments: [tile of 16 channels][k16][lane][4], element j <-> k = k16*16 + (lane/16)*4 + j.
+struct AttnSiteArgs {
+    const float* x; int ldx;
+    float* out; int ldo;
+    const float* g;        // LayerNorm gain [C]
+    const float* Wqkv;     // [24 tiles][C/16][64][4]
+    const float* Wo;       // [C/16 tiles][8][64][4]
+    const float* bo;       // [C]
+    int L;
+};
+
+template <int C, int NT, int PF>
+__global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) {
+    constexpr int NP = NT * 16, YP = C + 4, AP = 132, K16 = C / 16, CT = C / 16;
+    constexpr int CH = (C + 255) / 256;                  // float4 chunks per lane per row
+    constexpr int RW = NP / 4;                           // rows per wave in the LayerNorm phase
+    __shared__ __attribute__((aligned(16))) float Ys[NP * YP];
+    __shared__ __attribute__((aligned(16))) float At[NP * AP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int L = a.L;
+    const size_t row0 = (size_t)blockIdx.x * L;
+    const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+    // this wave's six channel tiles: q (2h, 2h+1), k (8+2h, ..), v (16+2h, ..)
+    int tile[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) tile[s] = (s >> 1) * 8 + 2 * w + (s & 1);
+    // weight ring: PF k16-steps in flight
+    float4 wr[PF][6];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wr[p][s] = (p < K16) ? Wq4[((size_t)tile[s] * K16 + p) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- LayerNorm over channels (biased variance, eps 1e-5), two-pass, rows w, w+4, ... of this sample ----
+    {
+        float4 xr[RW][CH];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int n = w + 4 * r;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                const int c4 = lane + 64 * m;
+                xr[r][m] = (n < L && c4 < C / 4) ? *reinterpret_cast<const float4*>(a.x + (row0 + n) * a.ldx + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float4 gv[CH];
+#pragma unroll
+        for (int m = 0; m < CH; ++m) {
+            const int c4 = lane + 64 * m;
+            gv[m] = (c4 < C / 4) ? *reinterpret_cast<const float4*>(a.g + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int n = w + 4 * r;
+            float s1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            const float mean = s1 * (1.0f / C);
+            float s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                const int c4 = lane + 64 * m;
+                if (c4 < C / 4) {
+                    const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
+                    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                const int c4 = lane + 64 * m;
+                if (c4 < C / 4) {
+                    float4 y;
+                    y.x = (xr[r][m].x - mean) * rstd * gv[m].x; y.y = (xr[r][m].y - mean) * rstd * gv[m].y;
+                    y.z = (xr[r][m].z - mean) * rstd * gv[m].z; y.w = (xr[r][m].w - mean) * rstd * gv[m].w;
+                    if (n >= L) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(&Ys[n * YP + 4 * c4]) = y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- q, k, v of head w ----
+    f32x4 qa[2][NT], ka[NT][2], va[NT][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { qa[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; ka[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; va[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int k16 = 0; k16 < K16; ++k16) {
+        float4 wc[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wc[s] = wr[k16 % PF][s];
+        if (k16 + PF < K16) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) wr[k16 % PF][s] = Wq4[((size_t)tile[s] * K16 + k16 + PF) * 64 + lane];
+        }
+        float4 yv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) yv[nt] = *reinterpret_cast<const float4*>(&Ys[(nt * 16 + lr) * YP + k16 * 16 + lq * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w0 = (&wc[0].x)[j], w1 = (&wc[1].x)[j], w2 = (&wc[2].x)[j], w3 = (&wc[3].x)[j], w4 = (&wc[4].x)[j], w5 = (&wc[5].x)[j];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float y = (&yv[nt].x)[j];
+                qa[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, y, qa[0][nt], 0, 0, 0);
+                qa[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, y, qa[1][nt], 0, 0, 0);
+                ka[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, w2, ka[nt][0], 0, 0, 0);
+                ka[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, w3, ka[nt][1], 0, 0, 0);
+                va[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, w4, va[nt][0], 0, 0, 0);
+                va[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y, w5, va[nt][1], 0, 0, 0);
+            }
+        }
+    }
+    // first projection tile of this wave: in flight during the attention core
+    const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
+    static_assert(CT % 4 == 0, "output channel tiles are split evenly over the four waves");
+    constexpr int TPW = CT / 4;                          // output channel tiles per wave
+    float4 wo[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wo[0][k] = Wo4[((size_t)(w * TPW) * 8 + k) * 64 + lane];
+
+    // ---- core: q *= 32^-1/2 ; k = softmax over positions ; ctx = k v^T ; att = ctx^T q ----
+    const float scale = 0.17677669529663687f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) qa[i][nt] *= scale;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nt * 16 + lq * 4 + i;
+                if (n >= L) ka[nt][dt][i] = -INFINITY;
+                mx = fmaxf(mx, ka[nt][dt][i]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = __builtin_amdgcn_exp2f((ka[nt][dt][i] - mx) * 1.4426950408889634f);
+                ka[nt][dt][i] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ka[nt][dt] *= inv;
+    }
+    f32x4 ctx[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][dt][i], va[nt][et][i], c, 0, 0, 0);
+            ctx[dt][et] = c;
+        }
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(ctx[dt][et][i], qa[dt][nt][i], o, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(&At[(nt * 16 + lr) * AP + w * 32 + et * 16 + lq * 4]) = o;
+        }
+    __syncthreads();
+
+    // ---- out = Wo att + bo + x : channel tiles [w*TPW, (w+1)*TPW) of this wave ----
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int ct = w * TPW + t;
+        if (t + 1 < TPW) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wo[(t + 1) & 1][k] = Wo4[((size_t)(ct + 1) * 8 + k) * 64 + lane];
+        }
+        f32x4 z[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 wv = wo[t & 1][k];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 av = *reinterpret_cast<const float4*>(&At[(nt * 16 + lr) * AP + k * 16 + lq * 4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((&wv.x)[j], (&av.x)[j], z[nt], 0, 0, 0);
+            }
+        }
+        const int c = ct * 16 + lq * 4;
+        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + lr;
+            if (n < L) {
+                const float4 xv = *reinterpret_cast<const float4*>(a.x + (row0 + n) * a.ldx + c);
+                float4 o;
+                o.x = z[nt][0] + b.x + xv.x; o.y = z[nt][1] + b.y + xv.y; o.z = z[nt][2] + b.z + xv.z; o.w = z[nt][3] + b.w + xv.w;
+                *reinterpret_cast<float4*>(a.out + (row0 + n) * a.ldo + c) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Counter-based Gaussian noise: Philox4x32-10 keyed by seed, counter = (element/4, sample, step, 0),
 // Box-Muller on the four 32-bit outputs.  Pure function of (seed, global sample, step, element):
 // results do not depend on the number of GPUs / batch partition.
