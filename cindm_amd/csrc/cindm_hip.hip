@@ -616,12 +616,20 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             AttnSiteArgs s;
             s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
             s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
-            s.L = L;
-            const dim3 grid((unsigned)Bp);
+            s.L = L; s.Bp = Bp;
+            static const int dbg3 = getenv("CINDM_DBG3") ? atoi(getenv("CINDM_DBG3")) : 0;
+            s.dbg = dbg3;
+            // samples per workgroup: as many 4-aligned slots as fit one 16-position tile (weights are streamed once
+            // per workgroup); CINDM_SITE_PACK=0 keeps one sample per workgroup
+            static const int pack = getenv("CINDM_SITE_PACK") ? atoi(getenv("CINDM_SITE_PACK")) : 1;
+            const int NTsel = (L > 16) ? 2 : 1;
+            s.slot = (L > 16) ? 32 : ceil_to(L, 4);
+            s.S = (L > 16 || !pack) ? 1 : 16 / s.slot;
+            const dim3 grid((unsigned)((Bp + s.S - 1) / s.S));
             E.prof_begin(5, 2.0 * Bp * L * 1024.0 * C + (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));
             for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
 #define SITE_LAUNCH(C_, NT_, PF_) hipLaunchKernelGGL((attn1d_site_kernel<C_, NT_, PF_>), grid, dim3(256), 0, E.stream, s)
-                if (L > 16) {
+                if (NTsel == 2) {
                     if (C == 64) SITE_LAUNCH(64, 2, 4); else if (C == 128) SITE_LAUNCH(128, 2, 4);
                     else if (C == 256) SITE_LAUNCH(256, 2, 4); else SITE_LAUNCH(512, 2, 4);
                 } else {

@@ -877,20 +877,28 @@ struct AttnSiteArgs {
     const float* Wqkv;     // [24 tiles][C/16][64][4]
     const float* Wo;       // [C/16 tiles][8][64][4]
     const float* bo;       // [C]
-    int L;
+    int L;                 // positions per sample
+    int S;                 // samples per workgroup
+    int slot;              // tile positions per sample: L rounded up to a multiple of 4 when S > 1, so that the order of
+                           // every per-sample reduction (hence every bit of the result) is independent of the slot
+    int Bp;                // samples in the batch
+    int dbg;               // timing ablations (wrong results): 1 no qkv loop, 2 no projection, 3 no core
 };
 
 template <int C, int NT, int PF>
 __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) {
     constexpr int NP = NT * 16, YP = C + 4, AP = 132, K16 = C / 16, CT = C / 16;
-    constexpr int CH = (C + 255) / 256;                  // float4 chunks per lane per row
+    constexpr int CH = (C + 255) / 256;                  // float4 chunks per lane per row (LayerNorm phase)
     constexpr int RW = NP / 4;                           // rows per wave in the LayerNorm phase
     __shared__ __attribute__((aligned(16))) float Ys[NP * YP];
     __shared__ __attribute__((aligned(16))) float At[NP * AP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int L = a.L;
-    const size_t row0 = (size_t)blockIdx.x * L;
+    const int s_here = min(a.S, a.Bp - (int)blockIdx.x * a.S);      // samples of this workgroup
+    const int slot = a.slot;
+    const int nend = s_here * slot;                                  // tile positions in use (pads inside a slot are zero rows)
+    const size_t row0 = (size_t)blockIdx.x * a.S * L;                // tile position n <-> row row0 + (n / slot) * L + n % slot
     const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
     // this wave's six channel tiles: q (2h, 2h+1), k (8+2h, ..), v (16+2h, ..)
     int tile[6];
@@ -903,54 +911,52 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
 #pragma unroll
         for (int s = 0; s < 6; ++s) wr[p][s] = (p < K16) ? Wq4[((size_t)tile[s] * K16 + p) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- LayerNorm over channels (biased variance, eps 1e-5), two-pass, rows w, w+4, ... of this sample ----
+    // ---- LayerNorm over channels (biased variance, eps 1e-5), two-pass.  LPR lanes share a row (RPP rows per wave and
+    // pass), so the butterflies are log2(LPR) deep; wave w owns tile positions [w*RW, (w+1)*RW) ----
     {
-        float4 xr[RW][CH];
+        constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;   // lanes per row
+        constexpr int RPP = 64 / LPR;                    // rows per pass
+        constexpr int NPASS = (RW + RPP - 1) / RPP;
+        const int lrow = lane / LPR, lcol = lane % LPR;
+        float4 xr[NPASS][CH];
+        bool okr[NPASS];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int n = w + 4 * r;
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
+            okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
 #pragma unroll
-            for (int m = 0; m < CH; ++m) {
-                const int c4 = lane + 64 * m;
-                xr[r][m] = (n < L && c4 < C / 4) ? *reinterpret_cast<const float4*>(a.x + (row0 + n) * a.ldx + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int m = 0; m < CH; ++m)
+                xr[r][m] = okr[r] ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + 4 * (lcol + LPR * m)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 gv[CH];
 #pragma unroll
-        for (int m = 0; m < CH; ++m) {
-            const int c4 = lane + 64 * m;
-            gv[m] = (c4 < C / 4) ? *reinterpret_cast<const float4*>(a.g + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int n = w + 4 * r;
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = w * RW + r * RPP + lrow;
             float s1 = 0.f;
 #pragma unroll
             for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
             const float mean = s1 * (1.0f / C);
             float s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < CH; ++m) {
-                const int c4 = lane + 64 * m;
-                if (c4 < C / 4) {
-                    const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
-                    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                }
+                const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
             const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            if (r * RPP + lrow < RW) {
 #pragma unroll
-            for (int m = 0; m < CH; ++m) {
-                const int c4 = lane + 64 * m;
-                if (c4 < C / 4) {
+                for (int m = 0; m < CH; ++m) {
                     float4 y;
                     y.x = (xr[r][m].x - mean) * rstd * gv[m].x; y.y = (xr[r][m].y - mean) * rstd * gv[m].y;
                     y.z = (xr[r][m].z - mean) * rstd * gv[m].z; y.w = (xr[r][m].w - mean) * rstd * gv[m].w;
-                    if (n >= L) y = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(&Ys[n * YP + 4 * c4]) = y;
+                    if (!okr[r]) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(&Ys[n * YP + 4 * (lcol + LPR * m)]) = y;
                 }
             }
         }
@@ -963,6 +969,7 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) { qa[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; ka[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; va[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (a.dbg != 1)
 #pragma unroll
     for (int k16 = 0; k16 < K16; ++k16) {
         float4 wc[6];
@@ -972,6 +979,7 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
 #pragma unroll
             for (int s = 0; s < 6; ++s) wr[k16 % PF][s] = Wq4[((size_t)tile[s] * K16 + k16 + PF) * 64 + lane];
         }
+        __builtin_amdgcn_sched_barrier(0);               // keep the refill ahead of this step's MFMAs (PF steps in flight)
         float4 yv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) yv[nt] = *reinterpret_cast<const float4*>(&Ys[(nt * 16 + lr) * YP + k16 * 16 + lq * 4]);
@@ -994,100 +1002,131 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
     const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
     static_assert(CT % 4 == 0, "output channel tiles are split evenly over the four waves");
     constexpr int TPW = CT / 4;                          // output channel tiles per wave
-    float4 wo[2][8];
+    constexpr int WOR = 3;                               // projection weight ring: two tiles in flight
+    float4 wo[WOR][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) wo[0][k] = Wo4[((size_t)(w * TPW) * 8 + k) * 64 + lane];
+    for (int t = 0; t < WOR - 1; ++t)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wo[t][k] = (t < TPW) ? Wo4[((size_t)(w * TPW + t) * 8 + k) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- core: q *= 32^-1/2 ; k = softmax over positions ; ctx = k v^T ; att = ctx^T q ----
+    // ---- core, per sample s: q *= 32^-1/2 ; k = softmax over the sample's positions ; ctx_s = k v^T ; att = ctx_s^T q ----
     const float scale = 0.17677669529663687f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) qa[i][nt] *= scale;
+    // sample of each accumulator row (k, v: rows = positions nt*16 + lq*4 + i) and column (q: cols = positions nt*16 + lr)
+    int sid_row[NT][4], sid_col[NT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        float mx = -INFINITY;
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = nt * 16 + lq * 4 + i;
-                if (n >= L) ka[nt][dt][i] = -INFINITY;
-                mx = fmaxf(mx, ka[nt][dt][i]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = __builtin_amdgcn_exp2f((ka[nt][dt][i] - mx) * 1.4426950408889634f);
-                ka[nt][dt][i] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) ka[nt][dt] *= inv;
+        for (int i = 0; i < 4; ++i) { const int n = nt * 16 + lq * 4 + i; sid_row[nt][i] = (n < nend && n % slot < L) ? n / slot : -1; }
+        const int n = nt * 16 + lr;
+        sid_col[nt] = (n < nend && n % slot < L) ? n / slot : -1;
     }
-    f32x4 ctx[2][2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int et = 0; et < 2; ++et) {
-            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][dt][i], va[nt][et][i], c, 0, 0, 0);
-            ctx[dt][et] = c;
-        }
+    f32x4 att[2][NT];
 #pragma unroll
     for (int et = 0; et < 2; ++et)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) att[et][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; s < (a.dbg == 3 ? 0 : s_here); ++s) {
+        f32x4 ks[NT][2];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt) {
+            float mx = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(ctx[dt][et][i], qa[dt][nt][i], o, 0, 0, 0);
-            *reinterpret_cast<f32x4*>(&At[(nt * 16 + lr) * AP + w * 32 + et * 16 + lq * 4]) = o;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (sid_row[nt][i] == s) mx = fmaxf(mx, ka[nt][dt][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = (sid_row[nt][i] == s) ? __builtin_amdgcn_exp2f((ka[nt][dt][i] - mx) * 1.4426950408889634f) : 0.f;
+                    ks[nt][dt][i] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ks[nt][dt] *= inv;
         }
+        f32x4 ctx[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[nt][dt][i], va[nt][et][i], c, 0, 0, 0);
+                ctx[dt][et] = c;
+            }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool mine = sid_col[nt] == s;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        att[et][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ctx[dt][et][i], mine ? qa[dt][nt][i] : 0.f, att[et][nt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4*>(&At[(nt * 16 + lr) * AP + w * 32 + et * 16 + lq * 4]) = att[et][nt];
     __syncthreads();
 
     // ---- out = Wo att + bo + x : channel tiles [w*TPW, (w+1)*TPW) of this wave ----
+    if (a.dbg != 2)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int ct = w * TPW + t;
-        if (t + 1 < TPW) {
+        if (t + WOR - 1 < TPW) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) wo[(t + 1) & 1][k] = Wo4[((size_t)(ct + 1) * 8 + k) * 64 + lane];
+            for (int k = 0; k < 8; ++k) wo[(t + WOR - 1) % WOR][k] = Wo4[((size_t)(ct + WOR - 1) * 8 + k) * 64 + lane];
         }
-        f32x4 z[NT];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 z[NT], z1[NT];                             // two chains per tile (head pairs) keep the matrix pipe busy
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) { z[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; z1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 wv = wo[t & 1][k];
+        for (int k = 0; k < 4; ++k) {
+            const float4 wv = wo[t % WOR][k], wv1 = wo[t % WOR][k + 4];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 av = *reinterpret_cast<const float4*>(&At[(nt * 16 + lr) * AP + k * 16 + lq * 4]);
+                const float4 av1 = *reinterpret_cast<const float4*>(&At[(nt * 16 + lr) * AP + (k + 4) * 16 + lq * 4]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((&wv.x)[j], (&av.x)[j], z[nt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((&wv.x)[j], (&av.x)[j], z[nt], 0, 0, 0);
+                    z1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32((&wv1.x)[j], (&av1.x)[j], z1[nt], 0, 0, 0);
+                }
             }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) z[nt] += z1[nt];
         const int c = ct * 16 + lq * 4;
         const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 16 + lr;
-            if (n < L) {
-                const float4 xv = *reinterpret_cast<const float4*>(a.x + (row0 + n) * a.ldx + c);
+            const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
+            if (n < nend && pn < L) {
+                const size_t row = row0 + sn * L + pn;
+                const float4 xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
                 float4 o;
                 o.x = z[nt][0] + b.x + xv.x; o.y = z[nt][1] + b.y + xv.y; o.z = z[nt][2] + b.z + xv.z; o.w = z[nt][3] + b.w + xv.w;
-                *reinterpret_cast<float4*>(a.out + (row0 + n) * a.ldo + c) = o;
+                *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
             }
         }
     }
