@@ -296,8 +296,33 @@ static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
                             w.host[(size_t)(t * 16 + (lane & 15)) * Ci + k * 16 + (lane >> 4) * 4 + j];
         h->packed[name] = pk;
     };
-    frag(wq, 384, C, attn_prefix + ".to_qkv#site");
-    frag(wo, C, 128, attn_prefix + ".to_out#site");
+    // split-fp16 fragments: [tile][k32][plane hi / scaled lo][lane][e] = W[tile*16 + lane%16][k32*32 + (lane/16)*8 + e]
+    auto frag_h3 = [&](const Param& w, int Co, int Ci, const std::string& name) {
+        Packed pk; pk.T = 1; pk.CinP = Ci; pk.Npad = Co; pk.N = Co; pk.KC = Ci; pk.h3 = true;
+        const int K32 = Ci / 32;
+        pk.off = bb.alloc((size_t)(Co / 16) * K32 * 2 * 64 * 4);
+        uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
+        auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
+        for (int t = 0; t < Co / 16; ++t)
+            for (int k = 0; k < K32; ++k)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = w.host[(size_t)(t * 16 + (lane & 15)) * Ci + k * 32 + (lane >> 4) * 8 + e];
+                        const _Float16 hv = (_Float16)v;
+                        const float lo = (v - (float)hv) * 2048.0f;
+                        const size_t q0 = ((size_t)t * K32 + k) * 2;
+                        base[((q0 + 0) * 64 + lane) * 8 + e] = bits((float)hv);
+                        base[((q0 + 1) * 64 + lane) * 8 + e] = bits(lo);
+                    }
+        h->packed[name] = pk;
+    };
+    if (h->use_h3) {
+        frag_h3(wq, 384, C, attn_prefix + ".to_qkv#site");
+        frag_h3(wo, C, 128, attn_prefix + ".to_out#site");
+    } else {
+        frag(wq, 384, C, attn_prefix + ".to_qkv#site");
+        frag(wo, C, 128, attn_prefix + ".to_out#site");
+    }
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -629,7 +654,16 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             E.prof_begin(5, 2.0 * Bp * L * 1024.0 * C + (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));
             for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
 #define SITE_LAUNCH(C_, NT_, PF_) hipLaunchKernelGGL((attn1d_site_kernel<C_, NT_, PF_>), grid, dim3(256), 0, E.stream, s)
-                if (NTsel == 2) {
+#define SITE_LAUNCH_H3(C_, NT_, PF_) hipLaunchKernelGGL((attn1d_site_h3_kernel<C_, NT_, PF_>), grid, dim3(256), 0, E.stream, s)
+                if (site->second.h3) {
+                    if (NTsel == 2) {
+                        if (C == 64) SITE_LAUNCH_H3(64, 2, 2); else if (C == 128) SITE_LAUNCH_H3(128, 2, 3);
+                        else if (C == 256) SITE_LAUNCH_H3(256, 2, 3); else SITE_LAUNCH_H3(512, 2, 3);
+                    } else {
+                        if (C == 64) SITE_LAUNCH_H3(64, 1, 2); else if (C == 128) SITE_LAUNCH_H3(128, 1, 3);
+                        else if (C == 256) SITE_LAUNCH_H3(256, 1, 3); else SITE_LAUNCH_H3(512, 1, 3);
+                    }
+                } else if (NTsel == 2) {
                     if (C == 64) SITE_LAUNCH(64, 2, 4); else if (C == 128) SITE_LAUNCH(128, 2, 4);
                     else if (C == 256) SITE_LAUNCH(256, 2, 4); else SITE_LAUNCH(512, 2, 4);
                 } else {
@@ -637,6 +671,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
                     else if (C == 256) SITE_LAUNCH(256, 1, 4); else SITE_LAUNCH(512, 1, 4);
                 }
 #undef SITE_LAUNCH
+#undef SITE_LAUNCH_H3
             }
             E.prof_end();
         }
@@ -726,16 +761,18 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
     Ten cur; cur.p = const_cast<float*>(x); cur.L = d.horizon; cur.C = d.transition_dim; cur.ld = d.transition_dim;
     std::vector<Ten> skips;
     float* lnp = nullptr;
+    // LayerNorm row partials from the producer are only needed where the attention site is not one fused launch
+    auto need_ln = [&](const std::string& ap, int L) { return att && !(h->packed.count(ap + ".fn.fn.to_qkv#site") && L <= 32); };
     for (int ind = 0; ind < nres; ++ind) {
         const int co = h->dims[ind + 1];
         const std::string p = "downs." + std::to_string(ind);
         cur = emit_rtb(E, p + ".0", cur, nullptr, co, false, nullptr);
-        cur = emit_rtb(E, p + ".1", cur, nullptr, co, att, &lnp);
+        cur = emit_rtb(E, p + ".1", cur, nullptr, co, need_ln(p + ".2", cur.L), &lnp);
         if (att) cur = emit_attn(E, p + ".2", cur, lnp);
         skips.push_back(cur);
         if (h->packed.count(p + ".3.conv")) cur = emit_resample(E, p + ".3", cur, false);
     }
-    cur = emit_rtb(E, "mid_block1", cur, nullptr, h->dims[nres], att, &lnp);
+    cur = emit_rtb(E, "mid_block1", cur, nullptr, h->dims[nres], need_ln("mid_attn", cur.L), &lnp);
     if (att) cur = emit_attn(E, "mid_attn", cur, lnp);
     cur = emit_rtb(E, "mid_block2", cur, nullptr, h->dims[nres], false, nullptr);
     for (int ind = 0; ind < nres - 1; ++ind) {
@@ -743,7 +780,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
         const std::string p = "ups." + std::to_string(ind);
         Ten skip = skips.back(); skips.pop_back();
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
-        cur = emit_rtb(E, p + ".1", cur, nullptr, ci, att, &lnp);
+        cur = emit_rtb(E, p + ".1", cur, nullptr, ci, need_ln(p + ".2", cur.L), &lnp);
         if (att) cur = emit_attn(E, p + ".2", cur, lnp);
         if (h->packed.count(p + ".3.conv")) cur = emit_resample(E, p + ".3", cur, true);
     }

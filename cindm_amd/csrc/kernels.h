@@ -885,6 +885,83 @@ struct AttnSiteArgs {
     int dbg;               // timing ablations (wrong results): 1 no qkv loop, 2 no projection, 3 no core
 };
 
+// Core of a site for the head of this wave, per sample s of the workgroup: q *= 32^-1/2 ; k = softmax over the sample's
+// positions ; ctx_s = k v^T ; att = ctx_s^T q.  qa: rows = channels, cols = positions; ka, va: rows = positions, cols =
+// channels (accumulator layouts of the 16x16 MFMAs); att: rows = e, cols = positions.
+template <int NT>
+__device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[NT][2], f32x4 (&va)[NT][2], f32x4 (&att)[2][NT],
+                                               int s_here, int nend, int slot, int L, int lq, int lr) {
+    const float scale = 0.17677669529663687f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) qa[i][nt] *= scale;
+    // sample of each accumulator row (k, v: rows = positions nt*16 + lq*4 + i) and column (q: cols = positions nt*16 + lr)
+    int sid_row[NT][4], sid_col[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int n = nt * 16 + lq * 4 + i; sid_row[nt][i] = (n < nend && n % slot < L) ? n / slot : -1; }
+        const int n = nt * 16 + lr;
+        sid_col[nt] = (n < nend && n % slot < L) ? n / slot : -1;
+    }
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) att[et][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; s < s_here; ++s) {
+        f32x4 ks[NT][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (sid_row[nt][i] == s) mx = fmaxf(mx, ka[nt][dt][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = (sid_row[nt][i] == s) ? __builtin_amdgcn_exp2f((ka[nt][dt][i] - mx) * 1.4426950408889634f) : 0.f;
+                    ks[nt][dt][i] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ks[nt][dt] *= inv;
+        }
+        f32x4 ctx[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[nt][dt][i], va[nt][et][i], c, 0, 0, 0);
+                ctx[dt][et] = c;
+            }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool mine = sid_col[nt] == s;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        att[et][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ctx[dt][et][i], mine ? qa[dt][nt][i] : 0.f, att[et][nt], 0, 0, 0);
+            }
+    }
+}
+
 template <int C, int NT, int PF>
 __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) {
     constexpr int NP = NT * 16, YP = C + 4, AP = 132, K16 = C / 16, CT = C / 16;
@@ -1009,77 +1086,9 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
 #pragma unroll
         for (int k = 0; k < 8; ++k) wo[t][k] = (t < TPW) ? Wo4[((size_t)(w * TPW + t) * 8 + k) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- core, per sample s: q *= 32^-1/2 ; k = softmax over the sample's positions ; ctx_s = k v^T ; att = ctx_s^T q ----
-    const float scale = 0.17677669529663687f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) qa[i][nt] *= scale;
-    // sample of each accumulator row (k, v: rows = positions nt*16 + lq*4 + i) and column (q: cols = positions nt*16 + lr)
-    int sid_row[NT][4], sid_col[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int n = nt * 16 + lq * 4 + i; sid_row[nt][i] = (n < nend && n % slot < L) ? n / slot : -1; }
-        const int n = nt * 16 + lr;
-        sid_col[nt] = (n < nend && n % slot < L) ? n / slot : -1;
-    }
+    // ---- core ----
     f32x4 att[2][NT];
-#pragma unroll
-    for (int et = 0; et < 2; ++et)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) att[et][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int s = 0; s < (a.dbg == 3 ? 0 : s_here); ++s) {
-        f32x4 ks[NT][2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (sid_row[nt][i] == s) mx = fmaxf(mx, ka[nt][dt][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float e = (sid_row[nt][i] == s) ? __builtin_amdgcn_exp2f((ka[nt][dt][i] - mx) * 1.4426950408889634f) : 0.f;
-                    ks[nt][dt][i] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) ks[nt][dt] *= inv;
-        }
-        f32x4 ctx[2][2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int et = 0; et < 2; ++et) {
-                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ks[nt][dt][i], va[nt][et][i], c, 0, 0, 0);
-                ctx[dt][et] = c;
-            }
-#pragma unroll
-        for (int et = 0; et < 2; ++et)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const bool mine = sid_col[nt] == s;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        att[et][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ctx[dt][et][i], mine ? qa[dt][nt][i] : 0.f, att[et][nt], 0, 0, 0);
-            }
-    }
+    attn_site_core<NT>(qa, ka, va, att, a.dbg == 3 ? 0 : s_here, nend, slot, L, lq, lr);
 #pragma unroll
     for (int et = 0; et < 2; ++et)
 #pragma unroll
@@ -1126,6 +1135,226 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
                 const float4 xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
                 float4 o;
                 o.x = z[nt][0] + b.x + xv.x; o.y = z[nt][1] + b.y + xv.y; o.z = z[nt][2] + b.z + xv.z; o.w = z[nt][3] + b.w + xv.w;
+                *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
+            }
+        }
+    }
+}
+
+// The same site with the two projections (to_qkv, to_out) on the split-fp16 scheme of conv_gemm_h3_kernel: LN(x)g and
+// att are staged as (hi, scaled lo) fp16 planes, the weights are pre-split on the host; three
+// v_mfma_f32_16x16x32_f16 per 32 channels instead of eight fp32 MFMAs.  The attention core stays in fp32 (its
+// operands are accumulators).  Weight fragments: [tile of 16 channels][k32][plane][lane][8 halfs], element e <->
+// k = k32*32 + (lane/16)*8 + e.
+template <int C, int NT, int PF>
+__global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs a) {
+    constexpr int NP = NT * 16, K32 = C / 32, CT = C / 16;
+    constexpr int YPB = 2 * C + 16;                      // bytes per position per plane (pad keeps b128 reads conflict-free)
+    constexpr int APB = 2 * 128 + 16;
+    constexpr int CH = (C + 255) / 256;
+    constexpr int RW = NP / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NP * YPB];      // [plane][position]
+    __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NP * APB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int L = a.L;
+    const int s_here = min(a.S, a.Bp - (int)blockIdx.x * a.S);
+    const int slot = a.slot;
+    const int nend = s_here * slot;
+    const size_t row0 = (size_t)blockIdx.x * a.S * L;
+    const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);      // one float4 = 8 halfs
+    int tile[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) tile[s] = (s >> 1) * 8 + 2 * w + (s & 1);
+    // weight ring: PF k32-steps in flight, [tile][plane]
+    float4 wr[PF][6][2];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                wr[p][s][pl] = (p < K32) ? Wq4[(((size_t)tile[s] * K32 + p) * 2 + pl) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- LayerNorm (as in attn1d_site_kernel), result split into the two fp16 planes ----
+    {
+        constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;
+        constexpr int RPP = 64 / LPR;
+        constexpr int NPASS = (RW + RPP - 1) / RPP;
+        const int lrow = lane / LPR, lcol = lane % LPR;
+        float4 xr[NPASS][CH];
+        bool okr[NPASS];
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
+            okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
+#pragma unroll
+            for (int m = 0; m < CH; ++m)
+                xr[r][m] = okr[r] ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + 4 * (lcol + LPR * m)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 gv[CH];
+#pragma unroll
+        for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = w * RW + r * RPP + lrow;
+            float s1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
+#pragma unroll
+            for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            const float mean = s1 * (1.0f / C);
+            float s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+#pragma unroll
+            for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            if (r * RPP + lrow < RW) {
+#pragma unroll
+                for (int m = 0; m < CH; ++m) {
+                    float4 y;
+                    y.x = (xr[r][m].x - mean) * rstd * gv[m].x; y.y = (xr[r][m].y - mean) * rstd * gv[m].y;
+                    y.z = (xr[r][m].z - mean) * rstd * gv[m].z; y.w = (xr[r][m].w - mean) * rstd * gv[m].w;
+                    if (!okr[r]) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    half4v hi, lo;
+                    hi[0] = (_Float16)y.x; hi[1] = (_Float16)y.y; hi[2] = (_Float16)y.z; hi[3] = (_Float16)y.w;
+                    lo[0] = (_Float16)((y.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y.y - (float)hi[1]) * H3_SCALE);
+                    lo[2] = (_Float16)((y.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y.w - (float)hi[3]) * H3_SCALE);
+                    const int off = n * YPB + 8 * (lcol + LPR * m);
+                    *reinterpret_cast<half4v*>(&Yp[0][off]) = hi;
+                    *reinterpret_cast<half4v*>(&Yp[1][off]) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- q, k, v of head w: main and low-order accumulators ----
+    f32x4 qM[2][NT], qL[2][NT], kM[NT][2], kL[NT][2], vM[NT][2], vL[NT][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            qM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; qL[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; kL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; vL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    if (a.dbg != 1)
+#pragma unroll
+    for (int k32 = 0; k32 < K32; ++k32) {
+        half8 wh[6], wl[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { wh[s] = __builtin_bit_cast(half8, wr[k32 % PF][s][0]); wl[s] = __builtin_bit_cast(half8, wr[k32 % PF][s][1]); }
+        if (k32 + PF < K32) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wr[k32 % PF][s][pl] = Wq4[(((size_t)tile[s] * K32 + k32 + PF) * 2 + pl) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int off = (nt * 16 + lr) * YPB + k32 * 64 + lq * 16;
+            const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+            const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                qM[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], yh, qM[i][nt], 0, 0, 0);
+                qL[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], yl, qL[i][nt], 0, 0, 0);
+                qL[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], yh, qL[i][nt], 0, 0, 0);
+                kM[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[2 + i], kM[nt][i], 0, 0, 0);
+                kL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[2 + i], kL[nt][i], 0, 0, 0);
+                kL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[2 + i], kL[nt][i], 0, 0, 0);
+                vM[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[4 + i], vM[nt][i], 0, 0, 0);
+                vL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[4 + i], vL[nt][i], 0, 0, 0);
+                vL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[4 + i], vL[nt][i], 0, 0, 0);
+            }
+        }
+    }
+    f32x4 qa[2][NT], ka[NT][2], va[NT][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            qa[i][j] = qM[i][j] + qL[i][j] * H3_INV;
+            ka[j][i] = kM[j][i] + kL[j][i] * H3_INV;
+            va[j][i] = vM[j][i] + vL[j][i] * H3_INV;
+        }
+    // projection weights of this wave's first tiles: in flight during the attention core
+    const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
+    static_assert(CT % 4 == 0, "output channel tiles are split evenly over the four waves");
+    constexpr int TPW = CT / 4;
+    constexpr int WOR = 3;
+    float4 wo[WOR][4][2];                                // [ring][k32][plane]
+#pragma unroll
+    for (int t = 0; t < WOR - 1; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                wo[t][k][pl] = (t < TPW) ? Wo4[(((size_t)(w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- core ----
+    f32x4 att[2][NT];
+    attn_site_core<NT>(qa, ka, va, att, a.dbg == 3 ? 0 : s_here, nend, slot, L, lq, lr);
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 v = att[et][nt];
+            half4v hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)((v[i] - (float)hi[i]) * H3_SCALE); }
+            const int off = (nt * 16 + lr) * APB + 2 * (w * 32 + et * 16 + lq * 4);
+            *reinterpret_cast<half4v*>(&Ap[0][off]) = hi;
+            *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
+        }
+    __syncthreads();
+
+    // ---- out = Wo att + bo + x ----
+    if (a.dbg != 2)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int ct = w * TPW + t;
+        if (t + WOR - 1 < TPW) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wo[(t + WOR - 1) % WOR][k][pl] = Wo4[(((size_t)(ct + WOR - 1) * 4 + k) * 2 + pl) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 zM[NT], zL[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { zM[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; zL[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half8 wh = __builtin_bit_cast(half8, wo[t % WOR][k][0]), wl = __builtin_bit_cast(half8, wo[t % WOR][k][1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (nt * 16 + lr) * APB + k * 64 + lq * 16;
+                const half8 ah = *reinterpret_cast<const half8*>(&Ap[0][off]);
+                const half8 al = *reinterpret_cast<const half8*>(&Ap[1][off]);
+                zM[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, zM[nt], 0, 0, 0);
+                zL[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, zL[nt], 0, 0, 0);
+                zL[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, zL[nt], 0, 0, 0);
+            }
+        }
+        const int c = ct * 16 + lq * 4;
+        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 z = zM[nt] + zL[nt] * H3_INV;
+            const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
+            if (n < nend && pn < L) {
+                const size_t row = row0 + sn * L + pn;
+                const float4 xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+                float4 o;
+                o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
                 *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
             }
         }
