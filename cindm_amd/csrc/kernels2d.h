@@ -1221,6 +1221,328 @@ __global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Residual(PreNorm(LinearAttention)) without the [pixels, 384] q|k|v tensor (model/diffusion_2d.py:226-254):
+//   la2d_context_kernel   per (image, 128-pixel slice), wave = head: y = LN(x) g as split-fp16 planes, k|v of the
+//                         head = y Wkv^T (rows = pixels) on the fp16 MFMA, slice softmax of k over pixels, partial
+//                         context k^ v^T on the fp32 MFMA (its operands are the k, v accumulators)
+//   la2d_merge_kernel     slices -> ctx[image][head][32][32], normalised, / (h w)
+//   la2d_apply_out_kernel per (image, 64 pixels): y again, q = Wq y^T, softmax over d, * 32^-1/2, att = ctx^T q,
+//                         z = Wo att + b, out = LN(z) g2 + x
+// HBM traffic per site: x twice, out once (the unfused path moved 7 x that).  Projection operands are the fragments
+// of attn1d_site_h3_kernel ([tile][k32][plane][lane][8 halfs]).
+struct La2dArgs {
+    const float* x; int ldx;       // [NI * HW, C]
+    float* out; int ldo;
+    const float* g;                // PreNorm gain [C]
+    const float* g2;               // to_out LayerNorm gain [C]
+    const float* Wqkv;             // 24 tiles x C
+    const float* Wo;               // C/16 tiles x 128
+    const float* bo;               // [C]
+    float* part;                   // [NI*4][nsplit][64 + 1024]: slice max | slice sum | unnormalised context
+    float* ctx;                    // [NI*4][1024]
+    int HW, nsplit;
+};
+constexpr int LA2_PX = 128;        // pixels per context slice
+constexpr int LA2_REC = 64 + 1024;
+
+// rows [0, NPX) of a tile -> LayerNorm over C channels (biased variance, eps 1e-5) * g -> (hi, scaled lo) fp16 planes
+template <int C, int NPX>
+__device__ __forceinline__ void ln_tile_to_planes(const float* __restrict__ x0, int ldx, const float* __restrict__ g,
+                                                  unsigned char* Yh, unsigned char* Yl, int tid) {
+    constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 16;
+    const int lrow = tid / LPR, lcol = tid % LPR;
+    float4 xr[NPASS];
+#pragma unroll
+    for (int r = 0; r < NPASS; ++r) xr[r] = *reinterpret_cast<const float4*>(x0 + (size_t)(r * RPP + lrow) * ldx + 4 * lcol);
+    const float4 gv = *reinterpret_cast<const float4*>(g + 4 * lcol);
+#pragma unroll
+    for (int r = 0; r < NPASS; ++r) {
+        float s1 = (xr[r].x + xr[r].y) + (xr[r].z + xr[r].w);
+#pragma unroll
+        for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 * (1.0f / C);
+        const float d0 = xr[r].x - mean, d1 = xr[r].y - mean, d2 = xr[r].z - mean, d3 = xr[r].w - mean;
+        float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+        for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+        const float y0 = d0 * rstd * gv.x, y1 = d1 * rstd * gv.y, y2 = d2 * rstd * gv.z, y3 = d3 * rstd * gv.w;
+        half4v hi, lo;
+        hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+        lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
+        lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
+        const int off = (r * RPP + lrow) * YPB + 8 * lcol;
+        *reinterpret_cast<half4v*>(Yh + off) = hi;
+        *reinterpret_cast<half4v*>(Yl + off) = lo;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = LA2_PX / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char Yp[2][LA2_PX * YPB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int img = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
+    const float* x0 = a.x + ((size_t)img * a.HW + (size_t)split * LA2_PX) * a.ldx;
+    // k | v fragments of head w, resident: tiles 8 + 2w, 9 + 2w (k), 16 + 2w, 17 + 2w (v)
+    const float4* W4 = reinterpret_cast<const float4*>(a.Wqkv);
+    half8 wh[4][K32], wl[4][K32];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int tile = 8 + (s >> 1) * 8 + 2 * w + (s & 1);
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            wh[s][k] = __builtin_bit_cast(half8, W4[(((size_t)tile * K32 + k) * 2 + 0) * 64 + lane]);
+            wl[s][k] = __builtin_bit_cast(half8, W4[(((size_t)tile * K32 + k) * 2 + 1) * 64 + lane]);
+        }
+    }
+    ln_tile_to_planes<C, LA2_PX>(x0, a.ldx, a.g, Yp[0], Yp[1], tid);
+    __syncthreads();
+    // k, v: rows = pixels (8 tiles of 16), cols = the head's 32 channels
+    f32x4 kk[NTL][2], vv[NTL][2];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        f32x4 M[4], Lo[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
+            const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+            const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[s][k], M[s], 0, 0, 0);
+                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[s][k], Lo[s], 0, 0, 0);
+                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[s][k], Lo[s], 0, 0, 0);
+            }
+        }
+        kk[nt][0] = M[0] + Lo[0] * H3_INV; kk[nt][1] = M[1] + Lo[1] * H3_INV;
+        vv[nt][0] = M[2] + Lo[2] * H3_INV; vv[nt][1] = M[3] + Lo[3] * H3_INV;
+    }
+    // slice softmax of k over the 128 pixels, per channel d = dt*16 + lr (pixels: rows nt*16 + lq*4 + i)
+    float* rec = a.part + ((size_t)(img * 4 + w) * a.nsplit + split) * LA2_REC;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, kk[nt][dt][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = __builtin_amdgcn_exp2f((kk[nt][dt][i] - mx) * 1.4426950408889634f);
+                kk[nt][dt][i] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lq == 0) { rec[dt * 16 + lr] = mx; rec[32 + dt * 16 + lr] = sum; }
+    }
+    // unnormalised partial context [d][e] = sum_pixels e^(k - max) v : two chains per output tile
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NTL; nt += 2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[nt][dt][i], vv[nt][et][i], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[nt + 1][dt][i], vv[nt + 1][et][i], c1, 0, 0, 0);
+                }
+            c0 += c1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rec[64 + (dt * 16 + lq * 4 + i) * 32 + et * 16 + lr] = c0[i];
+        }
+}
+
+__global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int nsplit, int HW) {
+    __shared__ float wgt[64 * 32];
+    const int ih = blockIdx.x;
+    const float* p = part + (size_t)ih * nsplit * LA2_REC;
+    if (threadIdx.x < 32) {
+        const int d = threadIdx.x;
+        float M = p[d];
+        for (int sp = 1; sp < nsplit; ++sp) M = fmaxf(M, p[(size_t)sp * LA2_REC + d]);
+        float S = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float e = __builtin_amdgcn_exp2f((p[(size_t)sp * LA2_REC + d] - M) * 1.4426950408889634f);
+            wgt[sp * 32 + d] = e;
+            S += p[(size_t)sp * LA2_REC + 32 + d] * e;
+        }
+        const float inv = 1.0f / (S * (float)HW);         // softmax denominator and v / (h w)
+        for (int sp = 0; sp < nsplit; ++sp) wgt[sp * 32 + d] *= inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += p[(size_t)sp * LA2_REC + 64 + i] * wgt[sp * 32 + (i >> 5)];
+        ctx[(size_t)ih * 1024 + i] = s;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];
+    __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NPX * APB];
+    static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "Z aliases the y planes");
+    float* Z = reinterpret_cast<float*>(&Yp[0][0]);       // the y planes are dead once every wave has its q (second barrier)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int tiles = a.HW / NPX;
+    const int img = blockIdx.x / tiles, t = blockIdx.x % tiles;
+    const size_t row0 = (size_t)img * a.HW + (size_t)t * NPX;
+    const float* x0 = a.x + row0 * a.ldx;
+    const float4* W4 = reinterpret_cast<const float4*>(a.Wqkv);
+    const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
+    half8 qh[2][K32], ql[2][K32];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            qh[s][k] = __builtin_bit_cast(half8, W4[(((size_t)(2 * w + s) * K32 + k) * 2 + 0) * 64 + lane]);
+            ql[s][k] = __builtin_bit_cast(half8, W4[(((size_t)(2 * w + s) * K32 + k) * 2 + 1) * 64 + lane]);
+        }
+    half8 oh[TPW][4], ol[TPW][4];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            oh[s][k] = __builtin_bit_cast(half8, Wo4[(((size_t)(w * TPW + s) * 4 + k) * 2 + 0) * 64 + lane]);
+            ol[s][k] = __builtin_bit_cast(half8, Wo4[(((size_t)(w * TPW + s) * 4 + k) * 2 + 1) * 64 + lane]);
+        }
+    // merged context of head w as A fragments of the second product: lane holds ctx[d = dt*16 + lq*4 + i][e = et*16 + lr]
+    float cf[2][2][4];
+    {
+        const float* cp = a.ctx + (size_t)(img * 4 + w) * 1024;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cf[dt][et][i] = cp[(dt * 16 + lq * 4 + i) * 32 + et * 16 + lr];
+    }
+    ln_tile_to_planes<C, NPX>(x0, a.ldx, a.g, Yp[0], Yp[1], tid);
+    __syncthreads();
+    // q of head w: rows = channels d, cols = pixels
+    f32x4 q[2][NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        f32x4 M[2], Lo[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
+            const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+            const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s][k], yh, M[s], 0, 0, 0);
+                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s][k], yl, Lo[s], 0, 0, 0);
+                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s][k], yh, Lo[s], 0, 0, 0);
+            }
+        }
+        q[0][nt] = M[0] + Lo[0] * H3_INV; q[1][nt] = M[1] + Lo[1] * H3_INV;
+    }
+    // softmax over d (rows: dt, lq, i) for each pixel column, then * 32^-1/2 ; att = ctx^T q
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, q[dt][nt][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = __builtin_amdgcn_exp2f((q[dt][nt][i] - mx) * 1.4426950408889634f);
+                q[dt][nt][i] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) q[dt][nt] = (q[dt][nt] * inv) * 0.17677669529663687f;
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[dt][et][i], q[dt][nt][i], o, 0, 0, 0);
+            half4v hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)o[i]; lo[i] = (_Float16)((o[i] - (float)hi[i]) * H3_SCALE); }
+            const int off = (nt * 16 + lr) * APB + 2 * (w * 32 + et * 16 + lq * 4);
+            *reinterpret_cast<half4v*>(&Ap[0][off]) = hi;
+            *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
+        }
+    }
+    __syncthreads();
+    // z = Wo att + bo : channel tiles [w*TPW, (w+1)*TPW) of this wave, all 64 pixels -> Z[pixel][channel]
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+        const int c = (w * TPW + s) * 16 + lq * 4;
+        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            f32x4 zM = f32x4{0.f, 0.f, 0.f, 0.f}, zL = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int off = (nt * 16 + lr) * APB + k * 64 + lq * 16;
+                const half8 ah = *reinterpret_cast<const half8*>(&Ap[0][off]);
+                const half8 al = *reinterpret_cast<const half8*>(&Ap[1][off]);
+                zM = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s][k], ah, zM, 0, 0, 0);
+                zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s][k], al, zL, 0, 0, 0);
+                zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s][k], ah, zL, 0, 0, 0);
+            }
+            const f32x4 z = zM + zL * H3_INV;
+            *reinterpret_cast<float4*>(&Z[(nt * 16 + lr) * ZP + c]) = make_float4(z[0] + b.x, z[1] + b.y, z[2] + b.z, z[3] + b.w);
+        }
+    }
+    __syncthreads();
+    // out = LayerNorm(z) g2 + x
+    {
+        constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP;
+        const int lrow = tid / LPR, lcol = tid % LPR;
+        const float4 gv = *reinterpret_cast<const float4*>(a.g2 + 4 * lcol);
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = r * RPP + lrow;
+            const float4 zv = *reinterpret_cast<const float4*>(&Z[n * ZP + 4 * lcol]);
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (row0 + n) * a.ldx + 4 * lcol);
+            float s1 = (zv.x + zv.y) + (zv.z + zv.w);
+#pragma unroll
+            for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            const float mean = s1 * (1.0f / C);
+            const float d0 = zv.x - mean, d1 = zv.y - mean, d2 = zv.z - mean, d3 = zv.w - mean;
+            float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+            for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            float4 o4;
+            o4.x = d0 * rstd * gv.x + xv.x; o4.y = d1 * rstd * gv.y + xv.y; o4.z = d2 * rstd * gv.z + xv.z; o4.w = d3 * rstd * gv.w + xv.w;
+            *reinterpret_cast<float4*>(a.out + (row0 + n) * a.ldo + 4 * lcol) = o4;
+        }
+    }
+}
+
 // out = LayerNorm_channels(z) * g + x   (LinearAttention's to_out[1] and the Residual, :126-135, :96-97); one wave per pixel row.
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                           const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C) {
