@@ -1241,50 +1241,76 @@ struct La2dArgs {
     const float* bo;               // [C]
     float* part;                   // [NI*4][nsplit][64 + 1024]: slice max | slice sum | unnormalised context
     float* ctx;                    // [NI*4][1024]
-    int HW, nsplit;
+    int HW, nsplit;                // nsplit = context workgroups (records) per image
+    int spw, tpw;                  // 128-pixel slices per context workgroup ; 64-pixel tiles per apply workgroup
+    int dbg;                       // timing ablations (wrong results)
 };
 constexpr int LA2_PX = 128;        // pixels per context slice
 constexpr int LA2_REC = 64 + 1024;
 
-// rows [0, NPX) of a tile -> LayerNorm over C channels (biased variance, eps 1e-5) * g -> (hi, scaled lo) fp16 planes
-template <int C, int NPX>
-__device__ __forceinline__ void ln_tile_to_planes(const float* __restrict__ x0, int ldx, const float* __restrict__ g,
-                                                  unsigned char* Yh, unsigned char* Yl, int tid) {
-    constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 16;
-    const int lrow = tid / LPR, lcol = tid % LPR;
-    float4 xr[NPASS];
-#pragma unroll
-    for (int r = 0; r < NPASS; ++r) xr[r] = *reinterpret_cast<const float4*>(x0 + (size_t)(r * RPP + lrow) * ldx + 4 * lcol);
-    const float4 gv = *reinterpret_cast<const float4*>(g + 4 * lcol);
-#pragma unroll
-    for (int r = 0; r < NPASS; ++r) {
-        float s1 = (xr[r].x + xr[r].y) + (xr[r].z + xr[r].w);
-#pragma unroll
-        for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
-        const float mean = s1 * (1.0f / C);
-        const float d0 = xr[r].x - mean, d1 = xr[r].y - mean, d2 = xr[r].z - mean, d3 = xr[r].w - mean;
-        float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-        for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-        const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
-        const float y0 = d0 * rstd * gv.x, y1 = d1 * rstd * gv.y, y2 = d2 * rstd * gv.z, y3 = d3 * rstd * gv.w;
-        half4v hi, lo;
-        hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
-        lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
-        lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
-        const int off = (r * RPP + lrow) * YPB + 8 * lcol;
-        *reinterpret_cast<half4v*>(Yh + off) = hi;
-        *reinterpret_cast<half4v*>(Yl + off) = lo;
-    }
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror:8, row_ror:4, two quad permutes: VALU speed, no LDS);
+// LPR = 32 adds the neighbouring row with one cross-lane exchange
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int LPR>
+__device__ __forceinline__ float rowgroup_sum(float v) {
+    static_assert(LPR == 16 || LPR == 32, "16 or 32 lanes per row");
+    v += dpp_get<0x128>(v);
+    v += dpp_get<0x124>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0xB1>(v);
+    if (LPR == 32) v += __shfl_xor(v, 16, 64);
+    return v;
 }
 
+// LayerNorm over C channels (biased variance, eps 1e-5) * g of the NPX tile rows held in xr (thread (lrow, lcol) owns
+// columns 4*lcol.. of rows r*RPP + lrow) -> (hi, scaled lo) fp16 planes
+template <int C, int NPX>
+struct LnTile {
+    static constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 16;
+    __device__ static __forceinline__ void load(float4 (&xr)[NPASS], const float* __restrict__ x0, int ldx, int tid) {
+        const int lrow = tid / LPR, lcol = tid % LPR;
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) xr[r] = *reinterpret_cast<const float4*>(x0 + (size_t)(r * RPP + lrow) * ldx + 4 * lcol);
+    }
+    __device__ static __forceinline__ void to_planes(const float4 (&xr)[NPASS], const float4 gv, unsigned char* Yh, unsigned char* Yl, int tid) {
+        const int lrow = tid / LPR, lcol = tid % LPR;
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const float s1 = rowgroup_sum<LPR>((xr[r].x + xr[r].y) + (xr[r].z + xr[r].w));
+            const float mean = s1 * (1.0f / C);
+            const float d0 = xr[r].x - mean, d1 = xr[r].y - mean, d2 = xr[r].z - mean, d3 = xr[r].w - mean;
+            const float s2 = rowgroup_sum<LPR>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            const float y0 = d0 * rstd * gv.x, y1 = d1 * rstd * gv.y, y2 = d2 * rstd * gv.z, y3 = d3 * rstd * gv.w;
+            half4v hi, lo;
+            hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+            lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
+            const int off = (r * RPP + lrow) * YPB + 8 * lcol;
+            *reinterpret_cast<half4v*>(Yh + off) = hi;
+            *reinterpret_cast<half4v*>(Yl + off) = lo;
+        }
+    }
+};
+
+// One workgroup = a.spw consecutive 128-pixel slices of one image (the next slice's rows are in flight while the
+// current one is processed); running maximum / sum / context are rescaled slice by slice (online softmax), one record
+// per workgroup.
 template <int C>
 __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
+    using LN = LnTile<C, LA2_PX>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = LA2_PX / 16;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][LA2_PX * YPB];
+    __shared__ float fac[4][32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int img = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
-    const float* x0 = a.x + ((size_t)img * a.HW + (size_t)split * LA2_PX) * a.ldx;
+    const float* x0 = a.x + ((size_t)img * a.HW + (size_t)split * a.spw * LA2_PX) * a.ldx;
+    float4 xr[LN::NPASS];
+    LN::load(xr, x0, a.ldx, tid);
+    const float4 gv = *reinterpret_cast<const float4*>(a.g + 4 * (tid % LN::LPR));
     // k | v fragments of head w, resident: tiles 8 + 2w, 9 + 2w (k), 16 + 2w, 17 + 2w (v)
     const float4* W4 = reinterpret_cast<const float4*>(a.Wqkv);
     half8 wh[4][K32], wl[4][K32];
@@ -1297,71 +1323,96 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
             wl[s][k] = __builtin_bit_cast(half8, W4[(((size_t)tile * K32 + k) * 2 + 1) * 64 + lane]);
         }
     }
-    ln_tile_to_planes<C, LA2_PX>(x0, a.ldx, a.g, Yp[0], Yp[1], tid);
-    __syncthreads();
-    // k, v: rows = pixels (8 tiles of 16), cols = the head's 32 channels
-    f32x4 kk[NTL][2], vv[NTL][2];
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        f32x4 M[4], Lo[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int k = 0; k < K32; ++k) {
-            const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
-            const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
-            const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[s][k], M[s], 0, 0, 0);
-                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[s][k], Lo[s], 0, 0, 0);
-                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[s][k], Lo[s], 0, 0, 0);
-            }
-        }
-        kk[nt][0] = M[0] + Lo[0] * H3_INV; kk[nt][1] = M[1] + Lo[1] * H3_INV;
-        vv[nt][0] = M[2] + Lo[2] * H3_INV; vv[nt][1] = M[3] + Lo[3] * H3_INV;
-    }
-    // slice softmax of k over the 128 pixels, per channel d = dt*16 + lr (pixels: rows nt*16 + lq*4 + i)
-    float* rec = a.part + ((size_t)(img * 4 + w) * a.nsplit + split) * LA2_REC;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, kk[nt][dt][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = __builtin_amdgcn_exp2f((kk[nt][dt][i] - mx) * 1.4426950408889634f);
-                kk[nt][dt][i] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        if (lq == 0) { rec[dt * 16 + lr] = mx; rec[32 + dt * 16 + lr] = sum; }
-    }
-    // unnormalised partial context [d][e] = sum_pixels e^(k - max) v : two chains per output tile
+    float run_m[2] = {-INFINITY, -INFINITY}, run_s[2] = {0.f, 0.f};       // per channel d = dt*16 + lr
+    f32x4 ctx[2][2];                                                       // rows d = dt*16 + lq*4 + i, cols e = et*16 + lr
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int et = 0; et < 2; ++et) {
-            f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int et = 0; et < 2; ++et) ctx[dt][et] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int sl = 0; sl < a.spw; ++sl) {
+        LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
+        __syncthreads();
+        if (sl + 1 < a.spw) LN::load(xr, x0 + (size_t)(sl + 1) * LA2_PX * a.ldx, a.ldx, tid);
+        // k, v: rows = pixels (8 tiles of 16), cols = the head's 32 channels
+        f32x4 kk[NTL][2], vv[NTL][2];
 #pragma unroll
-            for (int nt = 0; nt < NTL; nt += 2)
+        for (int nt = 0; nt < NTL; ++nt) {
+            f32x4 M[4], Lo[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int k = 0; k < K32; ++k) {
+                const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
+                const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+                const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[s][k], M[s], 0, 0, 0);
+                    Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[s][k], Lo[s], 0, 0, 0);
+                    Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[s][k], Lo[s], 0, 0, 0);
+                }
+            }
+            kk[nt][0] = M[0] + Lo[0] * H3_INV; kk[nt][1] = M[1] + Lo[1] * H3_INV;
+            vv[nt][0] = M[2] + Lo[2] * H3_INV; vv[nt][1] = M[3] + Lo[3] * H3_INV;
+        }
+        // online softmax of k over pixels, per channel d = dt*16 + lr (pixels: rows nt*16 + lq*4 + i)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, kk[nt][dt][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(run_m[dt], mx);
+            const float f = __builtin_amdgcn_exp2f((run_m[dt] - mnew) * 1.4426950408889634f);      // 0 on the first slice
+            float sum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[nt][dt][i], vv[nt][et][i], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[nt + 1][dt][i], vv[nt + 1][et][i], c1, 0, 0, 0);
+                    const float e = __builtin_amdgcn_exp2f((kk[nt][dt][i] - mnew) * 1.4426950408889634f);
+                    kk[nt][dt][i] = e;
+                    sum += e;
                 }
-            c0 += c1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rec[64 + (dt * 16 + lq * 4 + i) * 32 + et * 16 + lr] = c0[i];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            run_s[dt] = run_s[dt] * f + sum;
+            run_m[dt] = mnew;
+            if (lq == 0) fac[w][dt * 16 + lr] = f;
         }
+        __syncthreads();                                  // fac visible; every wave is done reading the planes
+        // ctx = ctx * f[d] + sum_pixels e^(k - m) v
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const float4 f4 = *reinterpret_cast<const float4*>(&fac[w][dt * 16 + lq * 4]);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                f32x4 c0 = ctx[dt][et], c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                c0[0] *= f4.x; c0[1] *= f4.y; c0[2] *= f4.z; c0[3] *= f4.w;
+#pragma unroll
+                for (int nt = 0; nt < NTL; nt += 2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[nt][dt][i], vv[nt][et][i], c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[nt + 1][dt][i], vv[nt + 1][et][i], c1, 0, 0, 0);
+                    }
+                ctx[dt][et] = c0 + c1;
+            }
+        }
+    }
+    float* rec = a.part + ((size_t)(img * 4 + w) * a.nsplit + split) * LA2_REC;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        if (lq == 0) { rec[dt * 16 + lr] = run_m[dt]; rec[32 + dt * 16 + lr] = run_s[dt]; }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rec[64 + (dt * 16 + lq * 4 + i) * 32 + et * 16 + lr] = ctx[dt][et][i];
+    }
 }
 
 __global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int nsplit, int HW) {
@@ -1391,18 +1442,25 @@ __global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict
     }
 }
 
+// One workgroup = a.tpw consecutive 64-pixel tiles of one image; weights and the head contexts stay in registers, the
+// next tile's rows are in flight while the current one is processed.
 template <int C>
 __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
+    using LN = LnTile<C, 64>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];
     __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NPX * APB];
     static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "Z aliases the y planes");
-    float* Z = reinterpret_cast<float*>(&Yp[0][0]);       // the y planes are dead once every wave has its q (second barrier)
+    float* Z = reinterpret_cast<float*>(&Yp[0][0]);       // the y planes are dead once every wave has its q
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
-    const int tiles = a.HW / NPX;
-    const int img = blockIdx.x / tiles, t = blockIdx.x % tiles;
-    const size_t row0 = (size_t)img * a.HW + (size_t)t * NPX;
-    const float* x0 = a.x + row0 * a.ldx;
+    const int wpi = a.HW / (NPX * a.tpw);                 // workgroups per image
+    const int img = blockIdx.x / wpi, t0 = (blockIdx.x % wpi) * a.tpw;
+    const size_t row00 = (size_t)img * a.HW + (size_t)t0 * NPX;
+    float4 xr[LN::NPASS];
+    LN::load(xr, a.x + row00 * a.ldx, a.ldx, tid);
+    const int lcol = tid % LN::LPR, lrow = tid / LN::LPR;
+    const float4 gv = *reinterpret_cast<const float4*>(a.g + 4 * lcol);
+    const float4 gv2 = *reinterpret_cast<const float4*>(a.g2 + 4 * lcol);
     const float4* W4 = reinterpret_cast<const float4*>(a.Wqkv);
     const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
     half8 qh[2][K32], ql[2][K32];
@@ -1414,13 +1472,16 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
             ql[s][k] = __builtin_bit_cast(half8, W4[(((size_t)(2 * w + s) * K32 + k) * 2 + 1) * 64 + lane]);
         }
     half8 oh[TPW][4], ol[TPW][4];
+    float4 bias[TPW];
 #pragma unroll
-    for (int s = 0; s < TPW; ++s)
+    for (int s = 0; s < TPW; ++s) {
+        bias[s] = *reinterpret_cast<const float4*>(a.bo + (w * TPW + s) * 16 + lq * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             oh[s][k] = __builtin_bit_cast(half8, Wo4[(((size_t)(w * TPW + s) * 4 + k) * 2 + 0) * 64 + lane]);
             ol[s][k] = __builtin_bit_cast(half8, Wo4[(((size_t)(w * TPW + s) * 4 + k) * 2 + 1) * 64 + lane]);
         }
+    }
     // merged context of head w as A fragments of the second product: lane holds ctx[d = dt*16 + lq*4 + i][e = et*16 + lr]
     float cf[2][2][4];
     {
@@ -1432,114 +1493,109 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cf[dt][et][i] = cp[(dt * 16 + lq * 4 + i) * 32 + et * 16 + lr];
     }
-    ln_tile_to_planes<C, NPX>(x0, a.ldx, a.g, Yp[0], Yp[1], tid);
-    __syncthreads();
-    // q of head w: rows = channels d, cols = pixels
-    f32x4 q[2][NTL];
+#pragma unroll 1
+    for (int tt = 0; tt < a.tpw; ++tt) {
+        const size_t row0 = row00 + (size_t)tt * NPX;
+        float4 xres[LN::NPASS];                           // the tile's own rows, for the residual
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        f32x4 M[2], Lo[2];
+        for (int r = 0; r < LN::NPASS; ++r) xres[r] = xr[r];
+        LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
+        __syncthreads();
+        if (tt + 1 < a.tpw) LN::load(xr, a.x + (row0 + NPX) * a.ldx, a.ldx, tid);
+        // q of head w: rows = channels d, cols = pixels ; softmax over d ; * 32^-1/2 ; att = ctx^T q
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int nt = 0; nt < NTL; ++nt) {
+            f32x4 M[2], Lo[2];
 #pragma unroll
-        for (int k = 0; k < K32; ++k) {
-            const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
-            const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
-            const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+            for (int s = 0; s < 2; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s][k], yh, M[s], 0, 0, 0);
-                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s][k], yl, Lo[s], 0, 0, 0);
-                Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s][k], yh, Lo[s], 0, 0, 0);
+            for (int k = 0; k < K32; ++k) {
+                const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
+                const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+                const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s][k], yh, M[s], 0, 0, 0);
+                    Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s][k], yl, Lo[s], 0, 0, 0);
+                    Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s][k], yh, Lo[s], 0, 0, 0);
+                }
             }
-        }
-        q[0][nt] = M[0] + Lo[0] * H3_INV; q[1][nt] = M[1] + Lo[1] * H3_INV;
-    }
-    // softmax over d (rows: dt, lq, i) for each pixel column, then * 32^-1/2 ; att = ctx^T q
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, q[dt][nt][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = __builtin_amdgcn_exp2f((q[dt][nt][i] - mx) * 1.4426950408889634f);
-                q[dt][nt][i] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) q[dt][nt] = (q[dt][nt] * inv) * 0.17677669529663687f;
-#pragma unroll
-        for (int et = 0; et < 2; ++et) {
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 q[2];
+            q[0] = M[0] + Lo[0] * H3_INV; q[1] = M[1] + Lo[1] * H3_INV;
+            float mx = -INFINITY;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[dt][et][i], q[dt][nt][i], o, 0, 0, 0);
-            half4v hi, lo;
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, q[dt][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)o[i]; lo[i] = (_Float16)((o[i] - (float)hi[i]) * H3_SCALE); }
-            const int off = (nt * 16 + lr) * APB + 2 * (w * 32 + et * 16 + lq * 4);
-            *reinterpret_cast<half4v*>(&Ap[0][off]) = hi;
-            *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
-        }
-    }
-    __syncthreads();
-    // z = Wo att + bo : channel tiles [w*TPW, (w+1)*TPW) of this wave, all 64 pixels -> Z[pixel][channel]
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int s = 0; s < TPW; ++s) {
-        const int c = (w * TPW + s) * 16 + lq * 4;
-        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+                for (int i = 0; i < 4; ++i) {
+                    const float e = __builtin_amdgcn_exp2f((q[dt][i] - mx) * 1.4426950408889634f);
+                    q[dt][i] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) {
-            f32x4 zM = f32x4{0.f, 0.f, 0.f, 0.f}, zL = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < 2; ++dt) q[dt] = (q[dt] * inv) * 0.17677669529663687f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int off = (nt * 16 + lr) * APB + k * 64 + lq * 16;
-                const half8 ah = *reinterpret_cast<const half8*>(&Ap[0][off]);
-                const half8 al = *reinterpret_cast<const half8*>(&Ap[1][off]);
-                zM = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s][k], ah, zM, 0, 0, 0);
-                zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s][k], al, zL, 0, 0, 0);
-                zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s][k], ah, zL, 0, 0, 0);
+            for (int et = 0; et < 2; ++et) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[dt][et][i], q[dt][i], o, 0, 0, 0);
+                half4v hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)o[i]; lo[i] = (_Float16)((o[i] - (float)hi[i]) * H3_SCALE); }
+                const int off = (nt * 16 + lr) * APB + 2 * (w * 32 + et * 16 + lq * 4);
+                *reinterpret_cast<half4v*>(&Ap[0][off]) = hi;
+                *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
             }
-            const f32x4 z = zM + zL * H3_INV;
-            *reinterpret_cast<float4*>(&Z[(nt * 16 + lr) * ZP + c]) = make_float4(z[0] + b.x, z[1] + b.y, z[2] + b.z, z[3] + b.w);
         }
-    }
-    __syncthreads();
-    // out = LayerNorm(z) g2 + x
-    {
-        constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP;
-        const int lrow = tid / LPR, lcol = tid % LPR;
-        const float4 gv = *reinterpret_cast<const float4*>(a.g2 + 4 * lcol);
+        __syncthreads();
+        // z = Wo att + bo : channel tiles [w*TPW, (w+1)*TPW) of this wave, all 64 pixels -> Z[pixel][channel]
 #pragma unroll
-        for (int r = 0; r < NPASS; ++r) {
-            const int n = r * RPP + lrow;
+        for (int s = 0; s < TPW; ++s) {
+            const int c = (w * TPW + s) * 16 + lq * 4;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                f32x4 zM = f32x4{0.f, 0.f, 0.f, 0.f}, zL = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int off = (nt * 16 + lr) * APB + k * 64 + lq * 16;
+                    const half8 ah = *reinterpret_cast<const half8*>(&Ap[0][off]);
+                    const half8 al = *reinterpret_cast<const half8*>(&Ap[1][off]);
+                    zM = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s][k], ah, zM, 0, 0, 0);
+                    zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[s][k], al, zL, 0, 0, 0);
+                    zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(ol[s][k], ah, zL, 0, 0, 0);
+                }
+                const f32x4 z = zM + zL * H3_INV;
+                *reinterpret_cast<float4*>(&Z[(nt * 16 + lr) * ZP + c]) = make_float4(z[0] + bias[s].x, z[1] + bias[s].y, z[2] + bias[s].z, z[3] + bias[s].w);
+            }
+        }
+        __syncthreads();
+        // out = LayerNorm(z) g2 + x
+#pragma unroll
+        for (int r = 0; r < LN::NPASS; ++r) {
+            const int n = r * LN::RPP + lrow;
             const float4 zv = *reinterpret_cast<const float4*>(&Z[n * ZP + 4 * lcol]);
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + (row0 + n) * a.ldx + 4 * lcol);
-            float s1 = (zv.x + zv.y) + (zv.z + zv.w);
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            const float s1 = rowgroup_sum<LN::LPR>((zv.x + zv.y) + (zv.z + zv.w));
             const float mean = s1 * (1.0f / C);
             const float d0 = zv.x - mean, d1 = zv.y - mean, d2 = zv.z - mean, d3 = zv.w - mean;
-            float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float s2 = rowgroup_sum<LN::LPR>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
             float4 o4;
-            o4.x = d0 * rstd * gv.x + xv.x; o4.y = d1 * rstd * gv.y + xv.y; o4.z = d2 * rstd * gv.z + xv.z; o4.w = d3 * rstd * gv.w + xv.w;
+            o4.x = d0 * rstd * gv2.x + xres[r].x; o4.y = d1 * rstd * gv2.y + xres[r].y;
+            o4.z = d2 * rstd * gv2.z + xres[r].z; o4.w = d3 * rstd * gv2.w + xres[r].w;
             *reinterpret_cast<float4*>(a.out + (row0 + n) * a.ldo + 4 * lcol) = o4;
         }
+        __syncthreads();                                  // Z (= the y planes) is rewritten by the next tile
     }
 }
 
