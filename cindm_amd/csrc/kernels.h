@@ -30,6 +30,44 @@ namespace cindm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Cross-row exchanges on gfx950 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane
+// halves between two registers, so with both operands = v the pair (a, b) holds (own half, other half) in some order
+// and a commutative op(a, b) is the xor-16 / xor-32 all-reduce step (checked against __shfl_xor by
+// tools/micro/permlane_test.hip).  The builtin form mis-folds identical operands, hence the asm.
+__device__ __forceinline__ void permlane16_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane32_pair(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xsum16(float v) { float a, b; permlane16_pair(v, a, b); return a + b; }
+__device__ __forceinline__ float xsum32(float v) { float a, b; permlane32_pair(v, a, b); return a + b; }
+__device__ __forceinline__ float xmax16(float v) { float a, b; permlane16_pair(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xmax32(float v) { float a, b; permlane32_pair(v, a, b); return fmaxf(a, b); }
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror:8, row_ror:4, two quad permutes: VALU speed)
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_get<0x128>(v);
+    v += dpp_get<0x124>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0xB1>(v);
+    return v;
+}
+// all-reduce sum over groups of LPR consecutive lanes (LPR = 16, 32 or 64)
+template <int LPR>
+__device__ __forceinline__ float rowgroup_sum(float v) {
+    static_assert(LPR == 16 || LPR == 32 || LPR == 64, "16, 32 or 64 lanes per group");
+    v = row16_sum(v);
+    if (LPR >= 32) v = xsum16(v);
+    if (LPR >= 64) v = xsum32(v);
+    return v;
+}
+
 constexpr int TM = 48;        // tile rows
 constexpr int TN = 32;        // tile cols
 constexpr int MAXR = 96;      // max input rows per tile (stride-2 conv: 2 * 48)
@@ -919,8 +957,7 @@ __device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[N
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (sid_row[nt][i] == s) mx = fmaxf(mx, ka[nt][dt][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xmax32(xmax16(mx));
             float sum = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -930,8 +967,7 @@ __device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[N
                     ks[nt][dt][i] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = xsum32(xsum16(sum));
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) ks[nt][dt] *= inv;
@@ -1014,8 +1050,7 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
             float s1 = 0.f;
 #pragma unroll
             for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            s1 = rowgroup_sum<LPR>(s1);
             const float mean = s1 * (1.0f / C);
             float s2 = 0.f;
 #pragma unroll
@@ -1023,8 +1058,7 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
                 const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
                 s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            s2 = rowgroup_sum<LPR>(s2);
             const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
             if (r * RPP + lrow < RW) {
 #pragma unroll
@@ -1201,8 +1235,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             float s1 = 0.f;
 #pragma unroll
             for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            s1 = rowgroup_sum<LPR>(s1);
             const float mean = s1 * (1.0f / C);
             float s2 = 0.f;
 #pragma unroll
@@ -1210,8 +1243,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
                 const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
                 s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            s2 = rowgroup_sum<LPR>(s2);
             const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
             if (r * RPP + lrow < RW) {
 #pragma unroll

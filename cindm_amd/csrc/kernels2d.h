@@ -945,8 +945,7 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) { const float d = pass ? accs[t][pb][rg] - mean[pb] : accs[t][pb][rg]; sm += pass ? d * d : d; }
                     }
-                sm += __shfl_xor(sm, 16, 64);
-                sm += __shfl_xor(sm, 32, 64);
+                sm = xsum32(xsum16(sm));
                 if (lg == 0) psum[pass][w][pb * 16 + lq] = sm;
             }
             __syncthreads();
@@ -1044,13 +1043,11 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
             if (a.ln_out) {
                 // LayerNorm partial of this pixel over the wave's 16 channels: 4 in this lane, 4 lanes (lg) per pixel
                 float sm = (v.x + v.y) + (v.z + v.w);
-                sm += __shfl_xor(sm, 16, 64);
-                sm += __shfl_xor(sm, 32, 64);
+                sm = xsum32(xsum16(sm));
                 const float mean = sm * (1.0f / 16.0f);
                 const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
                 float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                m2 += __shfl_xor(m2, 16, 64);
-                m2 += __shfl_xor(m2, 32, 64);
+                m2 = xsum32(xsum16(m2));
                 if (lg == 0) {
                     float* o = a.ln_out + (prow * (a.Npad / 16) + it * 4 + w) * 2;
                     o[0] = mean; o[1] = m2;
@@ -1197,13 +1194,11 @@ __global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__
         float mx = q[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) mx = fmaxf(mx, q[j]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax32(xmax16(mx));
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { q[j] = expf(q[j] - mx); sum += q[j]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xsum32(xsum16(sum));
         const float sc = 0.17677669529663687f / sum;
         f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1247,23 +1242,6 @@ struct La2dArgs {
 };
 constexpr int LA2_PX = 128;        // pixels per context slice
 constexpr int LA2_REC = 64 + 1024;
-
-// sum over the 16 lanes of a DPP row, result in every lane (row_ror:8, row_ror:4, two quad permutes: VALU speed, no LDS);
-// LPR = 32 adds the neighbouring row with one cross-lane exchange
-template <int CTRL>
-__device__ __forceinline__ float dpp_get(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-template <int LPR>
-__device__ __forceinline__ float rowgroup_sum(float v) {
-    static_assert(LPR == 16 || LPR == 32, "16 or 32 lanes per row");
-    v += dpp_get<0x128>(v);
-    v += dpp_get<0x124>(v);
-    v += dpp_get<0x4E>(v);
-    v += dpp_get<0xB1>(v);
-    if (LPR == 32) v += __shfl_xor(v, 16, 64);
-    return v;
-}
 
 // LayerNorm over C channels (biased variance, eps 1e-5) * g of the NPX tile rows held in xr (thread (lrow, lcol) owns
 // columns 4*lcol.. of rows r*RPP + lrow) -> (hi, scaled lo) fp16 planes
@@ -1365,8 +1343,7 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
             for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mx = fmaxf(mx, kk[nt][dt][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xmax32(xmax16(mx));
             const float mnew = fmaxf(run_m[dt], mx);
             const float f = __builtin_amdgcn_exp2f((run_m[dt] - mnew) * 1.4426950408889634f);      // 0 on the first slice
             float sum = 0.f;
@@ -1378,8 +1355,7 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
                     kk[nt][dt][i] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = xsum32(xsum16(sum));
             run_s[dt] = run_s[dt] * f + sum;
             run_m[dt] = mnew;
             if (lq == 0) fac[w][dt * 16 + lr] = f;
@@ -1527,8 +1503,7 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mx = fmaxf(mx, q[dt][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xmax32(xmax16(mx));
             float sum = 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -1538,8 +1513,7 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
                     q[dt][i] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = xsum32(xsum16(sum));
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) q[dt] = (q[dt] * inv) * 0.17677669529663687f;
@@ -1685,8 +1659,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, pr[mb][rg]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax32(xmax16(mx));
         const float mn = fmaxf(m, mx);
         const float corr = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
@@ -1710,8 +1683,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
         store_kv(buf ^ 1);
         __syncthreads();
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xsum32(xsum16(l));
     const float inv = 1.0f / l;
     float* op = out + ((size_t)img * n + q0 + lq) * 128 + h * 32 + lg * 4;
 #pragma unroll
