@@ -1606,8 +1606,19 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float Ks[2][64 * LDK];
     __shared__ __attribute__((aligned(16))) float Vs[2][64 * LDK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ih = blockIdx.y, img = ih >> 2, h = ih & 3;
-    const int q0 = blockIdx.x * 64 + w * 16;
+    // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the query
+    // blocks of one (image, head) are gathered on one XCD and its K/V is fetched from HBM once instead of 8 times
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const int j = (lin & 7) * (total >> 3) + (lin >> 3);
+            by = j / (int)gridDim.x; bx = j - by * (int)gridDim.x;
+        }
+    }
+    const int ih = by, img = ih >> 2, h = ih & 3;
+    const int q0 = bx * 64 + w * 16;
     const float* base = qkv + (size_t)img * n * 384;
     const int lq = lane & 15, lg = lane >> 4;
     float qb[8];

@@ -1,0 +1,16 @@
+cd /root/repo; export TMPDIR=/tmp
+python bench.py > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.err
+python bench.py --workload cfg5 > gpurun_out/bench_cfg5.json 2> gpurun_out/bench_cfg5.err
+cd /tmp
+rocprofv3 --kernel-trace -d /tmp/k2 -o c2 -- python3 /root/repo/tools/prof1d.py 256 50 > /dev/null 2>&1
+rocprofv3 --kernel-trace -d /tmp/k5 -o c5 -- python3 /root/repo/tools/prof2d.py 64 2 10 > /dev/null 2>&1
+cd /root/repo
+python3 tools/rocprof_summary.py $(find /tmp/k2 -name "*.db" | head -1) gpurun_out/kstats_cfg2.txt > /dev/null
+python3 tools/rocprof_summary.py $(find /tmp/k5 -name "*.db" | head -1) gpurun_out/kstats_cfg5.txt > /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc5_fetch -- python3 tools/prof2d.py 64 2 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc5_write -- python3 tools/prof2d.py 64 2 5 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc2_fetch -- python3 tools/prof1d.py 256 20 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc2_write -- python3 tools/prof1d.py 256 20 > /dev/null 2>&1
+python3 tools/pmc_traffic.py /tmp/pmc5_fetch /tmp/pmc5_write > gpurun_out/pmc_traffic_cfg5.json
+python3 tools/pmc_traffic.py /tmp/pmc2_fetch /tmp/pmc2_write > gpurun_out/pmc_traffic_cfg2.json
+cat gpurun_out/bench_cfg2.json gpurun_out/bench_cfg5.json
