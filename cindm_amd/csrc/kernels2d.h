@@ -1702,6 +1702,151 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
         *reinterpret_cast<float4*>(op + db * 16) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
 }
 
+// attn_full_h3_kernel: the same attention with both products on the split-fp16 scheme (three v_mfma_f32_16x16x32_f16 per
+// fp32-equivalent product, fp32 accumulation in two accumulator sets).  K is staged as (hi, scaled lo) planes
+// [key][32 d]; V is staged TRANSPOSED, [d][key slot], with the 64 keys of a chunk permuted so that the eight k-slots a
+// lane feeds to one MFMA -- keys 16*mbA + 4*lg + {0..3} and 16*mbB + 4*lg + {0..3}, the order in which the S^T
+// accumulators hold the probabilities -- are contiguous: P goes from the accumulators into the second product with
+// no data movement.  The exponentials and the fp16 splits of P are now the dominant work (VALU), not the MFMAs.
+__global__ __launch_bounds__(256, 2) void attn_full_h3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
+    constexpr int KPB = 80, VPB = 144;                   // bytes per key row (32 d) / per d row (64 key slots), padded
+    __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][64 * KPB];     // [buffer][plane]
+    __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][32 * VPB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const int j = (lin & 7) * (total >> 3) + (lin >> 3);
+            by = j / (int)gridDim.x; bx = j - by * (int)gridDim.x;
+        }
+    }
+    const int ih = by, img = ih >> 2, h = ih & 3;
+    const int q0 = bx * 64 + w * 16;
+    const float* base = qkv + (size_t)img * n * 384;
+    const int lq = lane & 15, lg = lane >> 4;
+    // Q^T fragment of this wave's 16 queries: lane (query lq, d = lg*8 .. +7), pre-scaled by 32^-1/2 log2 e
+    half8 qh, ql;
+    {
+        const float* qp = base + (size_t)(q0 + lq) * 384 + h * 32 + lg * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+        const float sc = 0.17677669529663687f * 1.4426950408889634f;
+        const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qh[e] = (_Float16)v[e]; ql[e] = (_Float16)((v[e] - (float)qh[e]) * H3_SCALE); }
+    }
+    const int sr = tid >> 3, sc4 = tid & 7;              // staging: keys sr, sr + 32 ; d = sc4*4 .. +3
+    float4 kr0, kr1, vr0, vr1;
+    auto load_kv = [&](int k0) {
+        const float* rp = base + (size_t)(k0 + sr) * 384 + h * 32 + sc4 * 4;
+        kr0 = *reinterpret_cast<const float4*>(rp + 128);
+        vr0 = *reinterpret_cast<const float4*>(rp + 256);
+        kr1 = *reinterpret_cast<const float4*>(rp + 32 * 384 + 128);
+        vr1 = *reinterpret_cast<const float4*>(rp + 32 * 384 + 256);
+    };
+    // key -> k-slot of the second product: step (key / 32), then lg = (key % 16) / 4, half = (key / 16) % 2, rg = key % 4
+    auto slot_of = [](int key) { return (key >> 5) * 32 + ((key & 15) >> 2) * 8 + ((key >> 4) & 1) * 4 + (key & 3); };
+    const int slot0 = slot_of(sr), slot1 = slot_of(sr + 32);
+    auto store_kv = [&](int buf) {
+        auto put_k = [&](const float4 v, int key) {
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&Kp[buf][0][key * KPB + sc4 * 8]) = hi;
+            *reinterpret_cast<half4v*>(&Kp[buf][1][key * KPB + sc4 * 8]) = lo;
+        };
+        auto put_v = [&](const float4 v, int slot) {
+            const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const _Float16 hi = (_Float16)f[j];
+                const _Float16 lo = (_Float16)((f[j] - (float)hi) * H3_SCALE);
+                *reinterpret_cast<_Float16*>(&Vp[buf][0][(sc4 * 4 + j) * VPB + slot * 2]) = hi;
+                *reinterpret_cast<_Float16*>(&Vp[buf][1][(sc4 * 4 + j) * VPB + slot * 2]) = lo;
+            }
+        };
+        put_k(kr0, sr); put_k(kr1, sr + 32);
+        put_v(vr0, slot0); put_v(vr1, slot1);
+    };
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    f32x4 oM[2], oL[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { oM[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; oL[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float m = -INFINITY, l = 0.f;
+    const int nchunk = n >> 6;
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        load_kv(min(c + 1, nchunk - 1) << 6);
+        __builtin_amdgcn_sched_barrier(0);
+        // S^T tiles: rows = keys 16*mb + 4*lg + rg, cols = queries
+        float pr[4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int off = (mb * 16 + lq) * KPB + lg * 16;
+            const half8 kh = *reinterpret_cast<const half8*>(&Kp[buf][0][off]);
+            const half8 kl = *reinterpret_cast<const half8*>(&Kp[buf][1][off]);
+            f32x4 sM = (f32x4){0.f, 0.f, 0.f, 0.f}, sL = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, sM, 0, 0, 0);
+            sL = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, sL, 0, 0, 0);
+            sL = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, sL, 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) pr[mb][rg] = sM[rg] + sL[rg] * H3_INV;
+        }
+        float mx = pr[0][0];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, pr[mb][rg]);
+        mx = xmax32(xmax16(mx));
+        const float mn = fmaxf(m, mx);
+        const float corr = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) { pr[mb][rg] = __builtin_amdgcn_exp2f(pr[mb][rg] - mn); ps += pr[mb][rg]; }
+        l = l * corr + ps;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { oM[db] *= corr; oL[db] *= corr; }
+        // O^T[d][q] += V^T[d][slots] P[slots][q], two k-steps of 32 key slots
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            half8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float p = pr[2 * st + (e >> 2)][e & 3];
+                ph[e] = (_Float16)p;
+                pl[e] = (_Float16)((p - (float)ph[e]) * H3_SCALE);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int off = (db * 16 + lq) * VPB + st * 64 + lg * 16;
+                const half8 vh = *reinterpret_cast<const half8*>(&Vp[buf][0][off]);
+                const half8 vl = *reinterpret_cast<const half8*>(&Vp[buf][1][off]);
+                oM[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oM[db], 0, 0, 0);
+                oL[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oL[db], 0, 0, 0);
+                oL[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oL[db], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_kv(buf ^ 1);
+        __syncthreads();
+    }
+    l = xsum32(xsum16(l));
+    const float inv = 1.0f / l;
+    float* op = out + ((size_t)img * n + q0 + lq) * 128 + h * 32 + lg * 4;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const f32x4 o = (oM[db] + oL[db] * H3_INV) * inv;
+        *reinterpret_cast<float4*>(op + db * 16) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // DDPM update with boundary sharing (share_states_over_boundaries :712-725, p_mean_variance :757-773, p_sample
 // :804-808): one thread per state element of x [B*nb, HW, C] (channel-last).  The model output's state channels
