@@ -1155,7 +1155,6 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.mean_out = io.mean_out; a.x0_out = io.x0_out; a.eps_out = io.eps_out; a.x_out = io.x_out;
     a.noise = io.noise; a.noise_t_stride = io.noise_t_stride; a.seed = io.seed; a.sample_off = io.sample_off; a.add_noise = io.add_noise;
     a.inp_cond = io.inp_cond; a.inp_steps = io.inp_steps; a.inp_noise = io.inp_noise; a.inp_noise_t_stride = io.inp_noise_t_stride;
-    if (io.dec_t) { a.t_dec = h->t_dev; a.done = reinterpret_cast<unsigned*>(h->t_dev + 1); }
     if (io.ddim_tab) { a.ddim_tab = io.ddim_tab; a.ddim_tnext = io.ddim_tnext; a.step_idx = h->t_dev + 2; }
     const bool guided = io.dz && io.x_out;
     if (guided) {
@@ -1181,6 +1180,7 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
                              w + s.off_ws_single, ws_bytes - s.off_ws_single, stream) != 0) return -1;
     const int64_t ne = B * (int64_t)Ltot * a.F;
     hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);
+    if (io.dec_t) hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, io.ddim_tab ? io.ddim_tnext : (const int*)nullptr);
     HIPCHK(hipGetLastError());
     if (guided) HIPCHK(hipMemcpyAsync(io.x_out, a.x_out, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return 0;

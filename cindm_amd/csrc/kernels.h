@@ -1472,7 +1472,7 @@ struct ComposeArgs {
     const float* noise; int64_t noise_t_stride;        // explicit noise (+ t * stride), or null
     uint64_t seed; int64_t sample_off; int add_noise;
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
-    int* t_dec; unsigned* done;     // sample loop: the last block to finish decrements the device step counter
+    int* t_dec; unsigned* done;     // unused by the kernel: the host launches step_counter_kernel after the update
     // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
     // device step index; noise tapes are then indexed by the step index instead of t
     const float* ddim_tab; const int* ddim_tnext; int* step_idx;
@@ -1707,17 +1707,16 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         a.x_out[i] = v;
     }
     }
-    if (a.t_dec) {
-        // every block has read t before it arrives here; the last arriver publishes t - 1 for the next graph replay
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(a.done, 1u) == gridDim.x - 1) {
-                *a.done = 0u;
-                if (a.ddim_tab) { *a.t_dec = max(a.ddim_tnext[sidx], 0); *a.step_idx = sidx + 1; }
-                else *a.t_dec = t - 1;
-            }
-        }
+}
+
+// Advances the device-side step counter after the update kernel of a step (its own graph node: every reader of t in this
+// step has finished).  A "last block done" atomic inside the update kernel cost one same-address device-scope atomic
+// and one release fence per block: 46 ns each, 282 us per step for the 6144 blocks of the 2-D update.
+// t_dev[0] = t, t_dev[2] = DDIM step index.
+__global__ void step_counter_kernel(int* t_dev, const int* ddim_tnext) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (ddim_tnext) { const int sidx = t_dev[2]; t_dev[0] = max(ddim_tnext[sidx], 0); t_dev[2] = sidx + 1; }
+        else t_dev[0] -= 1;
     }
 }
 

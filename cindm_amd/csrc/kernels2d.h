@@ -1939,13 +1939,6 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
             if (a.x_out) *reinterpret_cast<float4*>(a.x_out + o) = make_float4(rx[0], rx[1], rx[2], rx[3]);
         }
     }
-    if (a.t_dec) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(a.done, 1u) == gridDim.x - 1) { *a.done = 0u; *a.t_dec = t - 1; }
-        }
-    }
 }
 
 // x_T for the 2-D path from the counter-based generator (state channels shared over the boundaries of a design)
