@@ -17,7 +17,10 @@ import os
 import sys
 import time
 
-import torch
+# RCCL / IPC between the ranks of one node needs dmabuf handles on this driver (no-op when already exported)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
