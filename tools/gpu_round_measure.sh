@@ -1,3 +1,5 @@
+# Round-end measurement on the GPU box (run through gpurun): both bench lines, rocprofv3 kernel-trace summaries and the
+# two separate PMC passes per workload; results land in gpurun_out/ and are copied into profiles/ by hand.
 cd /root/repo; export TMPDIR=/tmp
 python bench.py > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.err
 python bench.py --workload cfg5 > gpurun_out/bench_cfg5.json 2> gpurun_out/bench_cfg5.err
