@@ -177,6 +177,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3]
     const int ns = min(a.spt, a.Bp - b0);
     const int rows_out = ns * a.Lout;
     const int n0 = nt * TN;
+    const int n = tid & 31, rq = tid >> 5;
+    const int gn = n0 + n;
+    const bool nok = gn < a.N;
+    // every global read of the epilogue is issued up front (the step index and the time-bias row it addresses are a
+    // dependent pair: left at their point of use they cost two exposed memory latencies per launch)
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+    float eg = 1.f, eb = 0.f;
+    if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
+    float ag = 1.f, ab = 0.f, atb = 0.f;
+    if (a.act_gamma && nok) {
+        ag = a.act_gamma[gn]; ab = a.act_beta[gn];
+        if (a.act_tb) atb = a.act_tb[(size_t)t_now * a.act_tb_ld + gn];
+    }
+    float ey[6], rs[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int r = rq + 8 * q;
+        ey[q] = 0.f; rs[q] = 0.f;
+        if (r < rows_out && nok) {
+            const size_t grow = (size_t)b0 * a.Lout + r;
+            if (a.e_y) ey[q] = a.e_y[grow * a.e_ld + gn];
+            if (a.res) rs[q] = a.res[grow * a.ldres + gn];
+        }
+    }
     // ---- cross-wave K reduction through LDS --------------------------------------------------
     // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
     if constexpr (T > 0) {
@@ -190,24 +215,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3]
         __syncthreads();
     }
 
-    const int n = tid & 31, rq = tid >> 5;
-    const int gn = n0 + n;
-    const bool nok = gn < a.N;
-    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
-    float eg = 1.f, eb = 0.f;
-    if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
-    // issue the epilogue's global reads first, then combine
-    float ey[6], rs[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int r = rq + 8 * q;
-        ey[q] = 0.f; rs[q] = 0.f;
-        if (r < rows_out && nok) {
-            const size_t grow = (size_t)b0 * a.Lout + r;
-            if (a.e_y) ey[q] = a.e_y[grow * a.e_ld + gn];
-            if (a.res) rs[q] = a.res[grow * a.ldres + gn];
-        }
-    }
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int r = rq + 8 * q;
@@ -253,9 +260,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3]
             }
         }
         __syncthreads();
-        const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
-        const float ag = nok ? a.act_gamma[gn] : 1.f, ab = nok ? a.act_beta[gn] : 0.f;
-        const float atb = (a.act_tb && nok) ? a.act_tb[(size_t)t_now * a.act_tb_ld + gn] : 0.f;
         const int gi = n >> (31 - __builtin_clz(gwt));
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
