@@ -61,6 +61,8 @@ struct cindm_unet1d {
     bool use_local_gn = true;              // producer-side GroupNorm + Mish where groups are tile-local (CINDM_LOCAL_GN=0 disables)
     bool use_wide_qkv = true;              // shallow-level qkv projections on conv1x1_wide_kernel (CINDM_WIDE_QKV=0 disables)
     bool use_attn_site = true;             // one launch per attention site, attn1d_site_kernel (CINDM_ATTN_SITE=0 disables)
+    bool level0_ok = false;                // level0_down_kernel operands packed (dim 64, F <= 32, attention, down-sampling)
+    bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
     // taps of the last forward
@@ -323,6 +325,43 @@ static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
         frag(wq, 384, C, attn_prefix + ".to_qkv#site");
         frag(wo, C, 128, attn_prefix + ".to_out#site");
     }
+}
+
+// level0_down_kernel operands: every convolution of downs.0 as split-fp16 fragments
+// [tile of 16 output channels][tap][k32][plane hi / scaled lo][lane][e] = W[tile*16 + lane%16][k32*32 + (lane/16)*8 + e][tap]
+// (input channels zero-padded to a multiple of 32)
+static void pack_level0(cindm_unet1d* h, BlobBuilder& bb) {
+    auto frag = [&](const std::string& prefix) -> bool {
+        auto it = h->index.find(prefix + ".weight");
+        if (it == h->index.end()) return false;
+        const Param& w = h->params[it->second];
+        const int Co = (int)w.shape[0], Ci = (int)w.shape[1], K = (int)w.shape[2];
+        if (Co != 64 || (Ci != 64 && Ci > 32)) return false;
+        const int KS = (Ci + 31) / 32;
+        Packed pk; pk.T = K; pk.CinP = KS * 32; pk.Npad = Co; pk.N = Co; pk.KC = 32; pk.h3 = true;
+        pk.off = bb.alloc((size_t)(Co / 16) * K * KS * 2 * 64 * 4);
+        uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
+        auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
+        for (int t = 0; t < Co / 16; ++t)
+            for (int tap = 0; tap < K; ++tap)
+                for (int k = 0; k < KS; ++k)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = t * 16 + (lane & 15), ci = k * 32 + (lane >> 4) * 8 + e;
+                            const float v = ci < Ci ? w.host[((size_t)co * Ci + ci) * K + tap] : 0.f;
+                            const _Float16 hv = (_Float16)v;
+                            const float lo = (v - (float)hv) * 2048.0f;
+                            const size_t q0 = (((size_t)t * K + tap) * KS + k) * 2;
+                            base[((q0 + 0) * 64 + lane) * 8 + e] = bits((float)hv);
+                            base[((q0 + 1) * 64 + lane) * 8 + e] = bits(lo);
+                        }
+        h->packed[prefix + "#lvl"] = pk;
+        return true;
+    };
+    bool ok = true;
+    for (const char* p : {"downs.0.0.blocks.0.block.0", "downs.0.0.blocks.1.block.0", "downs.0.1.blocks.0.block.0",
+                          "downs.0.1.blocks.1.block.0", "downs.0.0.residual_conv", "downs.0.3.conv"}) ok = frag(p) && ok;
+    h->level0_ok = ok && h->index.count("downs.0.2.fn.fn.to_qkv.weight") && !h->index.count("downs.0.1.residual_conv.weight");
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -766,6 +805,40 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
     for (int ind = 0; ind < nres; ++ind) {
         const int co = h->dims[ind + 1];
         const std::string p = "downs." + std::to_string(ind);
+        if (ind == 0 && h->level0_ok && att && cur.L <= 32 && (cur.L & 1) == 0 && h->packed.count("downs.0.2.fn.fn.to_qkv#site") &&
+            h->packed.at("downs.0.2.fn.fn.to_qkv#site").h3 && cur.ld == cur.C) {
+            // the whole level in one launch (level0_down_kernel)
+            const int L = cur.L;
+            Ten h1 = E.ten(L, 64), h2 = E.ten(L, 64), sk = E.ten(L, 64), dn = E.ten(L / 2, 64);
+            ++E.launches;
+            if (!E.dry) {
+                Level0Args l;
+                std::memset(&l, 0, sizeof(l));
+                l.x = cur.p; l.F = cur.C; l.h1 = h1.p; l.h2 = h2.p; l.skip = sk.p; l.down = dn.p;
+                const char* cv[4] = {"downs.0.0.blocks.0", "downs.0.0.blocks.1", "downs.0.1.blocks.0", "downs.0.1.blocks.1"};
+                for (int i = 0; i < 4; ++i) {
+                    const std::string cp = cv[i];
+                    l.Wc[i] = E.W(h->packed.at(cp + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cp + ".block.0"));
+                    l.gam[i] = E.V(cp + ".block.2.weight"); l.bet[i] = E.V(cp + ".block.2.bias");
+                }
+                l.Wr = E.W(h->packed.at("downs.0.0.residual_conv#lvl")); l.br = E.B(h->packed.at("downs.0.0.residual_conv"));
+                l.tb0 = h->ttable + h->tb_off.at("downs.0.0"); l.tb1 = h->ttable + h->tb_off.at("downs.0.1"); l.tb_ld = h->tb_ld;
+                l.ln_g = E.V("downs.0.2.fn.norm.g"); l.Wqkv = E.W(h->packed.at("downs.0.2.fn.fn.to_qkv#site"));
+                l.Wo = E.W(h->packed.at("downs.0.2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at("downs.0.2.fn.fn.to_out"));
+                l.Wd = E.W(h->packed.at("downs.0.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.0.3.conv"));
+                l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
+                E.prof_begin(5, 0.0);
+                for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
+                    if (L > 16) hipLaunchKernelGGL(level0_down_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, E.stream, l);
+                    else hipLaunchKernelGGL(level0_down_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, E.stream, l);
+                }
+                E.prof_end();
+            }
+            E.tap("downs.0.0", h1); E.tap("downs.0.1", h2); E.tap("downs.0.2", sk); E.tap("downs.0.3", dn);
+            skips.push_back(sk);
+            cur = dn;
+            continue;
+        }
         cur = emit_rtb(E, p + ".0", cur, nullptr, co, false, nullptr);
         cur = emit_rtb(E, p + ".1", cur, nullptr, co, need_ln(p + ".2", cur.L), &lnp);
         if (att) cur = emit_attn(E, p + ".2", cur, lnp);
@@ -836,6 +909,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         h->use_wide_qkv = !(wq && std::strcmp(wq, "0") == 0);
         const char* as = getenv("CINDM_ATTN_SITE");
         h->use_attn_site = !(as && std::strcmp(as, "0") == 0);
+        const char* l0 = getenv("CINDM_LEVEL0");
+        h->use_level0 = !(l0 && std::strcmp(l0, "0") == 0);
         const char* hr = getenv("CINDM_H3_RESAMPLE");
         h->use_h3_resample = !(hr && std::strcmp(hr, "0") == 0);
     }
@@ -873,6 +948,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         }
     }
     h->tb_ld = tb_ld;
+    h->level0_ok = false;
+    if (h->use_h3 && h->use_attn_site && h->use_level0 && h->use_local_gn) pack_level0(h, bb);
     if (h->blob) { (void)hipFree(h->blob); h->blob = nullptr; }
     if (h->ttable) { (void)hipFree(h->ttable); h->ttable = nullptr; }
     h->blob_floats = bb.data.size();

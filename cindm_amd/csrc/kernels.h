@@ -1398,6 +1398,316 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
 }
 
 // ---------------------------------------------------------------------------------------------
+// level0_down_kernel: the whole finest level of the down path -- ResidualTemporalBlock, ResidualTemporalBlock,
+// Residual(PreNorm(LinearAttentionTemporal)), Downsample1d (model/diffusion_1d.py:483-511, :272-291, :92-98; forward
+// :611-619) -- in ONE launch, one sample per workgroup.  GroupNorm, LayerNorm and the attention are per-sample, so a
+// workgroup never needs another one's data: six dependent launches (~58 us of critical path at any batch size) become
+// one.  Activations stay in LDS (as split-fp16 planes with a zero halo of two positions, so a convolution tap is a
+// row offset) and in registers; every product is a split-fp16 MFMA in the orientation of attn1d_site_h3_kernel
+// (A = weight fragments, B = activations: accumulator rows = channels, cols = positions), each wave owning 16 of the
+// 64 channels, which makes a GroupNorm group (8 channels) two lane-groups of one wave.  C = 64 (dim), L <= 32,
+// input channels F <= 32.  The three intermediate tensors are also written out (the tap API and the tests read them).
+struct Level0Args {
+    const float* x; int F;                 // [Bp, L, F]
+    float* h1; float* h2; float* skip; float* down;      // [Bp, L, 64] x 3, [Bp, L/2, 64]
+    const float* Wc[4]; const float* bc[4]; const float* gam[4]; const float* bet[4];      // the four k=5 convolutions
+    const float* Wr; const float* br;      // residual_conv of the first block (F -> 64, one tap)
+    const float* tb0; const float* tb1; int tb_ld;      // time-bias table bases (row t)
+    const float* ln_g; const float* Wqkv; const float* Wo; const float* bo;
+    const float* Wd; const float* bd;      // Downsample1d (k = 3, stride 2, pad 1)
+    const int* t_ptr; int t_imm;
+    int L;
+};
+
+// one 16-channel x (NT*16)-position tile of a k-tap convolution: A = this wave's weight fragments [tap][k32][plane],
+// B = activation planes at row (position * stride + tap + row0)
+template <int NT, int TAPS, int KS, int PITCHB>
+__device__ __forceinline__ void lvl_conv(const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
+                                         int stride, int row0, int maxrow, int lane, f32x4 (&out)[NT]) {
+    const int lr = lane & 15, lq = lane >> 4;
+    f32x4 M[NT], Lo[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { M[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float4 wr[TAPS * KS][2];
+#pragma unroll
+    for (int i = 0; i < TAPS * KS; ++i) { wr[i][0] = Wt[(i * 2 + 0) * 64 + lane]; wr[i][1] = Wt[(i * 2 + 1) * 64 + lane]; }
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const half8 wh = __builtin_bit_cast(half8, wr[tap * KS + k][0]), wl = __builtin_bit_cast(half8, wr[tap * KS + k][1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = min((nt * 16 + lr) * stride + tap + row0, maxrow) * PITCHB + k * 64 + lq * 16;
+                const half8 xh = *reinterpret_cast<const half8*>(Xh + off);
+                const half8 xl = *reinterpret_cast<const half8*>(Xl + off);
+                M[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, M[nt], 0, 0, 0);
+                Lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, Lo[nt], 0, 0, 0);
+                Lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, Lo[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) out[nt] = M[nt] + Lo[nt] * H3_INV;
+}
+
+// + bias ; GroupNorm over (8 channels x L positions) of this wave's two groups (rows 4*lq + i: lq 0,1 | lq 2,3) ; Mish
+template <int NT>
+__device__ __forceinline__ void lvl_gn_mish(f32x4 (&v)[NT], const float4 bias, const float4 gam, const float4 bet, int L, int lane) {
+    const int lr = lane & 15;
+    const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, gg[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
+    float s1 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[nt][i] += bb[i]; if (nt * 16 + lr < L) s1 += v[nt][i]; }
+    s1 = xsum16(row16_sum(s1));
+    const float inv_n = 1.0f / (8.0f * (float)L);
+    const float mean = s1 * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = v[nt][i] - mean; if (nt * 16 + lr < L) s2 += d * d; }
+    s2 = xsum16(row16_sum(s2));
+    const float rstd = 1.0f / sqrtf(s2 * inv_n + 1e-5f);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[nt][i] = mish_f((v[nt][i] - mean) * rstd * gg[i] + be[i]);
+}
+
+// accumulator tile (rows = channels c0 + 4*lq + i, cols = positions) -> split-fp16 planes at row (position + row0);
+// positions >= L are written as zeros (they are the right halo of the valid ones)
+template <int NT, int PITCHB>
+__device__ __forceinline__ void lvl_to_planes(const f32x4 (&v)[NT], unsigned char* Ph, unsigned char* Pl, int c0, int row0, int L, int lane) {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + lr;
+        half4v hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float f = (n < L) ? v[nt][i] : 0.f;
+            hi[i] = (_Float16)f; lo[i] = (_Float16)((f - (float)hi[i]) * H3_SCALE);
+        }
+        const int off = (n + row0) * PITCHB + 2 * (c0 + lq * 4);
+        *reinterpret_cast<half4v*>(Ph + off) = hi;
+        *reinterpret_cast<half4v*>(Pl + off) = lo;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void lvl_store(const f32x4 (&v)[NT], float* dst, int c0, int n_valid, int lane) {      // dst: [positions, 64] of this sample
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + lr;
+        if (n < n_valid) *reinterpret_cast<float4*>(dst + (size_t)n * 64 + c0 + lq * 4) = make_float4(v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
+    constexpr int C = 64, NP = NT * 16, ROWS = NP + 4;               // two halo positions on each side
+    constexpr int XPB = 2 * 32 + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char X0[2][ROWS * XPB];          // input, F padded to 32 channels
+    __shared__ __attribute__((aligned(16))) unsigned char P[2][2][ROWS * PPB];        // ping-pong activation planes
+    __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NP * APB];            // attention output planes
+    __shared__ __attribute__((aligned(16))) float H[NP * HP];                          // h2 in fp32 for the LayerNorm
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int L = a.L, b = blockIdx.x;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int c0 = w * 16;                                               // this wave's channels
+    const int cl = c0 + lq * 4;                                          // this lane's four channels
+    // ---- stage x (zero halo, zero pad channels / positions); clear the halos of the activation planes ----
+    {
+        const int r = tid >> 3, c4 = tid & 7;                            // 32 rows x 8 float4
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L && 4 * c4 < a.F) v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + r) * a.F + 4 * c4);
+        half4v hi, lo;
+        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+        lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+        if (r < NP) {
+            *reinterpret_cast<half4v*>(&X0[0][(r + 2) * XPB + 8 * c4]) = hi;
+            *reinterpret_cast<half4v*>(&X0[1][(r + 2) * XPB + 8 * c4]) = lo;
+        }
+        // halo rows 0, 1, NP + 2, NP + 3 of every plane
+        for (int i = tid; i < 4 * (PPB / 4); i += 256) {
+            const int hr = i / (PPB / 4), cw = i % (PPB / 4);
+            const int row = hr < 2 ? hr : NP + hr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) reinterpret_cast<float*>(&P[q][pl][row * PPB])[cw] = 0.f;
+            if (cw < XPB / 4) { reinterpret_cast<float*>(&X0[0][row * XPB])[cw] = 0.f; reinterpret_cast<float*>(&X0[1][row * XPB])[cw] = 0.f; }
+        }
+    }
+    // per-lane channel parameters of the first block
+    const float4* Wc0 = reinterpret_cast<const float4*>(a.Wc[0]) + (size_t)w * (5 * 1 * 2 * 64);
+    const float4* Wc1 = reinterpret_cast<const float4*>(a.Wc[1]) + (size_t)w * (5 * 2 * 2 * 64);
+    const float4* Wc2 = reinterpret_cast<const float4*>(a.Wc[2]) + (size_t)w * (5 * 2 * 2 * 64);
+    const float4* Wc3 = reinterpret_cast<const float4*>(a.Wc[3]) + (size_t)w * (5 * 2 * 2 * 64);
+    const float4* Wr4 = reinterpret_cast<const float4*>(a.Wr) + (size_t)w * (1 * 1 * 2 * 64);
+    const float4* Wd4 = reinterpret_cast<const float4*>(a.Wd) + (size_t)w * (3 * 2 * 2 * 64);
+    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + cl); };
+    const float4 tb0 = ld4(a.tb0 + (size_t)t_now * a.tb_ld), tb1 = ld4(a.tb1 + (size_t)t_now * a.tb_ld);
+    __syncthreads();
+
+    // ---- block 0 : y = Mish(GN(conv(x))) + tb0 ; h1 = Mish(GN(conv(y))) + (Wr x + br) ----
+    f32x4 v[NT], r1[NT];
+    lvl_conv<NT, 5, 1, XPB>(Wc0, X0[0], X0[1], 1, 0, ROWS - 1, lane, v);
+    lvl_conv<NT, 1, 1, XPB>(Wr4, X0[0], X0[1], 1, 2, ROWS - 1, lane, r1);
+    lvl_gn_mish<NT>(v, ld4(a.bc[0]), ld4(a.gam[0]), ld4(a.bet[0]), L, lane);
+    {
+        const float4 br = ld4(a.br);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            v[nt][0] += tb0.x; v[nt][1] += tb0.y; v[nt][2] += tb0.z; v[nt][3] += tb0.w;
+            r1[nt][0] += br.x; r1[nt][1] += br.y; r1[nt][2] += br.z; r1[nt][3] += br.w;
+        }
+    }
+    lvl_to_planes<NT, PPB>(v, P[0][0], P[0][1], c0, 2, L, lane);
+    __syncthreads();
+    lvl_conv<NT, 5, 2, PPB>(Wc1, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
+    lvl_gn_mish<NT>(v, ld4(a.bc[1]), ld4(a.gam[1]), ld4(a.bet[1]), L, lane);
+    f32x4 h1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) h1[nt] = v[nt] + r1[nt];
+    lvl_store<NT>(h1, a.h1 + (size_t)b * L * C, c0, L, lane);
+    lvl_to_planes<NT, PPB>(h1, P[1][0], P[1][1], c0, 2, L, lane);
+    __syncthreads();
+    // ---- block 1 (identity residual) ----
+    lvl_conv<NT, 5, 2, PPB>(Wc2, P[1][0], P[1][1], 1, 0, ROWS - 1, lane, v);
+    lvl_gn_mish<NT>(v, ld4(a.bc[2]), ld4(a.gam[2]), ld4(a.bet[2]), L, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { v[nt][0] += tb1.x; v[nt][1] += tb1.y; v[nt][2] += tb1.z; v[nt][3] += tb1.w; }
+    lvl_to_planes<NT, PPB>(v, P[0][0], P[0][1], c0, 2, L, lane);
+    __syncthreads();
+    lvl_conv<NT, 5, 2, PPB>(Wc3, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
+    lvl_gn_mish<NT>(v, ld4(a.bc[3]), ld4(a.gam[3]), ld4(a.bet[3]), L, lane);
+    f32x4 h2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) h2[nt] = v[nt] + h1[nt];
+    lvl_store<NT>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl]) = make_float4(h2[nt][0], h2[nt][1], h2[nt][2], h2[nt][3]);
+    __syncthreads();
+    // ---- attention: y = LN(h2) g -> planes P[1] (rows position + 2) ; q, k, v ; core ; out projection + h2 ----
+    {
+        constexpr int RPP = 16;                                          // 16 lanes per row, 16 rows per pass
+        const int lrow = tid >> 4, lcol = tid & 15;
+        const float4 gv = *reinterpret_cast<const float4*>(a.ln_g + 4 * lcol);
+#pragma unroll
+        for (int r = 0; r < NP / RPP; ++r) {
+            const int n = r * RPP + lrow;
+            const float4 xv = *reinterpret_cast<const float4*>(&H[n * HP + 4 * lcol]);
+            const float s1 = row16_sum((xv.x + xv.y) + (xv.z + xv.w));
+            const float mean = s1 * (1.0f / C);
+            const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+            const float s2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            const bool ok = n < L;
+            const float y0 = ok ? d0 * rstd * gv.x : 0.f, y1 = ok ? d1 * rstd * gv.y : 0.f, y2 = ok ? d2 * rstd * gv.z : 0.f, y3 = ok ? d3 * rstd * gv.w : 0.f;
+            half4v hi, lo;
+            hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+            lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&P[1][0][(n + 2) * PPB + 8 * lcol]) = hi;
+            *reinterpret_cast<half4v*>(&P[1][1][(n + 2) * PPB + 8 * lcol]) = lo;
+        }
+    }
+    __syncthreads();
+    f32x4 qa[2][NT], ka[NT][2], va[NT][2];
+    {
+        const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+        f32x4 qM[2][NT], qL[2][NT], kM[NT][2], kL[NT][2], vM[NT][2], vL[NT][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                qM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; qL[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                kM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; kL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; vL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        half8 wh[2][6], wl[2][6];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int tile = (s >> 1) * 8 + 2 * w + (s & 1);
+                wh[k][s] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 0) * 64 + lane]);
+                wl[k][s] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 1) * 64 + lane]);
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (nt * 16 + lr + 2) * PPB + k * 64 + lq * 16;
+                const half8 yh = *reinterpret_cast<const half8*>(&P[1][0][off]);
+                const half8 yl = *reinterpret_cast<const half8*>(&P[1][1][off]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    qM[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[k][i], yh, qM[i][nt], 0, 0, 0);
+                    qL[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[k][i], yl, qL[i][nt], 0, 0, 0);
+                    qL[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[k][i], yh, qL[i][nt], 0, 0, 0);
+                    kM[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[k][2 + i], kM[nt][i], 0, 0, 0);
+                    kL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[k][2 + i], kL[nt][i], 0, 0, 0);
+                    kL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[k][2 + i], kL[nt][i], 0, 0, 0);
+                    vM[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[k][4 + i], vM[nt][i], 0, 0, 0);
+                    vL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[k][4 + i], vL[nt][i], 0, 0, 0);
+                    vL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[k][4 + i], vL[nt][i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                qa[i][j] = qM[i][j] + qL[i][j] * H3_INV;
+                ka[j][i] = kM[j][i] + kL[j][i] * H3_INV;
+                va[j][i] = vM[j][i] + vL[j][i] * H3_INV;
+            }
+    }
+    f32x4 att[2][NT];
+    attn_site_core<NT>(qa, ka, va, att, 1, NP, NP, L, lq, lr);
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            half4v hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)att[et][nt][i]; lo[i] = (_Float16)((att[et][nt][i] - (float)hi[i]) * H3_SCALE); }
+            const int off = (nt * 16 + lr) * APB + 2 * (w * 32 + et * 16 + lq * 4);
+            *reinterpret_cast<half4v*>(&Ap[0][off]) = hi;
+            *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
+        }
+    __syncthreads();
+    f32x4 h3[NT];
+    {
+        const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo) + (size_t)w * (4 * 2 * 64);
+        lvl_conv<NT, 1, 4, APB>(Wo4, Ap[0], Ap[1], 1, 0, NP - 1, lane, h3);
+        const float4 bo = ld4(a.bo);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            h3[nt][0] += bo.x; h3[nt][1] += bo.y; h3[nt][2] += bo.z; h3[nt][3] += bo.w;
+            h3[nt] += h2[nt];
+        }
+    }
+    lvl_store<NT>(h3, a.skip + (size_t)b * L * C, c0, L, lane);
+    lvl_to_planes<NT, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
+    __syncthreads();
+    // ---- Downsample1d: out[n'] = sum_tap W[tap] h3[2 n' + tap - 1] + bd ----
+    {
+        f32x4 d[1];
+        lvl_conv<1, 3, 2, PPB>(Wd4, P[0][0], P[0][1], 2, 1, ROWS - 1, lane, d);
+        const float4 bd = ld4(a.bd);
+        d[0][0] += bd.x; d[0][1] += bd.y; d[0][2] += bd.z; d[0][3] += bd.w;
+        lvl_store<1>(d, a.down + (size_t)b * (L / 2) * C, c0, L / 2, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Counter-based Gaussian noise: Philox4x32-10 keyed by seed, counter = (element/4, sample, step, 0),
 // Box-Muller on the four 32-bit outputs.  Pure function of (seed, global sample, step, element):
 // results do not depend on the number of GPUs / batch partition.
