@@ -62,6 +62,7 @@ struct cindm_unet1d {
     bool use_wide_qkv = true;              // shallow-level qkv projections on conv1x1_wide_kernel (CINDM_WIDE_QKV=0 disables)
     bool use_attn_site = true;             // one launch per attention site, attn1d_site_kernel (CINDM_ATTN_SITE=0 disables)
     bool level0_ok = false;                // level0_down_kernel operands packed (dim 64, F <= 32, attention, down-sampling)
+    bool level1_ok = false;                // level1_down_kernel operands packed (64 -> 128)
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
@@ -330,38 +331,45 @@ static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
 // level0_down_kernel operands: every convolution of downs.0 as split-fp16 fragments
 // [tile of 16 output channels][tap][k32][plane hi / scaled lo][lane][e] = W[tile*16 + lane%16][k32*32 + (lane/16)*8 + e][tap]
 // (input channels zero-padded to a multiple of 32)
+static bool pack_level_frag(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int want_co) {
+    auto it = h->index.find(prefix + ".weight");
+    if (it == h->index.end()) return false;
+    const Param& w = h->params[it->second];
+    const int Co = (int)w.shape[0], Ci = (int)w.shape[1], K = (int)w.shape[2];
+    if (Co != want_co || (Ci > 32 && Ci % 32 != 0)) return false;
+    const int KS = (Ci + 31) / 32;
+    Packed pk; pk.T = K; pk.CinP = KS * 32; pk.Npad = Co; pk.N = Co; pk.KC = 32; pk.h3 = true;
+    pk.off = bb.alloc((size_t)(Co / 16) * K * KS * 2 * 64 * 4);
+    uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
+    auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
+    for (int t = 0; t < Co / 16; ++t)
+        for (int tap = 0; tap < K; ++tap)
+            for (int k = 0; k < KS; ++k)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = t * 16 + (lane & 15), ci = k * 32 + (lane >> 4) * 8 + e;
+                        const float v = ci < Ci ? w.host[((size_t)co * Ci + ci) * K + tap] : 0.f;
+                        const _Float16 hv = (_Float16)v;
+                        const float lo = (v - (float)hv) * 2048.0f;
+                        const size_t q0 = (((size_t)t * K + tap) * KS + k) * 2;
+                        base[((q0 + 0) * 64 + lane) * 8 + e] = bits((float)hv);
+                        base[((q0 + 1) * 64 + lane) * 8 + e] = bits(lo);
+                    }
+    h->packed[prefix + "#lvl"] = pk;
+    return true;
+}
+
 static void pack_level0(cindm_unet1d* h, BlobBuilder& bb) {
-    auto frag = [&](const std::string& prefix) -> bool {
-        auto it = h->index.find(prefix + ".weight");
-        if (it == h->index.end()) return false;
-        const Param& w = h->params[it->second];
-        const int Co = (int)w.shape[0], Ci = (int)w.shape[1], K = (int)w.shape[2];
-        if (Co != 64 || (Ci != 64 && Ci > 32)) return false;
-        const int KS = (Ci + 31) / 32;
-        Packed pk; pk.T = K; pk.CinP = KS * 32; pk.Npad = Co; pk.N = Co; pk.KC = 32; pk.h3 = true;
-        pk.off = bb.alloc((size_t)(Co / 16) * K * KS * 2 * 64 * 4);
-        uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
-        auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
-        for (int t = 0; t < Co / 16; ++t)
-            for (int tap = 0; tap < K; ++tap)
-                for (int k = 0; k < KS; ++k)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e) {
-                            const int co = t * 16 + (lane & 15), ci = k * 32 + (lane >> 4) * 8 + e;
-                            const float v = ci < Ci ? w.host[((size_t)co * Ci + ci) * K + tap] : 0.f;
-                            const _Float16 hv = (_Float16)v;
-                            const float lo = (v - (float)hv) * 2048.0f;
-                            const size_t q0 = (((size_t)t * K + tap) * KS + k) * 2;
-                            base[((q0 + 0) * 64 + lane) * 8 + e] = bits((float)hv);
-                            base[((q0 + 1) * 64 + lane) * 8 + e] = bits(lo);
-                        }
-        h->packed[prefix + "#lvl"] = pk;
-        return true;
-    };
     bool ok = true;
     for (const char* p : {"downs.0.0.blocks.0.block.0", "downs.0.0.blocks.1.block.0", "downs.0.1.blocks.0.block.0",
-                          "downs.0.1.blocks.1.block.0", "downs.0.0.residual_conv", "downs.0.3.conv"}) ok = frag(p) && ok;
-    h->level0_ok = ok && h->index.count("downs.0.2.fn.fn.to_qkv.weight") && !h->index.count("downs.0.1.residual_conv.weight");
+                          "downs.0.1.blocks.1.block.0", "downs.0.0.residual_conv", "downs.0.3.conv"}) ok = pack_level_frag(h, bb, p, 64) && ok;
+    h->level0_ok = ok && h->d.transition_dim <= 32 && h->index.count("downs.0.2.fn.fn.to_qkv.weight") && !h->index.count("downs.0.1.residual_conv.weight");
+    // the second level (64 -> 128 channels): level1_down_kernel
+    bool ok1 = h->dims.size() > 2 && h->dims[1] == 64 && h->dims[2] == 128;
+    if (ok1)
+        for (const char* p : {"downs.1.0.blocks.0.block.0", "downs.1.0.blocks.1.block.0", "downs.1.1.blocks.0.block.0",
+                              "downs.1.1.blocks.1.block.0", "downs.1.0.residual_conv", "downs.1.3.conv"}) ok1 = pack_level_frag(h, bb, p, 128) && ok1;
+    h->level1_ok = ok1 && h->index.count("downs.1.2.fn.fn.to_qkv.weight") && !h->index.count("downs.1.1.residual_conv.weight");
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -839,6 +847,42 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             cur = dn;
             continue;
         }
+        static const int lvl1 = getenv("CINDM_LEVEL1") ? atoi(getenv("CINDM_LEVEL1")) : 2;      // samples per workgroup (0 = off)
+        if (ind == 1 && lvl1 && h->level1_ok && att && cur.L <= 16 && (cur.L & 1) == 0 && cur.C == 64 && cur.ld == 64 &&
+            h->packed.count("downs.1.2.fn.fn.to_qkv#site") && h->packed.at("downs.1.2.fn.fn.to_qkv#site").h3) {
+            const int L = cur.L;
+            Ten h1 = E.ten(L, 128), h2 = E.ten(L, 128), sk = E.ten(L, 128), dn = E.ten(L / 2, 128);
+            ++E.launches;
+            if (!E.dry) {
+                Level1Args l;
+                std::memset(&l, 0, sizeof(l));
+                l.x = cur.p; l.h1 = h1.p; l.h2 = h2.p; l.skip = sk.p; l.down = dn.p;
+                const char* cv[4] = {"downs.1.0.blocks.0", "downs.1.0.blocks.1", "downs.1.1.blocks.0", "downs.1.1.blocks.1"};
+                for (int i = 0; i < 4; ++i) {
+                    const std::string cp = cv[i];
+                    l.Wc[i] = E.W(h->packed.at(cp + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cp + ".block.0"));
+                    l.gam[i] = E.V(cp + ".block.2.weight"); l.bet[i] = E.V(cp + ".block.2.bias");
+                }
+                l.Wr = E.W(h->packed.at("downs.1.0.residual_conv#lvl")); l.br = E.B(h->packed.at("downs.1.0.residual_conv"));
+                l.tb0 = h->ttable + h->tb_off.at("downs.1.0"); l.tb1 = h->ttable + h->tb_off.at("downs.1.1"); l.tb_ld = h->tb_ld;
+                l.ln_g = E.V("downs.1.2.fn.norm.g"); l.Wqkv = E.W(h->packed.at("downs.1.2.fn.fn.to_qkv#site"));
+                l.Wo = E.W(h->packed.at("downs.1.2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at("downs.1.2.fn.fn.to_out"));
+                l.Wd = E.W(h->packed.at("downs.1.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.1.3.conv"));
+                l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L; l.Bp = (int)E.rows;
+                const int S = lvl1 >= 4 ? 4 : 2;
+                const dim3 grid((unsigned)((E.rows + S - 1) / S));
+                E.prof_begin(5, 0.0);
+                for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
+                    if (S == 4) hipLaunchKernelGGL(level1_down_kernel<4>, grid, dim3(256), 0, E.stream, l);
+                    else hipLaunchKernelGGL(level1_down_kernel<2>, grid, dim3(256), 0, E.stream, l);
+                }
+                E.prof_end();
+            }
+            E.tap("downs.1.0", h1); E.tap("downs.1.1", h2); E.tap("downs.1.2", sk); E.tap("downs.1.3", dn);
+            skips.push_back(sk);
+            cur = dn;
+            continue;
+        }
         cur = emit_rtb(E, p + ".0", cur, nullptr, co, false, nullptr);
         cur = emit_rtb(E, p + ".1", cur, nullptr, co, need_ln(p + ".2", cur.L), &lnp);
         if (att) cur = emit_attn(E, p + ".2", cur, lnp);
@@ -948,7 +992,7 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         }
     }
     h->tb_ld = tb_ld;
-    h->level0_ok = false;
+    h->level0_ok = false; h->level1_ok = false;
     if (h->use_h3 && h->use_attn_site && h->use_level0 && h->use_local_gn) pack_level0(h, bb);
     if (h->blob) { (void)hipFree(h->blob); h->blob = nullptr; }
     if (h->ttable) { (void)hipFree(h->ttable); h->ttable = nullptr; }

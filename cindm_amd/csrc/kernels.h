@@ -1708,6 +1708,326 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// level1_down_kernel: the second down level (64 -> 128 channels, horizon / 2 <= 16 positions) in one launch.  The
+// level's weights are 1.6 MB, so a workgroup takes NT samples, ONE SAMPLE PER 16-POSITION TILE (own rows and halos in
+// the planes: a tap never crosses samples, GroupNorm / softmax segments are whole tiles), and streams the fragments
+// through a per-tap register ring.  Each wave owns 32 channels = two 16-channel tiles = two GroupNorm groups.
+struct Level1Args {
+    const float* x;                        // [Bp, L, 64]
+    float* h1; float* h2; float* skip; float* down;      // [Bp, L, 128] x 3, [Bp, L/2, 128]
+    const float* Wc[4]; const float* bc[4]; const float* gam[4]; const float* bet[4];
+    const float* Wr; const float* br;
+    const float* tb0; const float* tb1; int tb_ld;
+    const float* ln_g; const float* Wqkv; const float* Wo; const float* bo;
+    const float* Wd; const float* bd;
+    const int* t_ptr; int t_imm;
+    int L, Bp;
+};
+
+// MT x NT tiles of a k-tap convolution; the fragments of tap + 1 are in flight while tap is multiplied
+template <int MT, int NT, int TAPS, int KS, int PITCHB>
+__device__ __forceinline__ void lvlm_conv(const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
+                                          int tile_rows, int stride, int row0, int maxrow, int lane, f32x4 (&out)[MT][NT]) {
+    const int lr = lane & 15, lq = lane >> 4;
+    f32x4 M[MT][NT], Lo[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { M[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float4 wr[2][MT][KS][2];
+    auto load_tap = [&](int tap, int slot) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wr[slot][mt][k][pl] = Wt[((((size_t)mt * TAPS + tap) * KS + k) * 2 + pl) * 64 + lane];
+    };
+    load_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        if (tap + 1 < TAPS) load_tap(tap + 1, (tap + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = min(nt * tile_rows + lr * stride + tap + row0, maxrow) * PITCHB + k * 64 + lq * 16;
+                const half8 xh = *reinterpret_cast<const half8*>(Xh + off);
+                const half8 xl = *reinterpret_cast<const half8*>(Xl + off);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half8 wh = __builtin_bit_cast(half8, wr[tap & 1][mt][k][0]), wl = __builtin_bit_cast(half8, wr[tap & 1][mt][k][1]);
+                    M[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, M[mt][nt], 0, 0, 0);
+                    Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, Lo[mt][nt], 0, 0, 0);
+                    Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, Lo[mt][nt], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) out[mt][nt] = M[mt][nt] + Lo[mt][nt] * H3_INV;
+}
+
+// + bias ; GroupNorm of one 16-channel tile over the L positions of ONE sample tile (all 64 lanes) ; Mish
+__device__ __forceinline__ void lvlm_gn_mish(f32x4& v, const float4 bias, const float4 gam, const float4 bet, int L, int lane) {
+    const int lr = lane & 15;
+    const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, gg[4] = {gam.x, gam.y, gam.z, gam.w}, be[4] = {bet.x, bet.y, bet.z, bet.w};
+    const bool ok = lr < L;
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] += bb[i]; if (ok) s1 += v[i]; }
+    s1 = xsum32(xsum16(row16_sum(s1)));
+    const float inv_n = 1.0f / (16.0f * (float)L);
+    const float mean = s1 * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; if (ok) s2 += d * d; }
+    s2 = xsum32(xsum16(row16_sum(s2)));
+    const float rstd = 1.0f / sqrtf(s2 * inv_n + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = mish_f((v[i] - mean) * rstd * gg[i] + be[i]);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
+    constexpr int C = 128, CI = 64, RS = 20, ROWS = NT * RS, NP = NT * 16;
+    constexpr int XPB = 2 * CI + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
+    constexpr int RBYTES = (2 * ROWS * XPB > 2 * NP * APB) ? 2 * ROWS * XPB : 2 * NP * APB;
+    static_assert(NP * HP * 4 <= RBYTES, "H fits the shared region");
+    __shared__ __attribute__((aligned(16))) unsigned char P[2][2][ROWS * PPB];        // ping-pong activation planes
+    __shared__ __attribute__((aligned(16))) unsigned char R[RBYTES];                  // x planes, then h2 (fp32), then att planes
+    unsigned char* X0h = R; unsigned char* X0l = R + ROWS * XPB;
+    float* H = reinterpret_cast<float*>(R);
+    unsigned char* Aph = R; unsigned char* Apl = R + NP * APB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int L = a.L;
+    const int s0 = blockIdx.x * NT, s_here = min(NT, a.Bp - s0);
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    // ---- stage x: sample tile nt at rows nt*RS + 2 + position; everything else zero ----
+    for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(R)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    {
+        const int c4 = tid & 15;                                         // 16 float4 per row
+#pragma unroll
+        for (int pass = 0; pass < NT; ++pass) {
+            const int nt = pass, p = tid >> 4;                           // 16 positions per pass = one sample tile
+            if (nt < s_here && p < L) {
+                const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(s0 + nt) * L + p) * CI + 4 * c4);
+                half4v hi, lo;
+                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+                lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+                *reinterpret_cast<half4v*>(X0h + (nt * RS + 2 + p) * XPB + 8 * c4) = hi;
+                *reinterpret_cast<half4v*>(X0l + (nt * RS + 2 + p) * XPB + 8 * c4) = lo;
+            }
+        }
+    }
+    const int t0 = 2 * w;                                                // this wave's first 16-channel tile
+    auto cl = [&](int mt) { return (t0 + mt) * 16 + lq * 4; };           // the lane's four channels of tile mt
+    auto ld4 = [&](const float* p, int mt) { return *reinterpret_cast<const float4*>(p + cl(mt)); };
+    auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)t0 * taps * ks * 2 * 64; };
+    // accumulator tile -> planes (rows nt*RS + 2 + position), zero beyond L / beyond the samples of this workgroup
+    auto to_planes = [&](const f32x4 (&v)[2][NT], unsigned char* Ph, unsigned char* Pl) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool ok = lr < L && nt < s_here;
+                half4v hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float f = ok ? v[mt][nt][i] : 0.f;
+                    hi[i] = (_Float16)f; lo[i] = (_Float16)((f - (float)hi[i]) * H3_SCALE);
+                }
+                const int off = (nt * RS + 2 + lr) * PPB + 2 * cl(mt);
+                *reinterpret_cast<half4v*>(Ph + off) = hi;
+                *reinterpret_cast<half4v*>(Pl + off) = lo;
+            }
+    };
+    auto store = [&](const f32x4 (&v)[2][NT], float* dst, int Lo_) {    // dst [Bp, Lo_, 128]
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nt < s_here && lr < Lo_)
+                    *reinterpret_cast<float4*>(dst + ((size_t)(s0 + nt) * Lo_ + lr) * C + cl(mt)) =
+                        make_float4(v[mt][nt][0], v[mt][nt][1], v[mt][nt][2], v[mt][nt][3]);
+    };
+    auto gn_all = [&](f32x4 (&v)[2][NT], int ci) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float4 b = ld4(a.bc[ci], mt), g = ld4(a.gam[ci], mt), be = ld4(a.bet[ci], mt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) lvlm_gn_mish(v[mt][nt], b, g, be, L, lane);
+        }
+    };
+    auto add4 = [&](f32x4 (&v)[2][NT], const float* p) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float4 t = ld4(p, mt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { v[mt][nt][0] += t.x; v[mt][nt][1] += t.y; v[mt][nt][2] += t.z; v[mt][nt][3] += t.w; }
+        }
+    };
+    __syncthreads();
+
+    // ---- block 0 ----
+    f32x4 v[2][NT], r1[2][NT], h1[2][NT], h2[2][NT];
+    lvlm_conv<2, NT, 5, 2, XPB>(wbase(a.Wc[0], 5, 2), X0h, X0l, RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_conv<2, NT, 1, 2, XPB>(wbase(a.Wr, 1, 2), X0h, X0l, RS, 1, 2, ROWS - 1, lane, r1);
+    gn_all(v, 0);
+    add4(v, a.tb0 + (size_t)t_now * a.tb_ld);
+    add4(r1, a.br);
+    to_planes(v, P[0][0], P[0][1]);
+    __syncthreads();
+    lvlm_conv<2, NT, 5, 4, PPB>(wbase(a.Wc[1], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
+    gn_all(v, 1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) h1[mt][nt] = v[mt][nt] + r1[mt][nt];
+    store(h1, a.h1, L);
+    to_planes(h1, P[1][0], P[1][1]);
+    __syncthreads();
+    // ---- block 1 ----
+    lvlm_conv<2, NT, 5, 4, PPB>(wbase(a.Wc[2], 5, 4), P[1][0], P[1][1], RS, 1, 0, ROWS - 1, lane, v);
+    gn_all(v, 2);
+    add4(v, a.tb1 + (size_t)t_now * a.tb_ld);
+    to_planes(v, P[0][0], P[0][1]);
+    __syncthreads();
+    lvlm_conv<2, NT, 5, 4, PPB>(wbase(a.Wc[3], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
+    gn_all(v, 3);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) h2[mt][nt] = v[mt][nt] + h1[mt][nt];
+    store(h2, a.h2, L);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl(mt)]) = make_float4(h2[mt][nt][0], h2[mt][nt][1], h2[mt][nt][2], h2[mt][nt][3]);
+    __syncthreads();
+    // ---- attention: LayerNorm -> planes P[1] ----
+    {
+        const int lrow = tid >> 5, lcol = tid & 31;                      // 32 lanes per row, 8 rows per pass
+        const float4 gv = *reinterpret_cast<const float4*>(a.ln_g + 4 * lcol);
+#pragma unroll
+        for (int r = 0; r < NP / 8; ++r) {
+            const int n = r * 8 + lrow, nt = n >> 4, p = n & 15;
+            const float4 xv = *reinterpret_cast<const float4*>(&H[n * HP + 4 * lcol]);
+            const float s1 = xsum16(row16_sum((xv.x + xv.y) + (xv.z + xv.w)));
+            const float mean = s1 * (1.0f / C);
+            const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+            const float s2 = xsum16(row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)));
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            const bool ok = p < L && nt < s_here;
+            const float y0 = ok ? d0 * rstd * gv.x : 0.f, y1 = ok ? d1 * rstd * gv.y : 0.f, y2 = ok ? d2 * rstd * gv.z : 0.f, y3 = ok ? d3 * rstd * gv.w : 0.f;
+            half4v hi, lo;
+            hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+            lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&P[1][0][(nt * RS + 2 + p) * PPB + 8 * lcol]) = hi;
+            *reinterpret_cast<half4v*>(&P[1][1][(nt * RS + 2 + p) * PPB + 8 * lcol]) = lo;
+        }
+    }
+    __syncthreads();
+    // ---- q, k, v of head w (tiles 2w, 2w+1 | 8+2w.. | 16+2w..), K = 128: ring over the four k32 steps ----
+    f32x4 qa[2][NT], ka[NT][2], va[NT][2];
+    {
+        const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+        f32x4 qM[2][NT], qL[2][NT], kM[NT][2], kL[NT][2], vM[NT][2], vL[NT][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                qM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; qL[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                kM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; kL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; vL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        float4 wq[2][6][2];
+        auto load_k = [&](int k, int slot) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int tile = (s >> 1) * 8 + 2 * w + (s & 1);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wq[slot][s][pl] = Wq4[(((size_t)tile * 4 + k) * 2 + pl) * 64 + lane];
+            }
+        };
+        load_k(0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k + 1 < 4) load_k(k + 1, (k + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            half8 wh[6], wl[6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) { wh[s] = __builtin_bit_cast(half8, wq[k & 1][s][0]); wl[s] = __builtin_bit_cast(half8, wq[k & 1][s][1]); }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (nt * RS + 2 + lr) * PPB + k * 64 + lq * 16;
+                const half8 yh = *reinterpret_cast<const half8*>(&P[1][0][off]);
+                const half8 yl = *reinterpret_cast<const half8*>(&P[1][1][off]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    qM[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], yh, qM[i][nt], 0, 0, 0);
+                    qL[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], yl, qL[i][nt], 0, 0, 0);
+                    qL[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], yh, qL[i][nt], 0, 0, 0);
+                    kM[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[2 + i], kM[nt][i], 0, 0, 0);
+                    kL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[2 + i], kL[nt][i], 0, 0, 0);
+                    kL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[2 + i], kL[nt][i], 0, 0, 0);
+                    vM[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[4 + i], vM[nt][i], 0, 0, 0);
+                    vL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[4 + i], vL[nt][i], 0, 0, 0);
+                    vL[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[4 + i], vL[nt][i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                qa[i][j] = qM[i][j] + qL[i][j] * H3_INV;
+                ka[j][i] = kM[j][i] + kL[j][i] * H3_INV;
+                va[j][i] = vM[j][i] + vL[j][i] * H3_INV;
+            }
+    }
+    f32x4 att[2][NT];
+    attn_site_core<NT>(qa, ka, va, att, s_here, s_here * 16, 16, L, lq, lr);
+    __syncthreads();                                          // every wave is done with H (the att planes alias it)
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            half4v hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)att[et][nt][i]; lo[i] = (_Float16)((att[et][nt][i] - (float)hi[i]) * H3_SCALE); }
+            const int off = (nt * 16 + lr) * APB + 2 * (w * 32 + et * 16 + lq * 4);
+            *reinterpret_cast<half4v*>(Aph + off) = hi;
+            *reinterpret_cast<half4v*>(Apl + off) = lo;
+        }
+    __syncthreads();
+    f32x4 h3[2][NT];
+    lvlm_conv<2, NT, 1, 4, APB>(wbase(a.Wo, 1, 4), Aph, Apl, 16, 1, 0, NP - 1, lane, h3);
+    add4(h3, a.bo);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) h3[mt][nt] += h2[mt][nt];
+    store(h3, a.skip, L);
+    to_planes(h3, P[0][0], P[0][1]);
+    __syncthreads();
+    // ---- Downsample1d (k = 3, stride 2, pad 1): rows nt*RS + 2*n' + tap + 1 ----
+    {
+        f32x4 d[2][NT];
+        lvlm_conv<2, NT, 3, 4, PPB>(wbase(a.Wd, 3, 4), P[0][0], P[0][1], RS, 2, 1, ROWS - 1, lane, d);
+        add4(d, a.bd);
+        store(d, a.down, L / 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Counter-based Gaussian noise: Philox4x32-10 keyed by seed, counter = (element/4, sample, step, 0),
 // Box-Muller on the four 32-bit outputs.  Pure function of (seed, global sample, step, element):
 // results do not depend on the number of GPUs / batch partition.
