@@ -847,7 +847,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             cur = dn;
             continue;
         }
-        static const int lvl1 = getenv("CINDM_LEVEL1") ? atoi(getenv("CINDM_LEVEL1")) : 2;      // samples per workgroup (0 = off)
+        static const int lvl1 = getenv("CINDM_LEVEL1") ? atoi(getenv("CINDM_LEVEL1")) : 1;      // samples per workgroup: 1 (default) or 2; 0 = off
         if (ind == 1 && lvl1 && h->level1_ok && att && cur.L <= 16 && (cur.L & 1) == 0 && cur.C == 64 && cur.ld == 64 &&
             h->packed.count("downs.1.2.fn.fn.to_qkv#site") && h->packed.at("downs.1.2.fn.fn.to_qkv#site").h3) {
             const int L = cur.L;
@@ -869,11 +869,13 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wo = E.W(h->packed.at("downs.1.2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at("downs.1.2.fn.fn.to_out"));
                 l.Wd = E.W(h->packed.at("downs.1.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.1.3.conv"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L; l.Bp = (int)E.rows;
-                const int S = lvl1 >= 4 ? 4 : 2;
+                static const int dbg4 = getenv("CINDM_DBG4") ? atoi(getenv("CINDM_DBG4")) : 0;
+                l.dbg = dbg4;
+                const int S = lvl1 == 1 ? 1 : 2;
                 const dim3 grid((unsigned)((E.rows + S - 1) / S));
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
-                    if (S == 4) hipLaunchKernelGGL(level1_down_kernel<4>, grid, dim3(256), 0, E.stream, l);
+                    if (S == 1) hipLaunchKernelGGL(level1_down_kernel<1>, grid, dim3(256), 0, E.stream, l);
                     else hipLaunchKernelGGL(level1_down_kernel<2>, grid, dim3(256), 0, E.stream, l);
                 }
                 E.prof_end();

@@ -1722,11 +1722,32 @@ struct Level1Args {
     const float* Wd; const float* bd;
     const int* t_ptr; int t_imm;
     int L, Bp;
+    int dbg;                               // timing ablation: return after phase dbg (wrong results)
 };
 
-// MT x NT tiles of a k-tap convolution; the fragments of tap + 1 are in flight while tap is multiplied
-template <int MT, int NT, int TAPS, int KS, int PITCHB>
-__device__ __forceinline__ void lvlm_conv(const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
+// MT x NT tiles of a k-tap convolution.  The weight fragments stream through a register ring of RING taps that the
+// CALLER owns: lvlm_prefetch() issues the first RING - 1 taps (while the previous layer's epilogue runs -- a workgroup of
+// these kernels is alone on its CU, nothing else hides a load), lvlm_conv() keeps RING - 1 taps in flight.
+constexpr int LVL_RING = 3;
+template <int MT, int KSMAX>
+struct LvlRing { float4 wr[LVL_RING][MT][KSMAX][2]; };
+
+template <int MT, int TAPS, int KS, int KSMAX>
+__device__ __forceinline__ void lvlm_load_tap(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, int tap, int slot, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) rg.wr[slot][mt][k][pl] = Wt[((((size_t)mt * TAPS + tap) * KS + k) * 2 + pl) * 64 + lane];
+}
+template <int MT, int TAPS, int KS, int KSMAX>
+__device__ __forceinline__ void lvlm_prefetch(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, int lane) {
+#pragma unroll
+    for (int tap = 0; tap < LVL_RING - 1; ++tap) if (tap < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap, tap % LVL_RING, lane);
+}
+template <int MT, int NT, int TAPS, int KS, int PITCHB, int KSMAX>
+__device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
                                           int tile_rows, int stride, int row0, int maxrow, int lane, f32x4 (&out)[MT][NT]) {
     const int lr = lane & 15, lq = lane >> 4;
     f32x4 M[MT][NT], Lo[MT][NT];
@@ -1734,35 +1755,31 @@ __device__ __forceinline__ void lvlm_conv(const float4* __restrict__ Wt, const u
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { M[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float4 wr[2][MT][KS][2];
-    auto load_tap = [&](int tap, int slot) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int k = 0; k < KS; ++k)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) wr[slot][mt][k][pl] = Wt[((((size_t)mt * TAPS + tap) * KS + k) * 2 + pl) * 64 + lane];
-    };
-    load_tap(0, 0);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-        if (tap + 1 < TAPS) load_tap(tap + 1, (tap + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (tap + LVL_RING - 1 < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap + LVL_RING - 1, (tap + LVL_RING - 1) % LVL_RING, lane);
+        // all activation fragments of the tap first (one exposed LDS latency per tap instead of one per k-step), then the MFMAs
+        half8 xh[KS][NT], xl[KS][NT];
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int off = min(nt * tile_rows + lr * stride + tap + row0, maxrow) * PITCHB + k * 64 + lq * 16;
-                const half8 xh = *reinterpret_cast<const half8*>(Xh + off);
-                const half8 xl = *reinterpret_cast<const half8*>(Xl + off);
+                xh[k][nt] = *reinterpret_cast<const half8*>(Xh + off);
+                xl[k][nt] = *reinterpret_cast<const half8*>(Xl + off);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const half8 wh = __builtin_bit_cast(half8, wr[tap & 1][mt][k][0]), wl = __builtin_bit_cast(half8, wr[tap & 1][mt][k][1]);
-                    M[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, M[mt][nt], 0, 0, 0);
-                    Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, Lo[mt][nt], 0, 0, 0);
-                    Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, Lo[mt][nt], 0, 0, 0);
+                    const half8 wh = __builtin_bit_cast(half8, rg.wr[tap % LVL_RING][mt][k][0]), wl = __builtin_bit_cast(half8, rg.wr[tap % LVL_RING][mt][k][1]);
+                    M[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[k][nt], M[mt][nt], 0, 0, 0);
+                    Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[k][nt], Lo[mt][nt], 0, 0, 0);
+                    Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[k][nt], Lo[mt][nt], 0, 0, 0);
                 }
-            }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1801,10 +1818,25 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     unsigned char* X0h = R; unsigned char* X0l = R + ROWS * XPB;
     float* H = reinterpret_cast<float*>(R);
     unsigned char* Aph = R; unsigned char* Apl = R + NP * APB;
+    // per-channel parameter vectors, fetched once: 0-3 conv bias, 4-7 GroupNorm weight, 8-11 GroupNorm bias, 12 / 13 time bias
+    // of the two blocks (row t), 14 residual_conv bias, 15 to_out bias, 16 downsample bias
+    __shared__ __attribute__((aligned(16))) float PV[17][C];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int L = a.L;
     const int s0 = blockIdx.x * NT, s_here = min(NT, a.Bp - s0);
     const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t0 = 2 * w;                                                // this wave's first 16-channel tile
+    auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)t0 * taps * ks * 2 * 64; };
+    LvlRing<2, 4> ring;                                                  // convolution fragments
+    LvlRing<2, 2> ring_r;                                                // residual_conv fragments (one tap)
+    lvlm_prefetch<2, 5, 2, 4>(ring, wbase(a.Wc[0], 5, 2), lane);
+    lvlm_prefetch<2, 1, 2, 2>(ring_r, wbase(a.Wr, 1, 2), lane);
+    if (tid < C) {
+        const float* src[17] = {a.bc[0], a.bc[1], a.bc[2], a.bc[3], a.gam[0], a.gam[1], a.gam[2], a.gam[3], a.bet[0], a.bet[1], a.bet[2], a.bet[3],
+                                a.tb0 + (size_t)t_now * a.tb_ld, a.tb1 + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bd};
+#pragma unroll
+        for (int i = 0; i < 17; ++i) PV[i][tid] = src[i][tid];
+    }
     // ---- stage x: sample tile nt at rows nt*RS + 2 + position; everything else zero ----
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(R)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1825,10 +1857,8 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
             }
         }
     }
-    const int t0 = 2 * w;                                                // this wave's first 16-channel tile
     auto cl = [&](int mt) { return (t0 + mt) * 16 + lq * 4; };           // the lane's four channels of tile mt
-    auto ld4 = [&](const float* p, int mt) { return *reinterpret_cast<const float4*>(p + cl(mt)); };
-    auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)t0 * taps * ks * 2 * 64; };
+    auto ld4 = [&](int vec, int mt) { return *reinterpret_cast<const float4*>(&PV[vec][cl(mt)]); };
     // accumulator tile -> planes (rows nt*RS + 2 + position), zero beyond L / beyond the samples of this workgroup
     auto to_planes = [&](const f32x4 (&v)[2][NT], unsigned char* Ph, unsigned char* Pl) {
 #pragma unroll
@@ -1859,31 +1889,34 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     auto gn_all = [&](f32x4 (&v)[2][NT], int ci) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const float4 b = ld4(a.bc[ci], mt), g = ld4(a.gam[ci], mt), be = ld4(a.bet[ci], mt);
+            const float4 b = ld4(ci, mt), g = ld4(4 + ci, mt), be = ld4(8 + ci, mt);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) lvlm_gn_mish(v[mt][nt], b, g, be, L, lane);
         }
     };
-    auto add4 = [&](f32x4 (&v)[2][NT], const float* p) {
+    auto add4 = [&](f32x4 (&v)[2][NT], int vec) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const float4 t = ld4(p, mt);
+            const float4 t = ld4(vec, mt);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { v[mt][nt][0] += t.x; v[mt][nt][1] += t.y; v[mt][nt][2] += t.z; v[mt][nt][3] += t.w; }
         }
     };
     __syncthreads();
+    if (a.dbg == 1) return;
 
     // ---- block 0 ----
     f32x4 v[2][NT], r1[2][NT], h1[2][NT], h2[2][NT];
-    lvlm_conv<2, NT, 5, 2, XPB>(wbase(a.Wc[0], 5, 2), X0h, X0l, RS, 1, 0, ROWS - 1, lane, v);
-    lvlm_conv<2, NT, 1, 2, XPB>(wbase(a.Wr, 1, 2), X0h, X0l, RS, 1, 2, ROWS - 1, lane, r1);
+    lvlm_conv<2, NT, 5, 2, XPB, 4>(ring, wbase(a.Wc[0], 5, 2), X0h, X0l, RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_prefetch<2, 5, 4, 4>(ring, wbase(a.Wc[1], 5, 4), lane);
+    lvlm_conv<2, NT, 1, 2, XPB, 2>(ring_r, wbase(a.Wr, 1, 2), X0h, X0l, RS, 1, 2, ROWS - 1, lane, r1);
     gn_all(v, 0);
-    add4(v, a.tb0 + (size_t)t_now * a.tb_ld);
-    add4(r1, a.br);
+    add4(v, 12);
+    add4(r1, 14);
     to_planes(v, P[0][0], P[0][1]);
     __syncthreads();
-    lvlm_conv<2, NT, 5, 4, PPB>(wbase(a.Wc[1], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_conv<2, NT, 5, 4, PPB, 4>(ring, wbase(a.Wc[1], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_prefetch<2, 5, 4, 4>(ring, wbase(a.Wc[2], 5, 4), lane);
     gn_all(v, 1);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1892,13 +1925,16 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     store(h1, a.h1, L);
     to_planes(h1, P[1][0], P[1][1]);
     __syncthreads();
+    if (a.dbg == 2) return;
     // ---- block 1 ----
-    lvlm_conv<2, NT, 5, 4, PPB>(wbase(a.Wc[2], 5, 4), P[1][0], P[1][1], RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_conv<2, NT, 5, 4, PPB, 4>(ring, wbase(a.Wc[2], 5, 4), P[1][0], P[1][1], RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_prefetch<2, 5, 4, 4>(ring, wbase(a.Wc[3], 5, 4), lane);
     gn_all(v, 2);
-    add4(v, a.tb1 + (size_t)t_now * a.tb_ld);
+    add4(v, 13);
     to_planes(v, P[0][0], P[0][1]);
     __syncthreads();
-    lvlm_conv<2, NT, 5, 4, PPB>(wbase(a.Wc[3], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_conv<2, NT, 5, 4, PPB, 4>(ring, wbase(a.Wc[3], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
+    lvlm_prefetch<2, 1, 4, 4>(ring, wbase(a.Wo, 1, 4), lane);          // to_out fragments: in flight through the attention
     gn_all(v, 3);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1911,6 +1947,7 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
         for (int nt = 0; nt < NT; ++nt)
             *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl(mt)]) = make_float4(h2[mt][nt][0], h2[mt][nt][1], h2[mt][nt][2], h2[mt][nt][3]);
     __syncthreads();
+    if (a.dbg == 3) return;
     // ---- attention: LayerNorm -> planes P[1] ----
     {
         const int lrow = tid >> 5, lcol = tid & 31;                      // 32 lanes per row, 8 rows per pass
@@ -1935,6 +1972,7 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
         }
     }
     __syncthreads();
+    if (a.dbg == 4) return;
     // ---- q, k, v of head w (tiles 2w, 2w+1 | 8+2w.. | 16+2w..), K = 128: ring over the four k32 steps ----
     f32x4 qa[2][NT], ka[NT][2], va[NT][2];
     {
@@ -2008,9 +2046,11 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
             *reinterpret_cast<half4v*>(Apl + off) = lo;
         }
     __syncthreads();
+    if (a.dbg == 5) return;
     f32x4 h3[2][NT];
-    lvlm_conv<2, NT, 1, 4, APB>(wbase(a.Wo, 1, 4), Aph, Apl, 16, 1, 0, NP - 1, lane, h3);
-    add4(h3, a.bo);
+    lvlm_conv<2, NT, 1, 4, APB, 4>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 16, 1, 0, NP - 1, lane, h3);
+    lvlm_prefetch<2, 3, 4, 4>(ring, wbase(a.Wd, 3, 4), lane);
+    add4(h3, 15);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -2018,11 +2058,12 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     store(h3, a.skip, L);
     to_planes(h3, P[0][0], P[0][1]);
     __syncthreads();
+    if (a.dbg == 6) return;
     // ---- Downsample1d (k = 3, stride 2, pad 1): rows nt*RS + 2*n' + tap + 1 ----
     {
         f32x4 d[2][NT];
-        lvlm_conv<2, NT, 3, 4, PPB>(wbase(a.Wd, 3, 4), P[0][0], P[0][1], RS, 2, 1, ROWS - 1, lane, d);
-        add4(d, a.bd);
+        lvlm_conv<2, NT, 3, 4, PPB, 4>(ring, wbase(a.Wd, 3, 4), P[0][0], P[0][1], RS, 2, 1, ROWS - 1, lane, d);
+        add4(d, 16);
         store(d, a.down, L / 2);
     }
 }
