@@ -63,6 +63,7 @@ struct cindm_unet1d {
     bool use_attn_site = true;             // one launch per attention site, attn1d_site_kernel (CINDM_ATTN_SITE=0 disables)
     bool level0_ok = false;                // level0_down_kernel operands packed (dim 64, F <= 32, attention, down-sampling)
     bool level1_ok = false;                // level1_down_kernel operands packed (64 -> 128)
+    bool ups_last_ok = false;              // ups_last_kernel operands packed
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
@@ -331,14 +332,22 @@ static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
 // level0_down_kernel operands: every convolution of downs.0 as split-fp16 fragments
 // [tile of 16 output channels][tap][k32][plane hi / scaled lo][lane][e] = W[tile*16 + lane%16][k32*32 + (lane/16)*8 + e][tap]
 // (input channels zero-padded to a multiple of 32)
-static bool pack_level_frag(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int want_co) {
+static bool pack_level_frag(cindm_unet1d* h, BlobBuilder& bb, const std::string& prefix, int want_co, int kind = 0) {
+    // kind 0: Conv1d weight [Co][Ci][K]; kind 1: ConvTranspose1d weight [Ci][Co][K]; want_co < 0: any Co <= 16, padded to one tile
     auto it = h->index.find(prefix + ".weight");
-    if (it == h->index.end()) return false;
+    if (it == h->index.end()) {
+        if (getenv("CINDM_VERBOSE")) fprintf(stderr, "[cindm] level frag %s: no such parameter\n", prefix.c_str());
+        return false;
+    }
     const Param& w = h->params[it->second];
-    const int Co = (int)w.shape[0], Ci = (int)w.shape[1], K = (int)w.shape[2];
-    if (Co != want_co || (Ci > 32 && Ci % 32 != 0)) return false;
+    const int Co_ = (int)w.shape[kind == 1 ? 1 : 0], Ci = (int)w.shape[kind == 1 ? 0 : 1], K = (int)w.shape[2];
+    if ((want_co >= 0 && Co_ != want_co) || (want_co < 0 && Co_ > 16) || (Ci > 32 && Ci % 32 != 0)) {
+        if (getenv("CINDM_VERBOSE")) fprintf(stderr, "[cindm] level frag %s rejected: Co %d Ci %d K %d\n", prefix.c_str(), Co_, Ci, K);
+        return false;
+    }
+    const int Co = want_co < 0 ? 16 : Co_;
     const int KS = (Ci + 31) / 32;
-    Packed pk; pk.T = K; pk.CinP = KS * 32; pk.Npad = Co; pk.N = Co; pk.KC = 32; pk.h3 = true;
+    Packed pk; pk.T = K; pk.CinP = KS * 32; pk.Npad = Co; pk.N = Co_; pk.KC = 32; pk.h3 = true;
     pk.off = bb.alloc((size_t)(Co / 16) * K * KS * 2 * 64 * 4);
     uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
     auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
@@ -348,7 +357,8 @@ static bool pack_level_frag(cindm_unet1d* h, BlobBuilder& bb, const std::string&
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e) {
                         const int co = t * 16 + (lane & 15), ci = k * 32 + (lane >> 4) * 8 + e;
-                        const float v = ci < Ci ? w.host[((size_t)co * Ci + ci) * K + tap] : 0.f;
+                        float v = 0.f;
+                        if (ci < Ci && co < Co_) v = (kind == 1) ? w.host[((size_t)ci * Co_ + co) * K + tap] : w.host[((size_t)co * Ci + ci) * K + tap];
                         const _Float16 hv = (_Float16)v;
                         const float lo = (v - (float)hv) * 2048.0f;
                         const size_t q0 = (((size_t)t * K + tap) * KS + k) * 2;
@@ -370,6 +380,19 @@ static void pack_level0(cindm_unet1d* h, BlobBuilder& bb) {
         for (const char* p : {"downs.1.0.blocks.0.block.0", "downs.1.0.blocks.1.block.0", "downs.1.1.blocks.0.block.0",
                               "downs.1.1.blocks.1.block.0", "downs.1.0.residual_conv", "downs.1.3.conv"}) ok1 = pack_level_frag(h, bb, p, 128) && ok1;
     h->level1_ok = ok1 && h->index.count("downs.1.2.fn.fn.to_qkv.weight") && !h->index.count("downs.1.1.residual_conv.weight");
+    // the finest up level + output head: ups_last_kernel
+    const int nres = h->d.n_mults;
+    bool ok2 = ok1 && nres >= 3 && h->d.transition_dim <= 16 && h->d.transition_dim % 4 == 0;
+    if (ok2) {
+        const std::string u = "ups." + std::to_string(nres - 2);
+        for (const std::string& p : {u + ".0.blocks.0.block.0", u + ".0.blocks.1.block.0", u + ".0.residual_conv"}) ok2 = pack_level_frag(h, bb, p, 128) && ok2;
+        for (const std::string& p : {u + ".1.blocks.0.block.0", u + ".1.blocks.1.block.0", u + ".1.residual_conv",
+                                     std::string("final_conv.0.block.0")}) ok2 = pack_level_frag(h, bb, p, 64) && ok2;
+        ok2 = pack_level_frag(h, bb, u + ".3.conv", 64, 1) && ok2;
+        ok2 = pack_level_frag(h, bb, "final_conv.1", -1) && ok2;
+        ok2 = ok2 && h->index.count(u + ".2.fn.fn.to_qkv.weight");
+    }
+    h->ups_last_ok = ok2;
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -898,6 +921,39 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
         const int ci = h->dims[nres - 1 - ind], co = h->dims[nres - ind];
         const std::string p = "ups." + std::to_string(ind);
         Ten skip = skips.back(); skips.pop_back();
+        static const int upl = getenv("CINDM_UPS_LAST") ? atoi(getenv("CINDM_UPS_LAST")) : 1;
+        if (getenv("CINDM_VERBOSE") && E.dry) fprintf(stderr, "[cindm] ups ind %d nres %d ok %d att %d L %d C %d ld %d sC %d sld %d\n", ind, nres, (int)h->ups_last_ok, (int)att, cur.L, cur.C, cur.ld, skip.C, skip.ld);
+        if (upl && ind == nres - 2 && h->ups_last_ok && att && cur.L <= 16 && cur.C == 128 && cur.ld == 128 && skip.C == 128 && skip.ld == 128 &&
+            h->packed.count(p + ".2.fn.fn.to_qkv#site") && h->packed.at(p + ".2.fn.fn.to_qkv#site").h3 && h->packed.count(p + ".3.conv")) {
+            // the level and the output head in one launch (ups_last_kernel)
+            const int L = cur.L;
+            Ten h1 = E.ten(L, 128), h2 = E.ten(L, 64), h3 = E.ten(L, 64), up = E.ten(2 * L, 64), ypre = E.ten(2 * L, 64);
+            ++E.launches;
+            if (!E.dry) {
+                UpsLastArgs l;
+                std::memset(&l, 0, sizeof(l));
+                l.x = cur.p; l.skip = skip.p; l.h1 = h1.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p; l.ypre = ypre.p; l.eps = eps; l.F = d.transition_dim;
+                const std::string cv[5] = {p + ".0.blocks.0", p + ".0.blocks.1", p + ".1.blocks.0", p + ".1.blocks.1", "final_conv.0"};
+                for (int i = 0; i < 5; ++i) {
+                    l.Wc[i] = E.W(h->packed.at(cv[i] + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cv[i] + ".block.0"));
+                    l.gam[i] = E.V(cv[i] + ".block.2.weight"); l.bet[i] = E.V(cv[i] + ".block.2.bias");
+                }
+                l.Wr0 = E.W(h->packed.at(p + ".0.residual_conv#lvl")); l.br0 = E.B(h->packed.at(p + ".0.residual_conv"));
+                l.Wr1 = E.W(h->packed.at(p + ".1.residual_conv#lvl")); l.br1 = E.B(h->packed.at(p + ".1.residual_conv"));
+                l.tb0 = h->ttable + h->tb_off.at(p + ".0"); l.tb1 = h->ttable + h->tb_off.at(p + ".1"); l.tb_ld = h->tb_ld;
+                l.ln_g = E.V(p + ".2.fn.norm.g"); l.Wqkv = E.W(h->packed.at(p + ".2.fn.fn.to_qkv#site"));
+                l.Wo = E.W(h->packed.at(p + ".2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at(p + ".2.fn.fn.to_out"));
+                l.Wu = E.W(h->packed.at(p + ".3.conv#lvl")); l.bu = E.B(h->packed.at(p + ".3.conv"));
+                l.Wf = E.W(h->packed.at("final_conv.1#lvl")); l.bf = E.B(h->packed.at("final_conv.1"));
+                l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
+                E.prof_begin(5, 0.0);
+                for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
+                    hipLaunchKernelGGL(ups_last_kernel, dim3((unsigned)E.rows), dim3(256), 0, E.stream, l);
+                E.prof_end();
+            }
+            E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre);
+            return 0;
+        }
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
         cur = emit_rtb(E, p + ".1", cur, nullptr, ci, need_ln(p + ".2", cur.L), &lnp);
         if (att) cur = emit_attn(E, p + ".2", cur, lnp);
@@ -994,8 +1050,9 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         }
     }
     h->tb_ld = tb_ld;
-    h->level0_ok = false; h->level1_ok = false;
+    h->level0_ok = false; h->level1_ok = false; h->ups_last_ok = false;
     if (h->use_h3 && h->use_attn_site && h->use_level0 && h->use_local_gn) pack_level0(h, bb);
+    if (getenv("CINDM_VERBOSE")) fprintf(stderr, "[cindm] fused levels: level0 %d level1 %d ups_last %d\n", (int)h->level0_ok, (int)h->level1_ok, (int)h->ups_last_ok);
     if (h->blob) { (void)hipFree(h->blob); h->blob = nullptr; }
     if (h->ttable) { (void)hipFree(h->ttable); h->ttable = nullptr; }
     h->blob_floats = bb.data.size();

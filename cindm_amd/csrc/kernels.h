@@ -1746,7 +1746,9 @@ __device__ __forceinline__ void lvlm_prefetch(LvlRing<MT, KSMAX>& rg, const floa
 #pragma unroll
     for (int tap = 0; tap < LVL_RING - 1; ++tap) if (tap < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap, tap % LVL_RING, lane);
 }
-template <int MT, int NT, int TAPS, int KS, int PITCHB, int KSMAX>
+// RMODE 1 = ConvTranspose1d(k = 4, stride 2, pad 1): output position n reads input (n + 1 - tap) / 2 when that is a whole
+// number >= 0 (rows beyond the input are zero), otherwise the zero halo row 0
+template <int MT, int NT, int TAPS, int KS, int PITCHB, int KSMAX, int RMODE = 0>
 __device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
                                           int tile_rows, int stride, int row0, int maxrow, int lane, f32x4 (&out)[MT][NT]) {
     const int lr = lane & 15, lq = lane >> 4;
@@ -1764,7 +1766,9 @@ __device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX>& rg, const float4* 
         for (int k = 0; k < KS; ++k)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int off = min(nt * tile_rows + lr * stride + tap + row0, maxrow) * PITCHB + k * 64 + lq * 16;
+                int row = nt * tile_rows + lr * stride + tap + row0;
+                if constexpr (RMODE == 1) { const int q = nt * 16 + lr + 1 - tap; row = (q >= 0 && !(q & 1)) ? (q >> 1) + 2 : 0; }
+                const int off = min(row, maxrow) * PITCHB + k * 64 + lq * 16;
                 xh[k][nt] = *reinterpret_cast<const half8*>(Xh + off);
                 xl[k][nt] = *reinterpret_cast<const half8*>(Xl + off);
             }
@@ -2065,6 +2069,268 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
         lvlm_conv<2, NT, 3, 4, PPB, 4>(ring, wbase(a.Wd, 3, 4), P[0][0], P[0][1], RS, 2, 1, ROWS - 1, lane, d);
         add4(d, 16);
         store(d, a.down, L / 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ups_last_kernel: the finest up level and the output head in one launch, one sample per workgroup:
+//   cat(x, skip) [L, 256] -> ResidualTemporalBlock(256 -> 128) -> ResidualTemporalBlock(128 -> 64) -> attention site(64)
+//   -> Upsample1d (ConvTranspose1d k4 s2 p1, L -> 2L) -> final Conv1dBlock(64 -> 64, k5) -> Conv1d(64 -> F, 1)
+// (model/diffusion_1d.py:576-583, :635-646, :100-106, :605-608).  Same machinery as the down-level kernels; 8 launches
+// become one.  In the 128-channel block a wave owns two 16-channel tiles (= two GroupNorm groups), afterwards one.
+struct UpsLastArgs {
+    const float* x; const float* skip;                   // [Bp, L, 128] each (torch.cat((x, h.pop()), dim=1))
+    float* h1; float* h2; float* h3; float* up; float* ypre; float* eps; int F;      // h1 [Bp, L, 128]; h2, h3 [Bp, L, 64]; up, ypre [Bp, 2L, 64]
+    const float* Wc[5]; const float* bc[5]; const float* gam[5]; const float* bet[5];      // four block convolutions + final_conv.0
+    const float* Wr0; const float* br0; const float* Wr1; const float* br1;                 // residual_conv of the two blocks
+    const float* tb0; const float* tb1; int tb_ld;
+    const float* ln_g; const float* Wqkv; const float* Wo; const float* bo;
+    const float* Wu; const float* bu;
+    const float* Wf; const float* bf;                    // final 1x1, one 16-channel tile (rows >= F are zero)
+    const int* t_ptr; int t_imm;
+    int L;
+};
+
+__global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
+    constexpr int C = 64, CB = 128, CI = 256, NP1 = 16, NP2 = 32, ROWS1 = NP1 + 4, ROWS2 = NP2 + 4;
+    constexpr int XPB = 2 * CI + 16, QPB = 2 * CB + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char XI[2][ROWS1 * XPB];
+    __shared__ __attribute__((aligned(16))) unsigned char Q[2][2][ROWS1 * QPB];         // 128-channel planes of the first block
+    __shared__ __attribute__((aligned(16))) unsigned char P[2][2][ROWS2 * PPB];         // 64-channel planes
+    __shared__ __attribute__((aligned(16))) unsigned char R[2 * NP1 * APB];            // h2 in fp32 for the LayerNorm, then the att planes
+    // parameter vectors: 128-wide 0-2 conv1 (bias, GN weight, GN bias), 3-5 conv2, 6 time bias, 7 residual bias;
+    // 64-wide 0-2 conv3, 3-5 conv4, 6-8 final conv, 9 time bias, 10 residual bias, 11 to_out, 12 upsample, 13 final 1x1
+    __shared__ __attribute__((aligned(16))) float PVB[8][CB];
+    __shared__ __attribute__((aligned(16))) float PV[14][C];
+    static_assert(NP1 * HP * 4 <= 2 * NP1 * APB, "H fits the shared region");
+    float* H = reinterpret_cast<float*>(R);
+    unsigned char* Aph = R; unsigned char* Apl = R + NP1 * APB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int L = a.L, L2 = 2 * a.L, b = blockIdx.x;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int c0 = w * 16, cl = c0 + lq * 4;
+    auto clb = [&](int mt) { return (2 * w + mt) * 16 + lq * 4; };       // the lane's channels in the 128-channel block
+    auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)w * taps * ks * 2 * 64; };
+    LvlRing<1, 8> ring, ring_r;                                          // weight rings (one 16-channel tile at a time)
+    auto wtile = [&](const float* W, int tile, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)tile * taps * ks * 2 * 64; };
+    lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), lane);
+    lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), lane);
+    if (tid < CB) {
+        const float* src[8] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb0 + (size_t)t_now * a.tb_ld, a.br0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) PVB[i][tid] = src[i][tid];
+    } else if (tid < CB + C) {
+        const int c = tid - CB;
+        const float* src[13] = {a.bc[2], a.gam[2], a.bet[2], a.bc[3], a.gam[3], a.bet[3], a.bc[4], a.gam[4], a.bet[4],
+                                a.tb1 + (size_t)t_now * a.tb_ld, a.br1, a.bo, a.bu};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) PV[i][c] = src[i][c];
+        PV[13][c] = c < a.F ? a.bf[c] : 0.f;
+    }
+    for (int i = tid; i < 2 * ROWS1 * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    {
+        const int p = tid >> 4, c4 = tid & 15;                           // 16 positions x 16 float4, four channel quarters
+        if (p < L) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cf = c4 + 16 * q;                              // float4 index over the 256 channels
+                const float* src = cf < 32 ? a.x + ((size_t)b * L + p) * 128 + 4 * cf : a.skip + ((size_t)b * L + p) * 128 + 4 * (cf - 32);
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                half4v hi, lo;
+                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+                lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+                *reinterpret_cast<half4v*>(&XI[0][(p + 2) * XPB + 8 * cf]) = hi;
+                *reinterpret_cast<half4v*>(&XI[1][(p + 2) * XPB + 8 * cf]) = lo;
+            }
+        }
+    }
+    auto pv4 = [&](int vec) { return *reinterpret_cast<const float4*>(&PV[vec][cl]); };
+    auto pvb4 = [&](int vec, int mt) { return *reinterpret_cast<const float4*>(&PVB[vec][clb(mt)]); };
+    auto add4 = [&](f32x4& v, const float4 t) { v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; };
+    auto q_planes = [&](const f32x4 (&v)[2][1], unsigned char* Ph, unsigned char* Pl) {      // 128-channel tile -> planes, rows position + 2
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            half4v hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f = lr < L ? v[mt][0][i] : 0.f;
+                hi[i] = (_Float16)f; lo[i] = (_Float16)((f - (float)hi[i]) * H3_SCALE);
+            }
+            const int off = (lr + 2) * QPB + 2 * clb(mt);
+            *reinterpret_cast<half4v*>(Ph + off) = hi;
+            *reinterpret_cast<half4v*>(Pl + off) = lo;
+        }
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    // ---- block 0 (256 -> 128, residual_conv): the wave's two 16-channel tiles one after the other ----
+    f32x4 vb[2][1], rb[2][1], h1b[2][1];
+    {
+        f32x4 t[1][1];
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS1 - 1, lane, t); vb[0][0] = t[0][0];
+        lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), lane);
+        lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS1 - 1, lane, t); rb[0][0] = t[0][0];
+        lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w + 1, 1, 8), lane);
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS1 - 1, lane, t); vb[1][0] = t[0][0];
+        lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), lane);
+        lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr0, 2 * w + 1, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS1 - 1, lane, t); rb[1][0] = t[0][0];
+        lvlm_prefetch<1, 1, 4, 8>(ring_r, wtile(a.Wr1, w, 1, 4), lane);                   // second block's residual_conv (128 -> 64)
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        lvlm_gn_mish(vb[mt][0], pvb4(0, mt), pvb4(1, mt), pvb4(2, mt), L, lane);
+        add4(vb[mt][0], pvb4(6, mt));
+        add4(rb[mt][0], pvb4(7, mt));
+    }
+    q_planes(vb, Q[0][0], Q[0][1]);
+    __syncthreads();
+    {
+        f32x4 t[1][1];
+        lvlm_conv<1, 1, 5, 4, QPB, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), Q[0][0], Q[0][1], 0, 1, 0, ROWS1 - 1, lane, t); vb[0][0] = t[0][0];
+        lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[1], 2 * w + 1, 5, 4), lane);
+        lvlm_conv<1, 1, 5, 4, QPB, 8>(ring, wtile(a.Wc[1], 2 * w + 1, 5, 4), Q[0][0], Q[0][1], 0, 1, 0, ROWS1 - 1, lane, t); vb[1][0] = t[0][0];
+        lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[2], w, 5, 4), lane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        lvlm_gn_mish(vb[mt][0], pvb4(3, mt), pvb4(4, mt), pvb4(5, mt), L, lane);
+        h1b[mt][0] = vb[mt][0] + rb[mt][0];
+        if (lr < L) *reinterpret_cast<float4*>(a.h1 + ((size_t)b * L + lr) * CB + clb(mt)) = make_float4(h1b[mt][0][0], h1b[mt][0][1], h1b[mt][0][2], h1b[mt][0][3]);
+    }
+    q_planes(h1b, Q[1][0], Q[1][1]);
+    __syncthreads();
+    // ---- block 1 (128 -> 64, residual_conv) ----
+    f32x4 v1[1][1], r1[1][1], h2[1];
+    lvlm_conv<1, 1, 5, 4, QPB, 8>(ring, wtile(a.Wc[2], w, 5, 4), Q[1][0], Q[1][1], 0, 1, 0, ROWS1 - 1, lane, v1);
+    lvlm_prefetch<1, 5, 2, 8>(ring, wbase(a.Wc[3], 5, 2), lane);
+    lvlm_conv<1, 1, 1, 4, QPB, 8>(ring_r, wtile(a.Wr1, w, 1, 4), Q[1][0], Q[1][1], 0, 1, 2, ROWS1 - 1, lane, r1);
+    lvl_gn_mish<1>(v1[0], pv4(0), pv4(1), pv4(2), L, lane);
+    add4(v1[0][0], pv4(9));
+    add4(r1[0][0], pv4(10));
+    lvl_to_planes<1, PPB>(v1[0], P[0][0], P[0][1], c0, 2, L, lane);
+    __syncthreads();
+    lvlm_conv<1, 1, 5, 2, PPB, 8>(ring, wbase(a.Wc[3], 5, 2), P[0][0], P[0][1], 0, 1, 0, ROWS2 - 1, lane, v1);
+    lvlm_prefetch<1, 1, 4, 8>(ring, wbase(a.Wo, 1, 4), lane);           // to_out fragments: in flight through the attention
+    lvl_gn_mish<1>(v1[0], pv4(3), pv4(4), pv4(5), L, lane);
+    h2[0] = v1[0][0] + r1[0][0];
+    lvl_store<1>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
+    *reinterpret_cast<float4*>(&H[lr * HP + cl]) = make_float4(h2[0][0], h2[0][1], h2[0][2], h2[0][3]);
+    __syncthreads();
+    // ---- attention site (C = 64, one 16-position tile) ----
+    {
+        const int lrow = tid >> 4, lcol = tid & 15;
+        const float4 gv = *reinterpret_cast<const float4*>(a.ln_g + 4 * lcol);
+        const int n = lrow;
+        const float4 xv = *reinterpret_cast<const float4*>(&H[n * HP + 4 * lcol]);
+        const float s1 = row16_sum((xv.x + xv.y) + (xv.z + xv.w));
+        const float mean = s1 * (1.0f / C);
+        const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+        const float s2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+        const bool ok = n < L;
+        const float y0 = ok ? d0 * rstd * gv.x : 0.f, y1 = ok ? d1 * rstd * gv.y : 0.f, y2 = ok ? d2 * rstd * gv.z : 0.f, y3 = ok ? d3 * rstd * gv.w : 0.f;
+        half4v hi, lo;
+        hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+        lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
+        lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
+        *reinterpret_cast<half4v*>(&P[1][0][(n + 2) * PPB + 8 * lcol]) = hi;
+        *reinterpret_cast<half4v*>(&P[1][1][(n + 2) * PPB + 8 * lcol]) = lo;
+    }
+    __syncthreads();
+    f32x4 qa[2][1], ka[1][2], va[1][2];
+    {
+        const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+        f32x4 M[6], Lo[6];
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) { M[s6] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s6] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        half8 wh[2][6], wl[2][6];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int tile = (s6 >> 1) * 8 + 2 * w + (s6 & 1);
+                wh[k][s6] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 0) * 64 + lane]);
+                wl[k][s6] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 1) * 64 + lane]);
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int off = (lr + 2) * PPB + k * 64 + lq * 16;
+            const half8 yh = *reinterpret_cast<const half8*>(&P[1][0][off]);
+            const half8 yl = *reinterpret_cast<const half8*>(&P[1][1][off]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                M[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[k][i], yh, M[i], 0, 0, 0);
+                Lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[k][i], yl, Lo[i], 0, 0, 0);
+                Lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[k][i], yh, Lo[i], 0, 0, 0);
+#pragma unroll
+                for (int kv = 2; kv < 6; kv += 2) {
+                    M[kv + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[k][kv + i], M[kv + i], 0, 0, 0);
+                    Lo[kv + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[k][kv + i], Lo[kv + i], 0, 0, 0);
+                    Lo[kv + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[k][kv + i], Lo[kv + i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            qa[i][0] = M[i] + Lo[i] * H3_INV;
+            ka[0][i] = M[2 + i] + Lo[2 + i] * H3_INV;
+            va[0][i] = M[4 + i] + Lo[4 + i] * H3_INV;
+        }
+    }
+    f32x4 att[2][1];
+    attn_site_core<1>(qa, ka, va, att, 1, NP1, NP1, L, lq, lr);
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+        half4v hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)att[et][0][i]; lo[i] = (_Float16)((att[et][0][i] - (float)hi[i]) * H3_SCALE); }
+        const int off = lr * APB + 2 * (w * 32 + et * 16 + lq * 4);
+        *reinterpret_cast<half4v*>(Aph + off) = hi;
+        *reinterpret_cast<half4v*>(Apl + off) = lo;
+    }
+    __syncthreads();
+    f32x4 h3[1];
+    lvlm_conv<1, 1, 1, 4, APB, 8>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 0, 1, 0, NP1 - 1, lane, v1);
+    lvlm_prefetch<1, 4, 2, 8>(ring, wbase(a.Wu, 4, 2), lane);
+    h3[0] = v1[0][0];
+    add4(h3[0], pv4(11));
+    h3[0] += h2[0];
+    lvl_store<1>(h3, a.h3 + (size_t)b * L * C, c0, L, lane);
+    lvl_to_planes<1, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
+    __syncthreads();
+    // ---- Upsample1d: ConvTranspose1d(k = 4, stride 2, pad 1), L -> 2L positions (two tiles) ----
+    f32x4 u[1][2];
+    lvlm_conv<1, 2, 4, 2, PPB, 8, 1>(ring, wbase(a.Wu, 4, 2), P[0][0], P[0][1], 0, 0, 0, ROWS2 - 1, lane, u);
+    lvlm_prefetch<1, 5, 2, 8>(ring, wbase(a.Wc[4], 5, 2), lane);
+    add4(u[0][0], pv4(12)); add4(u[0][1], pv4(12));
+    lvl_store<2>(u[0], a.up + (size_t)b * L2 * C, c0, L2, lane);
+    lvl_to_planes<2, PPB>(u[0], P[1][0], P[1][1], c0, 2, L2, lane);
+    __syncthreads();
+    // ---- final Conv1dBlock(64 -> 64, k5) and Conv1d(64 -> F, 1) ----
+    f32x4 y[1][2];
+    lvlm_conv<1, 2, 5, 2, PPB, 8>(ring, wbase(a.Wc[4], 5, 2), P[1][0], P[1][1], 16, 1, 0, ROWS2 - 1, lane, y);
+    if (w == 0) lvlm_prefetch<1, 1, 2, 8>(ring, reinterpret_cast<const float4*>(a.Wf), lane);
+    add4(y[0][0], pv4(6)); add4(y[0][1], pv4(6));
+    lvl_store<2>(y[0], a.ypre + (size_t)b * L2 * C, c0, L2, lane);
+    lvl_gn_mish<2>(y[0], zero4, pv4(7), pv4(8), L2, lane);
+    lvl_to_planes<2, PPB>(y[0], P[0][0], P[0][1], c0, 2, L2, lane);
+    __syncthreads();
+    if (w == 0) {
+        f32x4 e[1][2];
+        lvlm_conv<1, 2, 1, 2, PPB, 8>(ring, reinterpret_cast<const float4*>(a.Wf), P[0][0], P[0][1], 16, 1, 2, ROWS2 - 1, lane, e);
+        const float4 bf = *reinterpret_cast<const float4*>(&PV[13][lq * 4]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nt * 16 + lr;
+            if (n < L2 && lq * 4 < a.F)
+                *reinterpret_cast<float4*>(a.eps + ((size_t)b * L2 + n) * a.F + lq * 4) =
+                    make_float4(e[0][nt][0] + bf.x, e[0][nt][1] + bf.y, e[0][nt][2] + bf.z, e[0][nt][3] + bf.w);
+        }
     }
 }
 
