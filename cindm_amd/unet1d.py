@@ -174,7 +174,7 @@ class TemporalUnet1D(nn.Module):
     # kind 4 = the k=5 convolutions: conv_gemm_h3_kernel<5,48,*> (split-fp16 MFMA; default) or
     # conv_gemm_kernel<5,32,48,*> (fp32 MFMA; CINDM_MFMA=f32)
     KERNEL_KINDS = ("conv_gemm_kernel<0>", "conv_gemm_kernel<1>", "conv_gemm_kernel<3>", "conv_gemm_kernel<4>",
-                    "conv5_gemm", "attention_sites")
+                    "conv5_gemm", "attention_and_level_kernels")
 
     @torch.no_grad()
     def profile(self, x, t):
