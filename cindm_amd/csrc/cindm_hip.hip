@@ -64,6 +64,7 @@ struct cindm_unet1d {
     bool level0_ok = false;                // level0_down_kernel operands packed (dim 64, F <= 32, attention, down-sampling)
     bool level1_ok = false;                // level1_down_kernel operands packed (64 -> 128)
     bool ups_last_ok = false;              // ups_last_kernel operands packed
+    bool ups_tail_ok = false;              // ups_tail128_kernel operands packed
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
@@ -393,6 +394,15 @@ static void pack_level0(cindm_unet1d* h, BlobBuilder& bb) {
         ok2 = ok2 && h->index.count(u + ".2.fn.fn.to_qkv.weight");
     }
     h->ups_last_ok = ok2;
+    // the second half of the level above it: ups_tail128_kernel (RTB(256 -> 128), attention(128), upsample(128))
+    bool ok3 = ok1 && nres >= 4 && h->dims[3] == 256;
+    if (ok3) {
+        const std::string u = "ups." + std::to_string(nres - 3);
+        for (const std::string& p : {u + ".1.blocks.0.block.0", u + ".1.blocks.1.block.0", u + ".1.residual_conv"}) ok3 = pack_level_frag(h, bb, p, 128) && ok3;
+        ok3 = pack_level_frag(h, bb, u + ".3.conv", 128, 1) && ok3;
+        ok3 = ok3 && h->index.count(u + ".2.fn.fn.to_qkv.weight");
+    }
+    h->ups_tail_ok = ok3;
 }
 
 // residual_conv (1x1) in the split-fp16 layout of conv_gemm_h3_kernel's second GEMM: [n-tile][stage of 128 channels]
@@ -955,6 +965,37 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             return 0;
         }
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
+        static const int upt = getenv("CINDM_UPS_TAIL") ? atoi(getenv("CINDM_UPS_TAIL")) : 1;
+        if (upt && ind == nres - 3 && h->ups_tail_ok && att && cur.L <= 8 && cur.C == 256 && cur.ld == 256 && ci == 128 &&
+            h->packed.count(p + ".2.fn.fn.to_qkv#site") && h->packed.at(p + ".2.fn.fn.to_qkv#site").h3 && h->packed.count(p + ".3.conv")) {
+            // the rest of the level in one launch (ups_tail128_kernel)
+            const int L = cur.L;
+            Ten h2 = E.ten(L, 128), h3 = E.ten(L, 128), up = E.ten(2 * L, 128);
+            ++E.launches;
+            if (!E.dry) {
+                UpsTailArgs l;
+                std::memset(&l, 0, sizeof(l));
+                l.x = cur.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p;
+                const std::string cv[2] = {p + ".1.blocks.0", p + ".1.blocks.1"};
+                for (int i = 0; i < 2; ++i) {
+                    l.Wc[i] = E.W(h->packed.at(cv[i] + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cv[i] + ".block.0"));
+                    l.gam[i] = E.V(cv[i] + ".block.2.weight"); l.bet[i] = E.V(cv[i] + ".block.2.bias");
+                }
+                l.Wr = E.W(h->packed.at(p + ".1.residual_conv#lvl")); l.br = E.B(h->packed.at(p + ".1.residual_conv"));
+                l.tb = h->ttable + h->tb_off.at(p + ".1"); l.tb_ld = h->tb_ld;
+                l.ln_g = E.V(p + ".2.fn.norm.g"); l.Wqkv = E.W(h->packed.at(p + ".2.fn.fn.to_qkv#site"));
+                l.Wo = E.W(h->packed.at(p + ".2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at(p + ".2.fn.fn.to_out"));
+                l.Wu = E.W(h->packed.at(p + ".3.conv#lvl")); l.bu = E.B(h->packed.at(p + ".3.conv"));
+                l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
+                E.prof_begin(5, 0.0);
+                for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
+                    hipLaunchKernelGGL(ups_tail128_kernel, dim3((unsigned)E.rows), dim3(256), 0, E.stream, l);
+                E.prof_end();
+            }
+            E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up);
+            cur = up;
+            continue;
+        }
         cur = emit_rtb(E, p + ".1", cur, nullptr, ci, need_ln(p + ".2", cur.L), &lnp);
         if (att) cur = emit_attn(E, p + ".2", cur, lnp);
         if (h->packed.count(p + ".3.conv")) cur = emit_resample(E, p + ".3", cur, true);
@@ -1050,9 +1091,9 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
         }
     }
     h->tb_ld = tb_ld;
-    h->level0_ok = false; h->level1_ok = false; h->ups_last_ok = false;
+    h->level0_ok = false; h->level1_ok = false; h->ups_last_ok = false; h->ups_tail_ok = false;
     if (h->use_h3 && h->use_attn_site && h->use_level0 && h->use_local_gn) pack_level0(h, bb);
-    if (getenv("CINDM_VERBOSE")) fprintf(stderr, "[cindm] fused levels: level0 %d level1 %d ups_last %d\n", (int)h->level0_ok, (int)h->level1_ok, (int)h->ups_last_ok);
+    if (getenv("CINDM_VERBOSE")) fprintf(stderr, "[cindm] fused levels: level0 %d level1 %d ups_last %d\n", (int)h->level0_ok, (int)h->level1_ok, (int)h->ups_last_ok + 2 * (int)h->ups_tail_ok);
     if (h->blob) { (void)hipFree(h->blob); h->blob = nullptr; }
     if (h->ttable) { (void)hipFree(h->ttable); h->ttable = nullptr; }
     h->blob_floats = bb.data.size();

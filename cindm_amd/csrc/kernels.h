@@ -2335,6 +2335,232 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ups_tail128_kernel: the second half of the second-finest up level in one launch, one sample per workgroup:
+//   ResidualTemporalBlock(256 -> 128) -> attention site(128) -> Upsample1d(128) (ConvTranspose1d k4 s2 p1, L -> 2L <= 16)
+// (the level's first block, 512 -> 256, keeps its per-layer launches: its weights are 3 MB).  Pieces of
+// level1_down_kernel (128-channel attention) and ups_last_kernel (256-channel input streamed tile by tile, transposed
+// convolution).
+struct UpsTailArgs {
+    const float* x;                        // [Bp, L, 256]
+    float* h2; float* h3; float* up;       // [Bp, L, 128] x 2, [Bp, 2L, 128]
+    const float* Wc[2]; const float* bc[2]; const float* gam[2]; const float* bet[2];
+    const float* Wr; const float* br;
+    const float* tb; int tb_ld;
+    const float* ln_g; const float* Wqkv; const float* Wo; const float* bo;
+    const float* Wu; const float* bu;
+    const int* t_ptr; int t_imm;
+    int L;
+};
+
+__global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
+    constexpr int C = 128, CI = 256, NP = 16, ROWS = NP + 4;
+    constexpr int XPB = 2 * CI + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char XI[2][ROWS * XPB];
+    __shared__ __attribute__((aligned(16))) unsigned char P[2][2][ROWS * PPB];
+    __shared__ __attribute__((aligned(16))) unsigned char R[2 * NP * APB];             // h2 in fp32 for the LayerNorm, then the att planes
+    // parameter vectors: 0-2 conv1 (bias, GN weight, GN bias), 3-5 conv2, 6 time bias, 7 residual bias, 8 to_out bias, 9 upsample bias
+    __shared__ __attribute__((aligned(16))) float PV[10][C];
+    static_assert(NP * HP * 4 <= 2 * NP * APB, "H fits the shared region");
+    float* H = reinterpret_cast<float*>(R);
+    unsigned char* Aph = R; unsigned char* Apl = R + NP * APB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int L = a.L, L2 = 2 * a.L, b = blockIdx.x;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    auto cl = [&](int mt) { return (2 * w + mt) * 16 + lq * 4; };
+    auto wtile = [&](const float* W, int tile, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)tile * taps * ks * 2 * 64; };
+    LvlRing<1, 8> ring, ring_r;
+    lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), lane);
+    lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), lane);
+    if (tid < C) {
+        const float* src[10] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bu};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) PV[i][tid] = src[i][tid];
+    }
+    for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    {
+        const int p = tid >> 4, c4 = tid & 15;
+        if (p < L) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cf = c4 + 16 * q;
+                const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + p) * CI + 4 * cf);
+                half4v hi, lo;
+                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+                lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+                *reinterpret_cast<half4v*>(&XI[0][(p + 2) * XPB + 8 * cf]) = hi;
+                *reinterpret_cast<half4v*>(&XI[1][(p + 2) * XPB + 8 * cf]) = lo;
+            }
+        }
+    }
+    auto pv4 = [&](int vec, int mt) { return *reinterpret_cast<const float4*>(&PV[vec][cl(mt)]); };
+    auto add4 = [&](f32x4& v, const float4 t) { v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; };
+    auto planes = [&](const f32x4 (&v)[2], unsigned char* Ph, unsigned char* Pl, int nvalid) {      // rows position + 2
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            half4v hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f = lr < nvalid ? v[mt][i] : 0.f;
+                hi[i] = (_Float16)f; lo[i] = (_Float16)((f - (float)hi[i]) * H3_SCALE);
+            }
+            const int off = (lr + 2) * PPB + 2 * cl(mt);
+            *reinterpret_cast<half4v*>(Ph + off) = hi;
+            *reinterpret_cast<half4v*>(Pl + off) = lo;
+        }
+    };
+    auto store = [&](const f32x4 (&v)[2], float* dst, int nvalid) {      // dst [Bp, nvalid, 128]
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            if (lr < nvalid) *reinterpret_cast<float4*>(dst + ((size_t)b * nvalid + lr) * C + cl(mt)) = make_float4(v[mt][0], v[mt][1], v[mt][2], v[mt][3]);
+    };
+    __syncthreads();
+
+    // ---- ResidualTemporalBlock(256 -> 128): the wave's two 16-channel tiles one after the other ----
+    f32x4 v[2], r[2], h2[2];
+    {
+        f32x4 t[1][1];
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS - 1, lane, t); v[0] = t[0][0];
+        lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), lane);
+        lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS - 1, lane, t); r[0] = t[0][0];
+        lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w + 1, 1, 8), lane);
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS - 1, lane, t); v[1] = t[0][0];
+        lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), lane);
+        lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr, 2 * w + 1, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS - 1, lane, t); r[1] = t[0][0];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        lvlm_gn_mish(v[mt], pv4(0, mt), pv4(1, mt), pv4(2, mt), L, lane);
+        add4(v[mt], pv4(6, mt));
+        add4(r[mt], pv4(7, mt));
+    }
+    planes(v, P[0][0], P[0][1], L);
+    __syncthreads();
+    {
+        f32x4 t[1][1];
+        lvlm_conv<1, 1, 5, 4, PPB, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), P[0][0], P[0][1], 0, 1, 0, ROWS - 1, lane, t); v[0] = t[0][0];
+        lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[1], 2 * w + 1, 5, 4), lane);
+        lvlm_conv<1, 1, 5, 4, PPB, 8>(ring, wtile(a.Wc[1], 2 * w + 1, 5, 4), P[0][0], P[0][1], 0, 1, 0, ROWS - 1, lane, t); v[1] = t[0][0];
+        lvlm_prefetch<1, 1, 4, 8>(ring, wtile(a.Wo, 2 * w, 1, 4), lane);            // to_out fragments of the first tile: in flight through the attention
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        lvlm_gn_mish(v[mt], pv4(3, mt), pv4(4, mt), pv4(5, mt), L, lane);
+        h2[mt] = v[mt] + r[mt];
+        *reinterpret_cast<float4*>(&H[lr * HP + cl(mt)]) = make_float4(h2[mt][0], h2[mt][1], h2[mt][2], h2[mt][3]);
+    }
+    store(h2, a.h2, L);
+    __syncthreads();
+    // ---- attention site (C = 128) ----
+    {
+        const int lrow = tid >> 5, lcol = tid & 31;                      // 32 lanes per row, 8 rows per pass
+        const float4 gv = *reinterpret_cast<const float4*>(a.ln_g + 4 * lcol);
+#pragma unroll
+        for (int rr = 0; rr < NP / 8; ++rr) {
+            const int n = rr * 8 + lrow;
+            const float4 xv = *reinterpret_cast<const float4*>(&H[n * HP + 4 * lcol]);
+            const float s1 = xsum16(row16_sum((xv.x + xv.y) + (xv.z + xv.w)));
+            const float mean = s1 * (1.0f / C);
+            const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+            const float s2 = xsum16(row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)));
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            const bool ok = n < L;
+            const float y0 = ok ? d0 * rstd * gv.x : 0.f, y1 = ok ? d1 * rstd * gv.y : 0.f, y2 = ok ? d2 * rstd * gv.z : 0.f, y3 = ok ? d3 * rstd * gv.w : 0.f;
+            half4v hi, lo;
+            hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+            lo[0] = (_Float16)((y0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y1 - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((y2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y3 - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&P[1][0][(n + 2) * PPB + 8 * lcol]) = hi;
+            *reinterpret_cast<half4v*>(&P[1][1][(n + 2) * PPB + 8 * lcol]) = lo;
+        }
+    }
+    __syncthreads();
+    f32x4 qa[2][1], ka[1][2], va[1][2];
+    {
+        const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+        f32x4 M[6], Lo[6];
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) { M[s6] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s6] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float4 wq[2][6][2];
+        auto load_k = [&](int k, int slot) {
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int tile = (s6 >> 1) * 8 + 2 * w + (s6 & 1);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wq[slot][s6][pl] = Wq4[(((size_t)tile * 4 + k) * 2 + pl) * 64 + lane];
+            }
+        };
+        load_k(0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k + 1 < 4) load_k(k + 1, (k + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int off = (lr + 2) * PPB + k * 64 + lq * 16;
+            const half8 yh = *reinterpret_cast<const half8*>(&P[1][0][off]);
+            const half8 yl = *reinterpret_cast<const half8*>(&P[1][1][off]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const half8 wqh = __builtin_bit_cast(half8, wq[k & 1][i][0]), wql = __builtin_bit_cast(half8, wq[k & 1][i][1]);
+                M[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wqh, yh, M[i], 0, 0, 0);
+                Lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wqh, yl, Lo[i], 0, 0, 0);
+                Lo[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wql, yh, Lo[i], 0, 0, 0);
+#pragma unroll
+                for (int kv = 2; kv < 6; kv += 2) {
+                    const half8 wh = __builtin_bit_cast(half8, wq[k & 1][kv + i][0]), wl = __builtin_bit_cast(half8, wq[k & 1][kv + i][1]);
+                    M[kv + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh, M[kv + i], 0, 0, 0);
+                    Lo[kv + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl, Lo[kv + i], 0, 0, 0);
+                    Lo[kv + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh, Lo[kv + i], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            qa[i][0] = M[i] + Lo[i] * H3_INV;
+            ka[0][i] = M[2 + i] + Lo[2 + i] * H3_INV;
+            va[0][i] = M[4 + i] + Lo[4 + i] * H3_INV;
+        }
+    }
+    f32x4 att[2][1];
+    attn_site_core<1>(qa, ka, va, att, 1, NP, NP, L, lq, lr);
+    __syncthreads();                                          // every wave is done with H (the att planes alias it)
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+        half4v hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)att[et][0][i]; lo[i] = (_Float16)((att[et][0][i] - (float)hi[i]) * H3_SCALE); }
+        const int off = lr * APB + 2 * (w * 32 + et * 16 + lq * 4);
+        *reinterpret_cast<half4v*>(Aph + off) = hi;
+        *reinterpret_cast<half4v*>(Apl + off) = lo;
+    }
+    __syncthreads();
+    f32x4 h3[2];
+    {
+        f32x4 t[1][1];
+        lvlm_conv<1, 1, 1, 4, APB, 8>(ring, wtile(a.Wo, 2 * w, 1, 4), Aph, Apl, 0, 1, 0, NP - 1, lane, t); h3[0] = t[0][0];
+        lvlm_prefetch<1, 1, 4, 8>(ring, wtile(a.Wo, 2 * w + 1, 1, 4), lane);
+        lvlm_conv<1, 1, 1, 4, APB, 8>(ring, wtile(a.Wo, 2 * w + 1, 1, 4), Aph, Apl, 0, 1, 0, NP - 1, lane, t); h3[1] = t[0][0];
+        lvlm_prefetch<1, 4, 4, 8>(ring, wtile(a.Wu, 2 * w, 4, 4), lane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { add4(h3[mt], pv4(8, mt)); h3[mt] += h2[mt]; }
+    store(h3, a.h3, L);
+    planes(h3, P[0][0], P[0][1], L);
+    __syncthreads();
+    // ---- Upsample1d: ConvTranspose1d(k = 4, stride 2, pad 1), L -> 2L <= 16 positions (one tile) ----
+    {
+        f32x4 u[2];
+        f32x4 t[1][1];
+        lvlm_conv<1, 1, 4, 4, PPB, 8, 1>(ring, wtile(a.Wu, 2 * w, 4, 4), P[0][0], P[0][1], 0, 0, 0, ROWS - 1, lane, t); u[0] = t[0][0];
+        lvlm_prefetch<1, 4, 4, 8>(ring, wtile(a.Wu, 2 * w + 1, 4, 4), lane);
+        lvlm_conv<1, 1, 4, 4, PPB, 8, 1>(ring, wtile(a.Wu, 2 * w + 1, 4, 4), P[0][0], P[0][1], 0, 0, 0, ROWS - 1, lane, t); u[1] = t[0][0];
+        add4(u[0], pv4(9, 0)); add4(u[1], pv4(9, 1));
+        store(u, a.up, L2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Counter-based Gaussian noise: Philox4x32-10 keyed by seed, counter = (element/4, sample, step, 0),
 // Box-Muller on the four 32-bit outputs.  Pure function of (seed, global sample, step, element):
 // results do not depend on the number of GPUs / batch partition.
