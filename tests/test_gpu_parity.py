@@ -110,6 +110,18 @@ def test_unet_ragged_batches_vs_oracle(device, unet8, B):
     assert rel(out, ref) < TOL_FWD
 
 
+@pytest.mark.parametrize("hz,F,B", [(16, 8, 5), (32, 8, 3), (32, 16, 2), (40, 8, 2), (12, 4, 7)])
+def test_unet_other_horizons_vs_oracle(device, hz, F, B):
+    """Horizons that exercise the other shapes of the level kernels (one / two position tiles, horizon 32 = every tile
+    full, horizons the level kernels do not cover) against the oracle on the same seeded input."""
+    m, sd = build_unet(device, hz, F, True)
+    x = torch.randn((B, hz, F), generator=torch.Generator().manual_seed(7 * hz + F))
+    for t in (3, 611):
+        ref = O.unet1d_forward(sd, x, torch.full((B,), t, dtype=torch.long))
+        out = m(x.to(device), torch.full((B,), t, device=device))
+        assert rel(out, ref) < TOL_FWD, (hz, F, t)
+
+
 def test_unet_rows_are_independent(device, unet8):
     """A sample's result does not depend on its batch mates (per-sample ops only; SURVEY 8c identity 5)."""
     m, _ = unet8
