@@ -128,12 +128,6 @@ __device__ __forceinline__ float mish_f(float x) {
     return x > 20.0f ? x : r;
 }
 
-__device__ __forceinline__ float wave_sum_seg(float v, int seg) {
-    // deterministic butterfly sum over aligned lane segments of size seg (power of two <= 64)
-    for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // Segmented lane reduction on the DPP network (no LDS round trips): after the call the LAST lane of every aligned
 // seg-lane segment (seg = 4, 8, 16 or 32) holds the segment's sum, accumulated in a fixed order.
 template <int CTRL, int ROW_MASK>
@@ -2886,7 +2880,5 @@ __global__ void step_counter_kernel(int* t_dev, const int* ddim_tnext) {
         else t_dev[0] -= 1;
     }
 }
-
-__global__ void dec_counter_kernel(int* t) { if (threadIdx.x == 0 && blockIdx.x == 0) *t -= 1; }
 
 }  // namespace cindm

@@ -1573,26 +1573,6 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
     }
 }
 
-// out = LayerNorm_channels(z) * g + x   (LinearAttention's to_out[1] and the Residual, :126-135, :96-97); one wave per pixel row.
-__global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ z, const float* __restrict__ g,
-                                                          const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* zp = z + row * C;
-    float v0 = lane < C ? zp[lane] : 0.f, v1 = lane + 64 < C ? zp[lane + 64] : 0.f;
-    float s = v0 + v1;
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)C;
-    const float d0 = lane < C ? v0 - mean : 0.f, d1 = lane + 64 < C ? v1 - mean : 0.f;
-    float m2 = d0 * d0 + d1 * d1;
-    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
-    const float rstd = 1.0f / sqrtf(m2 / (float)C + 1e-5f);
-    if (lane < C) out[row * C + lane] = d0 * rstd * g[lane] + x[row * C + lane];
-    if (lane + 64 < C) out[row * C + lane + 64] = d1 * rstd * g[lane + 64] + x[row * C + lane + 64];
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Full softmax attention (Attention.forward, :266-278) for n tokens, 4 heads x 32, on fp32 MFMA.  One workgroup per
 // (image, head, 64 queries), one wave per 16 queries; keys/values streamed through LDS in chunks of 64 (double
 // buffered).  Both products are computed TRANSPOSED so that the probabilities never leave registers:
