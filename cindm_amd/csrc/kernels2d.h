@@ -1240,8 +1240,9 @@ struct La2dArgs {
     int spw, tpw;                  // 128-pixel slices per context workgroup ; 64-pixel tiles per apply workgroup
     int dbg;                       // timing ablations (wrong results)
 };
-constexpr int LA2_PX = 128;        // pixels per context slice
+constexpr int LA2_PX = 128;        // pixels per context slice at C = 64; C = 128 uses 64 (la2_px): half the k|v registers, measured 108 -> 61 us
 constexpr int LA2_REC = 64 + 1024;
+constexpr int la2_px(int C) { return C == 64 ? LA2_PX : LA2_PX / 2; }
 
 // LayerNorm over C channels (biased variance, eps 1e-5) * g of the NPX tile rows held in xr (thread (lrow, lcol) owns
 // columns 4*lcol.. of rows r*RPP + lrow) -> (hi, scaled lo) fp16 planes
@@ -1279,13 +1280,14 @@ struct LnTile {
 // per workgroup.
 template <int C>
 __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
-    using LN = LnTile<C, LA2_PX>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = LA2_PX / 16;
-    __shared__ __attribute__((aligned(16))) unsigned char Yp[2][LA2_PX * YPB];
+    constexpr int PX = la2_px(C);
+    using LN = LnTile<C, PX>;
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = PX / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char Yp[2][PX * YPB];
     __shared__ float fac[4][32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int img = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
-    const float* x0 = a.x + ((size_t)img * a.HW + (size_t)split * a.spw * LA2_PX) * a.ldx;
+    const float* x0 = a.x + ((size_t)img * a.HW + (size_t)split * a.spw * PX) * a.ldx;
     float4 xr[LN::NPASS];
     LN::load(xr, x0, a.ldx, tid);
     const float4 gv = *reinterpret_cast<const float4*>(a.g + 4 * (tid % LN::LPR));
@@ -1312,7 +1314,7 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
     for (int sl = 0; sl < a.spw; ++sl) {
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();
-        if (sl + 1 < a.spw) LN::load(xr, x0 + (size_t)(sl + 1) * LA2_PX * a.ldx, a.ldx, tid);
+        if (sl + 1 < a.spw) LN::load(xr, x0 + (size_t)(sl + 1) * PX * a.ldx, a.ldx, tid);
         // k, v: rows = pixels (8 tiles of 16), cols = the head's 32 channels
         f32x4 kk[NTL][2], vv[NTL][2];
 #pragma unroll
