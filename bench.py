@@ -61,6 +61,29 @@ def cpu_baseline(sd, budget_s=20.0):
             "sample": f"{n} reverse steps of batch {BATCH} ({dt * 1e3:.1f} ms/step), extrapolated x{TIMESTEPS}"}
 
 
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves, as a CHILD
+    `torch.distributed.run` (one process per GPU, RCCL rendezvous on 127.0.0.1), forward its output and exit with its
+    code.  Runs before anything in this process touches the GPU (no exec of an initialised process).  Under torchrun
+    the world size must agree with --gpus."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
 FLOP_PER_IMAGE_2D = 10.467e9       # per Unet evaluation of one 64x64 image (SURVEY.md section 8, row a15)
 
 
@@ -207,6 +230,7 @@ def main():
                     help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg5 = the 2-D airfoil configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    spawn_ranks_if_needed(args)
     if args.workload == "cfg5":
         return main_cfg5(args)
     args.batch = args.batch or BATCH

@@ -59,6 +59,11 @@ _vp, _i32, _i64, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_s
 SIGNATURES = {
     "cindm_abi_version": (C.c_int, []),
     "cindm_last_error": (C.c_char_p, []),
+    "cindm_source_hash": (C.c_char_p, []),
+    "cindm_unet1d_status": (C.c_int, [_vp, _vp]),
+    "cindm_unet1d_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "cindm_unet1d_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32)]),
+    "cindm_unet2d_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "cindm_unet1d_create": (C.c_int, [C.POINTER(UnetDesc), C.POINTER(_vp)]),
     "cindm_unet1d_destroy": (None, [_vp]),
     "cindm_unet1d_num_params": (C.c_int, [_vp]),
@@ -112,7 +117,8 @@ SIGNATURES = {
 
 
 def lib():
-    """Loads (building first if the sources are newer and hipcc exists) libcindm_hip.so."""
+    """Loads libcindm_hip.so, building it first when it is missing or was compiled from other sources than the ones
+    next to it (the library embeds the sha256 of its sources).  A stale library is never used silently."""
     global _lib
     if _lib is not None:
         return _lib
@@ -121,16 +127,15 @@ def lib():
         if os.environ.get("LOCAL_RANK", "0") not in ("0", ""):
             # multi-process launch (torchrun): local rank 0 builds, the others wait for its library
             import time
-            for _ in range(600):
+            for _ in range(1200):
                 if not _build.needs_build():
                     break
                 time.sleep(0.5)
         else:
             try:
                 _build.build()
-            except Exception as e:  # no hipcc on this box: fall through to whatever is on disk
-                if not os.path.isfile(path):
-                    raise CindmError(f"libcindm_hip.so is missing and could not be built: {e}") from e
+            except Exception as e:
+                raise CindmError(f"libcindm_hip.so is missing or stale and could not be built: {e}") from e
     try:
         L = C.CDLL(path)
     except OSError as e:
@@ -141,6 +146,10 @@ def lib():
         fn.argtypes = args
     if L.cindm_abi_version() != 1:
         raise CindmError("libcindm_hip.so ABI version mismatch")
+    have, want = L.cindm_source_hash().decode(), _build.source_hash()
+    if have != want:
+        raise CindmError(f"libcindm_hip.so was built from other sources (library {have[:12]}, tree {want[:12]}); "
+                         "run `python -m cindm_amd.build --force`")
     _lib = L
     return L
 

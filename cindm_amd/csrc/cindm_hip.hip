@@ -3,6 +3,7 @@
 // reference) and of one DDPM reverse step (model/diffusion_1d.py:951-1044, :1047-1186, :1190-1376,
 // :1380-1652) out of the kernels in kernels.h.  gfx950 only.
 #include "kernels.h"
+#include "kernels_dconv.h"
 #include "kernels2d.h"
 #include "../../include/cindm_hip.h"
 
@@ -23,6 +24,10 @@ static int fail(const std::string& m) { g_err = m; return -1; }
 #define REQUIRE(c, msg) do { if (!(c)) return fail(msg); } while (0)
 
 extern "C" int cindm_abi_version(void) { return CINDM_ABI_VERSION; }
+#ifndef CINDM_SRC_HASH
+#define CINDM_SRC_HASH "unknown"
+#endif
+extern "C" const char* cindm_source_hash(void) { return CINDM_SRC_HASH; }
 extern "C" const char* cindm_last_error(void) { return g_err.c_str(); }
 
 static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -68,6 +73,11 @@ struct cindm_unet1d {
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
+    int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag
+    const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
+    // kernel-path options (cindm_unet1d_set_option; defaults = the fast path, overridable by CINDM_* at create)
+    std::map<std::string, int> opt;
+    int O(const char* k) const { auto it = opt.find(k); return it == opt.end() ? 0 : it->second; }
     // taps of the last forward
     struct Tap { size_t off; int L, C, ld; };
     std::unordered_map<std::string, Tap> taps;
@@ -135,6 +145,51 @@ static int build_manifest(cindm_unet1d* h) {
     return 0;
 }
 
+// Option keys, defaults and the environment variables that override the defaults at create (ablation scripts):
+// every alternative kernel path is selectable per handle so the parity suite can run each of them in one process.
+struct OptDef { const char* key; int def; const char* env; };
+static const OptDef kUnet1dOpts[] = {
+    {"mfma_f32", 0, nullptr},          // 1: every product on the exact fp32 MFMA kernels (CINDM_MFMA=f32)
+    {"local_gn", 1, "CINDM_LOCAL_GN"}, // producer-side GroupNorm + Mish, block tails folded into launch B
+    {"wide_qkv", 1, "CINDM_WIDE_QKV"}, // shallow-level qkv projections on conv1x1_wide_kernel (three-launch attention path)
+    {"attn_site", 1, "CINDM_ATTN_SITE"},   // one launch per attention site
+    {"level0", 1, "CINDM_LEVEL0"},     // level kernels (master switch)
+    {"level1", 1, "CINDM_LEVEL1"},     // level1_down_kernel: samples per workgroup (0 = off, 1, 2)
+    {"ups_last", 1, "CINDM_UPS_LAST"},
+    {"ups_tail", 1, "CINDM_UPS_TAIL"},
+    {"h3_resample", 1, "CINDM_H3_RESAMPLE"},   // resampling convolutions on the split-fp16 kernel
+    {"site_pack", 1, "CINDM_SITE_PACK"},   // several samples per attention-site workgroup
+    {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
+    {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
+    {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
+    {"dbg", 0, "CINDM_DBG"}, {"dbg3", 0, "CINDM_DBG3"}, {"dbg4", 0, "CINDM_DBG4"},   // timing ablations (wrong results)
+};
+static void unet1d_default_options(cindm_unet1d* h) {
+    for (const auto& o : kUnet1dOpts) {
+        int v = o.def;
+        if (o.env) { const char* e = getenv(o.env); if (e) v = atoi(e); }
+        h->opt[o.key] = v;
+    }
+    const char* e = getenv("CINDM_MFMA");
+    if (e && std::strcmp(e, "f32") == 0) h->opt["mfma_f32"] = 1;
+}
+
+extern "C" int cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value) {
+    REQUIRE(h && key, "null argument");
+    auto it = h->opt.find(key);
+    if (it == h->opt.end()) return fail(std::string("unknown option: ") + key);
+    if (it->second != value) { it->second = value; h->finalized = false; }
+    return 0;
+}
+
+extern "C" int cindm_unet1d_get_option(const cindm_unet1d* h, const char* key, int32_t* value) {
+    REQUIRE(h && key && value, "null argument");
+    auto it = h->opt.find(key);
+    if (it == h->opt.end()) return fail(std::string("unknown option: ") + key);
+    *value = it->second;
+    return 0;
+}
+
 extern "C" int cindm_unet1d_create(const cindm_unet1d_desc* desc, cindm_unet1d** out) {
     REQUIRE(desc && out, "null argument");
     REQUIRE(desc->n_mults >= 1 && desc->n_mults <= 8, "n_mults out of range");
@@ -147,6 +202,7 @@ extern "C" int cindm_unet1d_create(const cindm_unet1d_desc* desc, cindm_unet1d**
     REQUIRE(desc->timesteps >= 1, "timesteps must be >= 1");
     auto* h = new cindm_unet1d();
     h->d = *desc;
+    unet1d_default_options(h);
     if (build_manifest(h) != 0) { delete h; return -1; }
     // every internal length must stay integral
     int L = desc->horizon;
@@ -162,6 +218,7 @@ extern "C" void cindm_unet1d_destroy(cindm_unet1d* h) {
     if (!h) return;
     if (h->blob) (void)hipFree(h->blob);
     if (h->ttable) (void)hipFree(h->ttable);
+    if (h->epoch_dev) (void)hipFree(h->epoch_dev);
     delete h;
 }
 
@@ -498,7 +555,7 @@ static void pack_vec(cindm_unet1d* h, BlobBuilder& bb, const std::string& key) {
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-struct Ten { float* p = nullptr; int L = 0, C = 0, ld = 0; };
+struct Ten { float* p = nullptr; int L = 0, C = 0, ld = 0; uint4* pl = nullptr; size_t pst = 0; };   // pl: tiled split-fp16 planes (dconv_kernel)
 
 struct Emitter {
     cindm_unet1d* h;
@@ -512,6 +569,22 @@ struct Emitter {
     struct ProfRec { int kind; hipEvent_t e0, e1; double flops; int gx, gy, nstage; };
     std::vector<ProfRec>* prof = nullptr;     // when set, every launch is bracketed by HIP events
     static constexpr int prof_reps = 8;
+    bool epoch_bumped = false;                // dconv pair exchanges: the per-forward epoch has been advanced
+    std::vector<std::pair<size_t, size_t>>* xregions = nullptr;      // dry run: (offset, bytes) of the exchange regions
+
+    // tiled planes of an [rows, L, C] tensor (kernels_dconv.h): two planes of tiles * (C / 32) * 192 uint4
+    void planes(Ten& t) {
+        const int S = 48 / t.L;
+        const size_t tiles = (size_t)((rows + S - 1) / S);
+        t.pst = tiles * (size_t)(t.C / 32) * 192;
+        t.pl = reinterpret_cast<uint4*>(alloc(t.pst * 2 * 4));
+    }
+    unsigned long long* xchg(size_t granules) {
+        const size_t off = ws_off;
+        float* p = alloc(granules * 2);
+        if (xregions) xregions->push_back({off, granules * 8});
+        return reinterpret_cast<unsigned long long*>(p);
+    }
 
     void prof_begin(int kind, double flops) {
         if (!prof || dry) return;
@@ -565,9 +638,16 @@ struct Emitter {
         // profile mode: the (idempotent) launch is repeated inside one event bracket so that the ~6 us cost of the
         // bracket itself is amortised; the reported time is bracket / prof_reps
         for (int rep = 0; rep < (prof ? prof_reps : 1); ++rep) {
-        static const int dbg_h3 = getenv("CINDM_DBG") ? atoi(getenv("CINDM_DBG")) : 0;
+        const int dbg_h3 = h ? h->O("dbg") : 0;
         const_cast<GemmArgs&>(a).dbg = a.h3 ? dbg_h3 : 0;
         if (a.h3 && T == 5 && mode == SRC_PLAIN && a.W2) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, true>), grid, dim3(256), 0, stream, a);
+        else if (a.h3 && T == 5 && mode == SRC_PLAIN && dbg_h3 >= 21 && dbg_h3 <= 25) {
+            if (dbg_h3 == 21) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, false, 1>), grid, dim3(256), 0, stream, a);
+            else if (dbg_h3 == 22) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, false, 2>), grid, dim3(256), 0, stream, a);
+            else if (dbg_h3 == 23) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, false, 3>), grid, dim3(256), 0, stream, a);
+            else if (dbg_h3 == 24) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, false, 4>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN, false, 5>), grid, dim3(256), 0, stream, a);
+        }
         else if (a.h3 && T == 5 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
         else if (a.h3 && T == 5 && mode == SRC_GN_MISH) hipLaunchKernelGGL((conv_gemm_h3_kernel<5, 48, SRC_GN_MISH>), grid, dim3(256), 0, stream, a);
         else if (a.h3 && T == 3 && mode == SRC_PLAIN) hipLaunchKernelGGL((conv_gemm_h3_kernel<3, 96, SRC_PLAIN>), grid, dim3(256), 0, stream, a);
@@ -575,7 +655,7 @@ struct Emitter {
         else if (a.h3) ok = false;
         else if (T == 0) CINDM_LAUNCH(0, 32, 48, SRC_PLAIN);
         else if (T == 5 && mode == SRC_PLAIN) {
-            static const int dbg = getenv("CINDM_DBG") ? atoi(getenv("CINDM_DBG")) : 0;   // timing ablations (wrong results)
+            const int dbg = h ? h->O("dbg") : 0;   // timing ablations (wrong results)
             if (dbg == 1) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 1>), grid, dim3(256), 0, stream, a);
             else if (dbg == 2) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 2>), grid, dim3(256), 0, stream, a);
             else if (dbg == 3) hipLaunchKernelGGL((conv_gemm_kernel<5, 32, 48, SRC_PLAIN, 3>), grid, dim3(256), 0, stream, a);
@@ -618,12 +698,117 @@ struct Emitter {
 
 struct GnRef { const float* stats; int P, gw; float cnt; const float* gamma; const float* beta; };
 
+// ---- deep levels: ResidualTemporalBlock as TWO dconv_kernel launches (kernels_dconv.h) --------------------------
+//   A: y0 = Mish(GN(conv5(x) + b0)) + tbias_t  -> planes only;   r = Wr . x + br rides on A's centre tap
+//   B: out = Mish(GN(conv5(y0) + b1)) + (x | r) -> fp32 (taps, attention, identity residuals) + planes (next conv)
+static bool dconv_instantiated(int L, int k0, int k1, bool res) {
+    if (L == 6) return (k0 == 1 && k1 == 0 && res) || (k0 == 2 && k1 == 0 && !res) || (k0 == 2 && k1 == 2 && res);
+    if (L == 3) return (k0 == 2 && k1 == 0) || (k0 == 4 && k1 == 0) || (k0 == 4 && k1 == 4 && res);
+    return false;
+}
+
+static void dconv_launch(Emitter& E, int L, int k0, int k1, bool res, const DconvArgs& d, double flops) {
+    ++E.launches;
+    if (E.dry) return;
+    const int S = 48 / L;
+    const dim3 grid((unsigned)d.NT, (unsigned)((d.Bp + S - 1) / S));
+    E.prof_begin(4, flops);
+    if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }
+    for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
+#define DC(L_, K0_, K1_, R_) hipLaunchKernelGGL((dconv_kernel<L_, K0_, K1_, R_>), grid, dim3(256), 0, E.stream, d)
+        if (L == 6) {
+            if (k0 == 1) DC(6, 1, 0, true);
+            else if (k1 == 2) DC(6, 2, 2, true);
+            else DC(6, 2, 0, false);
+        } else {
+            if (k0 == 2 && res) DC(3, 2, 0, true);
+            else if (k0 == 2) DC(3, 2, 0, false);
+            else if (k1 == 4) DC(3, 4, 4, true);
+            else if (res) DC(3, 4, 0, true);
+            else DC(3, 4, 0, false);
+        }
+#undef DC
+    }
+    E.prof_end();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess && E.err == hipSuccess) E.err = e;
+}
+
+static bool dconv_applicable(cindm_unet1d* h, const std::string& p, const Ten& x0, const Ten* x1, int cout) {
+    if (!h->O("dconv") || !h->use_h3 || !h->use_local_gn) return false;
+    const int L = x0.L, gw = cout / 8;
+    if ((L != 3 && L != 6) || cout % 32 || (gw != 16 && gw != 32 && gw != 64)) return false;
+    if (gw == 64 && (!h->O("dconv_pair") || (cout / 32) % 2)) return false;
+    if (x0.C % 128 || (x1 && (x1->C % 128 || x1->L != L))) return false;
+    if (x0.ld != x0.C || (x1 && x1->ld != x1->C)) return false;      // (every tensor that reaches a block has an fp32 copy)
+    auto w0 = h->packed.find(p + ".blocks.0.block.0"), w1 = h->packed.find(p + ".blocks.1.block.0");
+    if (w0 == h->packed.end() || w1 == h->packed.end() || !w0->second.h3 || !w1->second.h3) return false;
+    const bool identity = !h->packed.count(p + ".residual_conv");
+    if (!identity && !h->packed.count(p + ".residual_conv#h3")) return false;
+    const int k0 = x0.C / 128, k1 = x1 ? x1->C / 128 : 0;
+    if (w0->second.CinP != (k0 + k1) * 128 || w1->second.CinP != cout || cout % 128) return false;
+    return dconv_instantiated(L, k0, k1, !identity) && dconv_instantiated(L, cout / 128, 0, false);
+}
+
+static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const Ten* x1, int cout) {
+    cindm_unet1d* h = E.h;
+    const int Bp = (int)E.rows, L = x0.L, S = 48 / L, gw = cout / 8, NT = cout / 32;
+    const int tiles = (Bp + S - 1) / S;
+    const Packed& w0 = h->packed.at(p + ".blocks.0.block.0");
+    const Packed& w1 = h->packed.at(p + ".blocks.1.block.0");
+    const bool identity = !h->packed.count(p + ".residual_conv");
+    Ten y0; y0.L = L; y0.C = cout; y0.ld = cout; E.planes(y0);
+    Ten out = E.ten(L, cout); E.planes(out);
+    Ten r; if (!identity) r = E.ten(L, cout);
+    auto pair_setup = [&](DconvArgs& d) {
+        if (gw != 64) return;
+        d.xchg = E.xchg((size_t)tiles * NT * 32);
+        d.epoch = h->epoch_dev; d.err_flag = h->epoch_dev + 1;
+        if (!E.epoch_bumped) {              // the exchanges of one forward are tagged with its epoch
+            E.epoch_bumped = true;
+            ++E.launches;
+            if (!E.dry) hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, E.stream, h->epoch_dev);
+        }
+    };
+    auto src = [](DSrc& s, const Ten& t) { s.f32 = t.pl ? nullptr : t.p; s.planes = t.pl; s.pstride = t.pst; s.C = t.C; s.ld = t.ld; };
+    const double cin = (double)x0.C + (x1 ? (double)x1->C : 0.0);
+    DconvArgs d;
+    // A
+    std::memset(&d, 0, sizeof(d));
+    src(d.src[0], x0); if (x1) src(d.src[1], *x1);
+    d.W = reinterpret_cast<const uint4*>(E.W(w0)); d.bias = E.B(w0); d.nch = w0.CinP / 128;
+    d.Bp = Bp; d.N = cout; d.NT = NT; d.gw = gw;
+    d.gamma = E.V(p + ".blocks.0.block.2.weight"); d.beta = E.V(p + ".blocks.0.block.2.bias");
+    d.tb = h->ttable + h->tb_off.at(p); d.tb_ld = h->tb_ld; d.t_ptr = E.t_ptr; d.t_imm = E.t_imm;
+    d.out_planes = y0.pl; d.out_pstride = y0.pst;
+    if (!identity) {
+        const Packed& rc = h->packed.at(p + ".residual_conv#h3");
+        d.W2 = reinterpret_cast<const uint4*>(E.W(rc)); d.bias2 = E.B(rc); d.out2 = r.p; d.ldo2 = r.ld;
+    }
+    pair_setup(d);
+    dconv_launch(E, L, x0.C / 128, x1 ? x1->C / 128 : 0, !identity, d, 2.0 * Bp * L * cout * cin * (5.0 + (identity ? 0.0 : 1.0)));
+    // B
+    std::memset(&d, 0, sizeof(d));
+    src(d.src[0], y0);
+    d.W = reinterpret_cast<const uint4*>(E.W(w1)); d.bias = E.B(w1); d.nch = w1.CinP / 128;
+    d.Bp = Bp; d.N = cout; d.NT = NT; d.gw = gw;
+    d.gamma = E.V(p + ".blocks.1.block.2.weight"); d.beta = E.V(p + ".blocks.1.block.2.bias");
+    d.t_ptr = E.t_ptr; d.t_imm = E.t_imm;
+    if (identity) { d.res = x0.p; d.ldres = x0.ld; } else { d.res = r.p; d.ldres = r.ld; }
+    d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
+    pair_setup(d);
+    dconv_launch(E, L, cout / 128, 0, false, d, 2.0 * Bp * L * cout * (double)cout * 5.0);
+    E.tap(p, out);
+    return out;
+}
+
 // ResidualTemporalBlock (model/diffusion_1d.py:483-511) as three launches:
 //   A: y0 = conv5(x) + b0                      (+ GroupNorm partial stats of y0)
 //   B: y1 = conv5(Mish(GN(y0)) + tbias_t) + b1 (normalise-on-load; + stats of y1)
 //   C: out = Mish(GN(y1)) + (Wr x + br | x)    (1x1 GEMM or epilogue-only; + LayerNorm row partials)
 static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* x1, int cout, bool want_ln, float** ln_out) {
     cindm_unet1d* h = E.h;
+    if (!want_ln && dconv_applicable(h, p, x0, x1, cout)) return emit_rtb_dconv(E, p, x0, x1, cout);
     const int Bp = (int)E.rows, L = x0.L;
     const int gw = cout / 8, Pn = gw > TN ? gw / TN : 1;
     const float cnt = (float)(L * (gw < TN ? gw : TN));
@@ -722,11 +907,10 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
             s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
             s.L = L; s.Bp = Bp;
-            static const int dbg3 = getenv("CINDM_DBG3") ? atoi(getenv("CINDM_DBG3")) : 0;
-            s.dbg = dbg3;
+            s.dbg = h->O("dbg3");
             // samples per workgroup: as many 4-aligned slots as fit one 16-position tile (weights are streamed once
             // per workgroup); CINDM_SITE_PACK=0 keeps one sample per workgroup
-            static const int pack = getenv("CINDM_SITE_PACK") ? atoi(getenv("CINDM_SITE_PACK")) : 1;
+            const int pack = h->O("site_pack");
             const int NTsel = (L > 16) ? 2 : 1;
             s.slot = (L > 16) ? 32 : ceil_to(L, 4);
             s.S = (L > 16 || !pack) ? 1 : 16 / s.slot;
@@ -880,7 +1064,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             cur = dn;
             continue;
         }
-        static const int lvl1 = getenv("CINDM_LEVEL1") ? atoi(getenv("CINDM_LEVEL1")) : 1;      // samples per workgroup: 1 (default) or 2; 0 = off
+        const int lvl1 = h->O("level1");      // samples per workgroup: 1 (default) or 2; 0 = off
         if (ind == 1 && lvl1 && h->level1_ok && att && cur.L <= 16 && (cur.L & 1) == 0 && cur.C == 64 && cur.ld == 64 &&
             h->packed.count("downs.1.2.fn.fn.to_qkv#site") && h->packed.at("downs.1.2.fn.fn.to_qkv#site").h3) {
             const int L = cur.L;
@@ -902,8 +1086,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wo = E.W(h->packed.at("downs.1.2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at("downs.1.2.fn.fn.to_out"));
                 l.Wd = E.W(h->packed.at("downs.1.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.1.3.conv"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L; l.Bp = (int)E.rows;
-                static const int dbg4 = getenv("CINDM_DBG4") ? atoi(getenv("CINDM_DBG4")) : 0;
-                l.dbg = dbg4;
+                l.dbg = h->O("dbg4");
                 const int S = lvl1 == 1 ? 1 : 2;
                 const dim3 grid((unsigned)((E.rows + S - 1) / S));
                 E.prof_begin(5, 0.0);
@@ -931,7 +1114,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
         const int ci = h->dims[nres - 1 - ind], co = h->dims[nres - ind];
         const std::string p = "ups." + std::to_string(ind);
         Ten skip = skips.back(); skips.pop_back();
-        static const int upl = getenv("CINDM_UPS_LAST") ? atoi(getenv("CINDM_UPS_LAST")) : 1;
+        const int upl = h->O("ups_last");
         if (getenv("CINDM_VERBOSE") && E.dry) fprintf(stderr, "[cindm] ups ind %d nres %d ok %d att %d L %d C %d ld %d sC %d sld %d\n", ind, nres, (int)h->ups_last_ok, (int)att, cur.L, cur.C, cur.ld, skip.C, skip.ld);
         if (upl && ind == nres - 2 && h->ups_last_ok && att && cur.L <= 16 && cur.C == 128 && cur.ld == 128 && skip.C == 128 && skip.ld == 128 &&
             h->packed.count(p + ".2.fn.fn.to_qkv#site") && h->packed.at(p + ".2.fn.fn.to_qkv#site").h3 && h->packed.count(p + ".3.conv")) {
@@ -965,7 +1148,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             return 0;
         }
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
-        static const int upt = getenv("CINDM_UPS_TAIL") ? atoi(getenv("CINDM_UPS_TAIL")) : 1;
+        const int upt = h->O("ups_tail");
         if (upt && ind == nres - 3 && h->ups_tail_ok && att && cur.L <= 8 && cur.C == 256 && cur.ld == 256 && ci == 128 &&
             h->packed.count(p + ".2.fn.fn.to_qkv#site") && h->packed.at(p + ".2.fn.fn.to_qkv#site").h3 && h->packed.count(p + ".3.conv")) {
             // the rest of the level in one launch (ups_tail128_kernel)
@@ -1043,20 +1226,12 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
             }
     }
     BlobBuilder bb;
-    {
-        const char* e = getenv("CINDM_MFMA");
-        h->use_h3 = !(e && std::strcmp(e, "f32") == 0);
-        const char* g = getenv("CINDM_LOCAL_GN");
-        h->use_local_gn = !(g && std::strcmp(g, "0") == 0);
-        const char* wq = getenv("CINDM_WIDE_QKV");
-        h->use_wide_qkv = !(wq && std::strcmp(wq, "0") == 0);
-        const char* as = getenv("CINDM_ATTN_SITE");
-        h->use_attn_site = !(as && std::strcmp(as, "0") == 0);
-        const char* l0 = getenv("CINDM_LEVEL0");
-        h->use_level0 = !(l0 && std::strcmp(l0, "0") == 0);
-        const char* hr = getenv("CINDM_H3_RESAMPLE");
-        h->use_h3_resample = !(hr && std::strcmp(hr, "0") == 0);
-    }
+    h->use_h3 = !h->O("mfma_f32");
+    h->use_local_gn = h->O("local_gn") != 0;
+    h->use_wide_qkv = h->O("wide_qkv") != 0;
+    h->use_attn_site = h->O("attn_site") != 0;
+    h->use_level0 = h->O("level0") != 0;
+    h->use_h3_resample = h->O("h3_resample") != 0;
     h->packed.clear(); h->vec_off.clear(); h->tb_off.clear();
     std::vector<RtbDesc> rtbs;
     int tb_ld = 0;
@@ -1100,6 +1275,8 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     HIPCHK(hipMalloc((void**)&h->blob, bb.data.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->blob, bb.data.data(), bb.data.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&h->ttable, (size_t)T * tb_ld * sizeof(float)));
+    if (!h->epoch_dev) { HIPCHK(hipMalloc((void**)&h->epoch_dev, 256)); HIPCHK(hipMemset(h->epoch_dev, 0, 256)); }
+    h->seen_ws = nullptr; h->seen_rows = 0;
     HIPCHK(hipMemsetAsync(h->ttable, 0, (size_t)T * tb_ld * sizeof(float), stream));
 
     // ---- time path for every timestep with the GEMM kernel ("samples" = timesteps, L = 1) ----
@@ -1144,6 +1321,34 @@ extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t ro
 
 extern "C" int cindm_unet1d_launches_per_forward(const cindm_unet1d* h) { return h ? h->launches : 0; }
 
+// The pair-exchange regions of a workspace must not hold a stale tag equal to the current epoch: clear them the first
+// time a (workspace, rows) pair is seen (caller-owned memory arrives uninitialised).  Must run outside stream capture;
+// the sample loops call it before they capture their step.
+static int unet1d_prepare_ws(cindm_unet1d* h, void* ws, int64_t rows, hipStream_t stream) {
+    if (h->seen_ws == ws && h->seen_rows == rows) return 0;
+    std::vector<std::pair<size_t, size_t>> regions;
+    Emitter D{h, nullptr, true, nullptr, 0, rows, nullptr, 0};
+    D.xregions = &regions;
+    emit_forward(D, nullptr, nullptr);
+    for (const auto& r : regions) HIPCHK(hipMemsetAsync((char*)ws + r.first, 0, r.second, stream));
+    h->seen_ws = ws; h->seen_rows = rows;
+    return 0;
+}
+
+// Error flag of the in-kernel pair exchange (a partner that never arrived): synchronises the stream.
+extern "C" int cindm_unet1d_status(cindm_unet1d* h, void* stream) {
+    REQUIRE(h, "null handle");
+    if (!h->epoch_dev) return 0;
+    int v[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(v, h->epoch_dev, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (v[1]) {
+        (void)hipMemsetAsync(h->epoch_dev + 1, 0, sizeof(int), (hipStream_t)stream);
+        return fail("dconv_kernel: a GroupNorm pair exchange timed out (results of that forward are invalid)");
+    }
+    return 0;
+}
+
 extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int32_t* t_dev,
                                     float* eps, int64_t rows, void* ws, size_t ws_bytes, void* stream) {
     REQUIRE(h && x && eps && ws, "null argument");
@@ -1153,6 +1358,7 @@ extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, 
     REQUIRE(ws_bytes >= cindm_unet1d_workspace_bytes(h, rows), "workspace too small");
     REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)x & 15) == 0, "workspace must be 256-byte aligned, x 16-byte aligned");
     h->taps.clear(); h->taps_rows = rows;
+    if (unet1d_prepare_ws(h, ws, rows, (hipStream_t)stream) != 0) return -1;
     Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, t_dev, t};
     emit_forward(E, x, eps);
     if (E.err != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(E.err));
@@ -1167,6 +1373,7 @@ extern "C" int cindm_unet1d_profile(cindm_unet1d* h, const float* x, int32_t t, 
     REQUIRE(t >= 0 && t < h->d.timesteps, "timestep out of range");
     REQUIRE(ws_bytes >= cindm_unet1d_workspace_bytes(h, rows), "workspace too small");
     std::vector<Emitter::ProfRec> recs;
+    if (unet1d_prepare_ws(h, ws, rows, (hipStream_t)stream) != 0) return -1;
     Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, nullptr, t};
     E.prof = &recs;
     h->taps.clear(); h->taps_rows = rows;
@@ -1191,6 +1398,7 @@ extern "C" int cindm_unet1d_profile_detail(cindm_unet1d* h, const float* x, int3
     REQUIRE(h->finalized, "cindm_unet1d_finalize has not been called");
     REQUIRE(ws_bytes >= cindm_unet1d_workspace_bytes(h, rows), "workspace too small");
     std::vector<Emitter::ProfRec> recs;
+    if (unet1d_prepare_ws(h, ws, rows, (hipStream_t)stream) != 0) return -1;
     Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, nullptr, t};
     E.prof = &recs;
     h->taps.clear(); h->taps_rows = rows;
@@ -1347,10 +1555,25 @@ struct StepIO {
     const float* iso; int iso_steps;
 };
 
+// clears the exchange regions of the U-Net workspaces inside a step workspace (before a step is captured into a graph)
+static int prepare_step_ws(cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c, int64_t B, void* ws,
+                           size_t ws_bytes, hipStream_t stream) {
+    REQUIRE(pair && c && ws, "null argument");
+    StepLayout s;
+    if (step_layout(pair, uncond, c, B, state_len(pair, c), s) != 0) return -1;
+    REQUIRE(ws_bytes >= s.total, "workspace too small");
+    if (unet1d_prepare_ws(pair, (char*)ws + s.off_ws_pair, s.pair_rows, stream) != 0) return -1;
+    if (s.single_rows && unet1d_prepare_ws(uncond, (char*)ws + s.off_ws_single, s.single_rows, stream) != 0) return -1;
+    return 0;
+}
+
 static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
                     const StepIO& io, int32_t t, const int32_t* t_dev, int64_t B, void* ws, size_t ws_bytes, hipStream_t stream) {
     REQUIRE(h && pair && c && io.x && ws, "null argument");
     REQUIRE(t_dev || (t >= 0 && t < h->T), "timestep out of range");
+    // the U-Net's time path is a per-timestep table of d.timesteps rows: a longer diffusion would index past it
+    REQUIRE(h->T <= pair->d.timesteps && (!uncond || h->T <= uncond->d.timesteps),
+            "the diffusion has more timesteps than the U-Net's per-timestep table (construct TemporalUnet1D(..., timesteps=T))");
     REQUIRE(c->cond_steps == 0 || io.cond, "cond_steps > 0 requires cond");
     REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
     const int Ltot = state_len(pair, c);
@@ -1452,6 +1675,7 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1;
+    if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)t_start);
     const int nsteps = t_start - t_end + 1;
     if (!use_graph) {
@@ -1545,6 +1769,7 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
+    if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)times[0]);
     return replay_steps(stream, n_steps, use_graph,
                         [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
@@ -1579,6 +1804,7 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dz = dz; io.iso = initial_state_overwrite; io.iso_steps = initial_state_overwrite ? overwrite_steps : 0;
     io.recur_t_stride = (int64_t)(R > 0 ? R : 1) * B * Ltot * F;
+    if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
     hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)t_start);
     // one reverse step (:1286-1370): R x [p_mean_variance, mean - grad, overwrite, relaxation]; the last iteration's
     // relaxation is never used by the reference, its pred + sigma z is the step's result

@@ -571,7 +571,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
 
-template <int T, int ROWS, int MODE, bool RES = false>
+// ABL (timing ablations of the main loop, wrong results): 1 no weight reloads, 2 no MFMAs, 3 no activation restaging
+// (and no per-stage barrier), 4 = 1 + 3, 5 no LDS fragment reads
+template <int T, int ROWS, int MODE, bool RES = false, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     constexpr int KC = 128;
     constexpr int PITCH = 272;              // bytes per LDS row per plane: 128 halfs + 16 B pad
@@ -757,9 +759,9 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     if (a.dbg == 11) return;                          // prologue only
     for (int ch = 0; ch < (a.dbg == 7 ? 0 : nch); ++ch) {
         const int chn = min(ch + 1, nch - 1);
-        load_a(chn);
-        const unsigned char* P0 = Ah[ch & 1][0];
-        const unsigned char* P1 = Ah[ch & 1][1];
+        if constexpr (ABL != 3 && ABL != 4) load_a(chn);
+        const unsigned char* P0 = Ah[(ABL == 3 || ABL == 4) ? 0 : (ch & 1)][0];
+        const unsigned char* P1 = Ah[(ABL == 3 || ABL == 4) ? 0 : (ch & 1)][1];
         // A fragments are read one tap AHEAD of their use into an explicit second register set (hipcc otherwise
         // re-uses one set and exposes the LDS latency in front of every 6 MFMAs)
         half8 fh[2][3], fl[2][3];
@@ -770,13 +772,22 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
                 al[mb] = *reinterpret_cast<const half8*>(P1 + aaddr[mb][tap]);
             }
         };
-        read_frags(0, fh[0], fl[0]);
+        if (ABL != 5 || ch == 0) read_frags(0, fh[0], fl[0]);
 #pragma unroll
         for (int tap = 0; tap < T; ++tap) {
-            if (tap + 1 < T) read_frags(tap + 1, fh[(tap + 1) & 1], fl[(tap + 1) & 1]);
+            if (tap + 1 < T && (ABL != 5 || ch == 0)) read_frags(tap + 1, fh[(tap + 1) & 1], fl[(tap + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             const half8 (&ah)[3] = fh[tap & 1];
             const half8 (&al)[3] = fl[tap & 1];
+            if constexpr (ABL == 2) {
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        accM[mb][nb][0] += (float)ah[mb][0] * (float)breg[tap][nb][0][0];
+                        accL[mb][nb][0] += (float)al[mb][0] * (float)breg[tap][nb][1][0];
+                    }
+            } else {
 #pragma unroll
             for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
@@ -785,6 +796,7 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
                     accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], breg[tap][nb][1], accL[mb][nb], 0, 0, 0);
                     accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], breg[tap][nb][0], accL[mb][nb], 0, 0, 0);
                 }
+            }
             if constexpr (RES) if (tap == T / 2) {     // the 1x1 residual_conv on the same (centre-tap) rows
 #pragma unroll
                 for (int mb = 0; mb < 3; ++mb)
@@ -796,11 +808,13 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
                     }
                 load_r(chn);
             }
-            load_b_tap(chn, tap);          // next stage's fragments for this tap, T-1 taps ahead of their use
+            if constexpr (ABL != 1 && ABL != 4) load_b_tap(chn, tap);          // next stage's fragments for this tap, T-1 taps ahead of their use
         }
         // (staging the next stage's rows in per-tap slices was measured: no faster, and one build of it was flaky)
-        store_a(chn, (ch + 1) & 1, 0, NP);
-        __syncthreads();
+        if constexpr (ABL != 3 && ABL != 4) {
+            store_a(chn, (ch + 1) & 1, 0, NP);
+            __syncthreads();
+        }
     }
 
     f32x4 acc[3][2];

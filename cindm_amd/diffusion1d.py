@@ -68,6 +68,10 @@ class GaussianDiffusion1D(nn.Module):
         assert objective in {"pred_noise", "pred_x0", "pred_v"}, "objective must be pred_noise, pred_x0 or pred_v"
         tables = make_schedule(beta_schedule, timesteps, objective)
         self.num_timesteps = int(timesteps)
+        # the model's time path is a table with model.timesteps rows (the reference evaluates its time MLP per call)
+        mt = getattr(model, "timesteps", None)
+        if mt is not None and int(mt) < int(timesteps):
+            raise ValueError(f"model was built with timesteps={mt} < diffusion timesteps={timesteps}: pass timesteps={timesteps} to the model")
         self.loss_type = loss_type
         self.loss_weight_discount = loss_weight_discount
         self.sampling_timesteps = sampling_timesteps if _exists(sampling_timesteps) else timesteps

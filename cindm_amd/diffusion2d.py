@@ -74,6 +74,10 @@ class GaussianDiffusion(nn.Module):
         assert image_size == model.image_size, "image_size must match the Unet's launch plan"
         tables = make_schedule(beta_schedule, timesteps, objective)
         self.num_timesteps = int(timesteps)
+        # the model's time path is a table with model.timesteps rows (the reference evaluates its time MLP per call)
+        mt = getattr(model, "timesteps", None)
+        if mt is not None and int(mt) < int(timesteps):
+            raise ValueError(f"model was built with timesteps={mt} < diffusion timesteps={timesteps}: pass timesteps={timesteps} to the model")
         self.loss_type = loss_type
         self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else timesteps
         assert self.sampling_timesteps <= timesteps

@@ -26,9 +26,13 @@ def all_gather_designs(local, total, group=None):
     if local.shape[0] < maxb:
         pad = torch.cat([local, local.new_zeros((maxb - local.shape[0],) + tuple(local.shape[1:]))], 0)
     pad = pad.contiguous()
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+    # gloo (CPU tests, or several ranks sharing one GPU) has no device all_gather: stage through the host
+    via_host = pad.is_cuda and dist.get_backend(group) == "gloo"
+    send = pad.cpu() if via_host else pad
+    out = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(out, send, group=group)
+    res = torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+    return res.to(local.device) if via_host else res
 
 
 def sample_sharded(diffusion, batch_size, *, seed, group=None, gather=True, cond=None, **sample_kw):

@@ -133,6 +133,14 @@ class TemporalUnet1D(nn.Module):
             _ffi.check(L.cindm_unet1d_finalize(self._h, _ffi.current_stream(dev)))
         self._sig = sig
 
+    def set_option(self, key, value):
+        """Selects a kernel path of this model (``cindm_unet1d_set_option``; keys in include/cindm_hip.h), e.g.
+        ``set_option("mfma_f32", 1)``.  Every path computes the same function; takes effect at the next call."""
+        _ffi.check(_ffi.lib().cindm_unet1d_set_option(self._h, key.encode(), int(value)))
+        self._sig = None
+        self._ws = None
+        return self
+
     def workspace(self, rows, device):
         L = _ffi.lib()
         if self._ws is None or self._ws_rows < rows or self._ws.device != device:

@@ -124,6 +124,13 @@ class Unet(nn.Module):
             _ffi.check(L.cindm_unet2d_finalize(self._h, _ffi.current_stream(dev)))
         self._sig = sig
 
+    def set_option(self, key, value):
+        """Selects a kernel path of this model (``cindm_unet2d_set_option``; keys in include/cindm_hip.h)."""
+        _ffi.check(_ffi.lib().cindm_unet2d_set_option(self._h, key.encode(), int(value)))
+        self._sig = None
+        self._ws = None
+        return self
+
     def workspace(self, images, device):
         if self._ws is None or self._ws_images < images or self._ws.device != device:
             nbytes = _ffi.lib().cindm_unet2d_workspace_bytes(self._h, images)

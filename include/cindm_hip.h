@@ -38,6 +38,9 @@ typedef struct cindm_ddpm1d cindm_ddpm1d;
 /* ------------------------------------------------------------------ misc */
 int cindm_abi_version(void);
 const char* cindm_last_error(void);
+/* sha256 (hex) of the sources this library was compiled from (everything under cindm_amd/csrc plus this header), embedded by
+ * cindm_amd/build.py: the Python face refuses a library whose hash differs from the sources next to it. */
+const char* cindm_source_hash(void);
 
 /* ------------------------------------------------------------------ TemporalUnet1D
  * Replaces TemporalUnet1D.__init__/forward, model/diffusion_1d.py:517-646, and the blocks it
@@ -73,6 +76,18 @@ int  cindm_unet1d_set_sinusoid_table(cindm_unet1d* h, const float* table_host, i
  * the time path time_mlp -> per-block Mish->Linear biases (:537-542, :493-497, :509) with the
  * GEMM kernels.  Synchronises `stream`. */
 int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
+
+/* Kernel-path selection for this handle (before *_finalize; changing an option un-finalizes the handle).  Every
+ * alternative path computes the same function (the parity suite runs all of them); defaults are the fast path.
+ * Keys: "mfma_f32" (1 = exact fp32 MFMA kernels instead of the split-fp16 ones), "local_gn", "attn_site",
+ * "wide_qkv", "level0", "level1", "ups_last", "ups_tail", "h3_resample", "site_pack", "auto_range",
+ * "dbg"/"dbg3"/"dbg4" (timing ablations, wrong results).  No reference counterpart (PyTorch picks its own kernels). */
+int  cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value);
+int  cindm_unet1d_get_option(const cindm_unet1d* h, const char* key, int32_t* value);
+
+/* Synchronises `stream` and reports a device-side fault of earlier forwards (the bounded in-kernel exchange between
+ * workgroup pairs of the C = 512 GroupNorms timing out).  0 = healthy. */
+int  cindm_unet1d_status(cindm_unet1d* h, void* stream);
 
 size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t rows);
 /* eps[rows,horizon,F] = TemporalUnet1D.forward(x[rows,horizon,F], time=t)   (:610-646).
@@ -281,6 +296,8 @@ int  cindm_unet2d_set_sinusoid_table(cindm_unet2d* h, const float* table, int64_
 /* Weight standardisation (WeightStandardizedConv2d :116-124) folded, MFMA-fragment repack,
  * time path (SinusoidalPosEmb -> Linear -> GELU -> Linear -> per block SiLU -> Linear, :320-326,
  * :205-208) evaluated for every timestep into a device table. */
+/* Kernel-path selection, as cindm_unet1d_set_option.  Keys: "mfma_f32", "la_site", "auto_range", "dbg2"/"dbg3". */
+int  cindm_unet2d_set_option(cindm_unet2d* h, const char* key, int32_t value);
 int  cindm_unet2d_finalize(cindm_unet2d* h, void* stream);
 int  cindm_unet2d_padded_channels(const cindm_unet2d* h);
 size_t cindm_unet2d_workspace_bytes(const cindm_unet2d* h, int64_t images);
