@@ -75,6 +75,7 @@ struct cindm_unet1d {
     int launches = 0;
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
+    bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
     // kernel-path options (cindm_unet1d_set_option; defaults = the fast path, overridable by CINDM_* at create)
     std::map<std::string, int> opt;
     int O(const char* k) const { auto it = opt.find(k); return it == opt.end() ? 0 : it->second; }
@@ -161,6 +162,7 @@ static const OptDef kUnet1dOpts[] = {
     {"site_pack", 1, "CINDM_SITE_PACK"},   // several samples per attention-site workgroup
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
+    {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"dbg", 0, "CINDM_DBG"}, {"dbg3", 0, "CINDM_DBG3"}, {"dbg4", 0, "CINDM_DBG4"},   // timing ablations (wrong results)
 };
@@ -569,6 +571,7 @@ struct Emitter {
     struct ProfRec { int kind; hipEvent_t e0, e1; double flops; int gx, gy, nstage; };
     std::vector<ProfRec>* prof = nullptr;     // when set, every launch is bracketed by HIP events
     static constexpr int prof_reps = 8;
+    const char* pf_next = nullptr; size_t pf_next_bytes = 0;      // weights of the launch that follows the next block (L2 warm-up)
     bool epoch_bumped = false;                // dconv pair exchanges: the per-forward epoch has been advanced
     std::vector<std::pair<size_t, size_t>>* xregions = nullptr;      // dry run: (offset, bytes) of the exchange regions
 
@@ -712,6 +715,7 @@ static void dconv_launch(Emitter& E, int L, int k0, int k1, bool res, const Dcon
     if (E.dry) return;
     const int S = 48 / L;
     const dim3 grid((unsigned)d.NT, (unsigned)((d.Bp + S - 1) / S));
+    const_cast<DconvArgs&>(d).dbg = E.h->O("dbg") >= 30 ? E.h->O("dbg") - 30 : 0;      // dbg 31..35: dconv phase ablations
     E.prof_begin(4, flops);
     if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }
     for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
@@ -766,8 +770,12 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
         d.epoch = h->epoch_dev; d.err_flag = h->epoch_dev + 1;
         if (!E.epoch_bumped) {              // the exchanges of one forward are tagged with its epoch
             E.epoch_bumped = true;
-            ++E.launches;
-            if (!E.dry) hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, E.stream, h->epoch_dev);
+            if (!E.dry && h->epoch_prebumped) {
+                h->epoch_prebumped = false; // advanced by the previous step's counter kernel (sample loops)
+            } else {
+                ++E.launches;
+                if (!E.dry) hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, E.stream, h->epoch_dev);
+            }
         }
     };
     auto src = [](DSrc& s, const Ten& t) { s.f32 = t.pl ? nullptr : t.p; s.planes = t.pl; s.pstride = t.pst; s.C = t.C; s.ld = t.ld; };
@@ -786,6 +794,11 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
         d.W2 = reinterpret_cast<const uint4*>(E.W(rc)); d.bias2 = E.B(rc); d.out2 = r.p; d.ldo2 = r.ld;
     }
     pair_setup(d);
+    if (h->O("l2_prefetch")) {              // warm the L2s with launch B's weights (tile nt' of B runs on XCD nt' % 8)
+        d.pf = reinterpret_cast<const char*>(E.W(w1)); d.pf_regions = NT / 8; d.pf_tile_bytes = (unsigned)(w1.CinP / 128) * 20 * 256 * 16;
+        d.pf_stride = d.pf_tile_bytes;
+        if (!d.err_flag) d.err_flag = h->epoch_dev + 1;
+    }
     dconv_launch(E, L, x0.C / 128, x1 ? x1->C / 128 : 0, !identity, d, 2.0 * Bp * L * cout * cin * (5.0 + (identity ? 0.0 : 1.0)));
     // B
     std::memset(&d, 0, sizeof(d));
@@ -797,6 +810,11 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
     if (identity) { d.res = x0.p; d.ldres = x0.ld; } else { d.res = r.p; d.ldres = r.ld; }
     d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
     pair_setup(d);
+    if (h->O("l2_prefetch") && E.pf_next && E.pf_next_bytes) {      // the next launch's weights (read by every workgroup of it)
+        d.pf = E.pf_next; d.pf_regions = 1; d.pf_stride = 0; d.pf_tile_bytes = (unsigned)E.pf_next_bytes;
+        if (!d.err_flag) d.err_flag = h->epoch_dev + 1;
+    }
+    E.pf_next = nullptr; E.pf_next_bytes = 0;
     dconv_launch(E, L, cout / 128, 0, false, d, 2.0 * Bp * L * cout * (double)cout * 5.0);
     E.tap(p, out);
     return out;
@@ -1146,6 +1164,17 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             }
             E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre);
             return 0;
+        }
+        if (h->O("ups_tail") && ind == nres - 3 && h->ups_tail_ok && h->packed.count(p + ".1.blocks.0.block.0#lvl")) {
+            // the level-tail kernel that follows streams these weights in every workgroup: have the block warm the L2s
+            size_t lo = ~(size_t)0, hi = 0;
+            for (const std::string& k : {p + ".1.blocks.0.block.0#lvl", p + ".1.blocks.1.block.0#lvl", p + ".1.residual_conv#lvl", p + ".3.conv#lvl"}) {
+                auto it = h->packed.find(k);
+                if (it == h->packed.end()) continue;
+                const Packed& pk = it->second;
+                lo = std::min(lo, pk.off); hi = std::max(hi, pk.off + (size_t)(pk.Npad / 16) * pk.T * (pk.CinP / 32) * 2 * 64 * 4);
+            }
+            if (hi > lo && hi <= h->blob_floats) { E.pf_next = reinterpret_cast<const char*>(h->blob + lo); E.pf_next_bytes = std::min((hi - lo) * 4, (size_t)2 << 20); }
         }
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
         const int upt = h->O("ups_tail");
@@ -1624,7 +1653,13 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
                              w + s.off_ws_single, ws_bytes - s.off_ws_single, stream) != 0) return -1;
     const int64_t ne = B * (int64_t)Ltot * a.F;
     hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);
-    if (io.dec_t) hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, io.ddim_tab ? io.ddim_tnext : (const int*)nullptr);
+    if (io.dec_t) {
+        // the counter kernel also advances the U-Nets' exchange epochs for the step that follows
+        hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, io.ddim_tab ? io.ddim_tnext : (const int*)nullptr,
+                           pair->epoch_dev, (s.single_rows && uncond) ? uncond->epoch_dev : (int*)nullptr);
+        pair->epoch_prebumped = true;
+        if (s.single_rows && uncond) uncond->epoch_prebumped = true;
+    }
     HIPCHK(hipGetLastError());
     if (guided) HIPCHK(hipMemcpyAsync(io.x_out, a.x_out, (size_t)ne * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return 0;
@@ -1651,6 +1686,19 @@ extern "C" int cindm_ddpm1d_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet
 }
 
 __global__ void set_counter_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = v; p[1] = 0; p[2] = 0; } }
+// the sample loops end with a handle whose epoch has been advanced for a step that never runs: harmless (the next
+// forward simply uses that epoch), but the flag must describe the stream-ordered truth, so loops clear nothing.
+
+
+// start of a sample loop: set the device step counter and advance the U-Nets' exchange epochs once, eagerly, so that the
+// captured step carries no epoch launch (its counter kernel advances them for the following step)
+static void start_loop(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c, int t0, hipStream_t stream) {
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, t0);
+    if (pair->epoch_dev) { hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, stream, pair->epoch_dev); pair->epoch_prebumped = true; }
+    if (c->mode == CINDM_COMPOSE_MULTIBODY && uncond && uncond->epoch_dev) {
+        hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, stream, uncond->epoch_dev); uncond->epoch_prebumped = true;
+    }
+}
 
 extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
                                    float* x, const float* cond, const float* noise_steps, uint64_t seed, int64_t sample_offset,
@@ -1676,7 +1724,7 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1;
     if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
-    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)t_start);
+    start_loop(h, pair, uncond, c, (int)t_start, stream);
     const int nsteps = t_start - t_end + 1;
     if (!use_graph) {
         for (int i = 0; i < nsteps; ++i) {
@@ -1770,7 +1818,7 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
     if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
-    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)times[0]);
+    start_loop(h, pair, uncond, c, (int)times[0], stream);
     return replay_steps(stream, n_steps, use_graph,
                         [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
 }
@@ -1805,7 +1853,7 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
     io.dz = dz; io.iso = initial_state_overwrite; io.iso_steps = initial_state_overwrite ? overwrite_steps : 0;
     io.recur_t_stride = (int64_t)(R > 0 ? R : 1) * B * Ltot * F;
     if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
-    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, (int)t_start);
+    start_loop(h, pair, uncond, c, (int)t_start, stream);
     // one reverse step (:1286-1370): R x [p_mean_variance, mean - grad, overwrite, relaxation]; the last iteration's
     // relaxation is never used by the reference, its pred + sigma z is the step's result
     auto step = [&]() -> int {

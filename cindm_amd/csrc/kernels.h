@@ -2888,10 +2888,14 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
 // step has finished).  A "last block done" atomic inside the update kernel cost one same-address device-scope atomic
 // and one release fence per block: 46 ns each, 282 us per step for the 6144 blocks of the 2-D update.
 // t_dev[0] = t, t_dev[2] = DDIM step index.
-__global__ void step_counter_kernel(int* t_dev, const int* ddim_tnext) {
+// e0 / e1: per-forward epochs of the U-Nets the NEXT step will run (dconv_kernel's pair exchanges), advanced here so
+// that a step needs no epoch launch of its own; null = none
+__global__ void step_counter_kernel(int* t_dev, const int* ddim_tnext, int* e0, int* e1) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (ddim_tnext) { const int sidx = t_dev[2]; t_dev[0] = max(ddim_tnext[sidx], 0); t_dev[2] = sidx + 1; }
         else t_dev[0] -= 1;
+        if (e0) e0[0] += 1;
+        if (e1) e1[0] += 1;
     }
 }
 

@@ -45,6 +45,11 @@ struct DconvArgs {
     uint4* out_planes; size_t out_pstride;      // planes output (tiled) or null
     const uint4* W2; const float* bias2; float* out2; int ldo2;     // riding 1x1 residual_conv: out2 = W2 . x + bias2
     unsigned long long* xchg; const int* epoch; int* err_flag;     // gw == 64: pair exchange of GroupNorm halves
+    // L2 warm-up for the NEXT launch: its weight tiles (pf_regions of pf_tile_bytes each, tile index = this
+    // workgroup's XCD + 8 k) are touched one dword per 128-byte line while this launch runs; null = none
+    const char* pf; int pf_regions; unsigned pf_tile_bytes; unsigned pf_stride;    // region k of XCD x: pf + (x + 8 k) * pf_stride
+    int dbg;                                    // timing ablations (wrong results): 1 return at entry, 2 after staging,
+                                                // 3 no K loop, 4 no epilogue, 5 no pair exchange, 6 return after the cross-wave reduce, 7 before the stores, 8 no planes store
 };
 
 __global__ void dconv_epoch_kernel(int* e) { if (threadIdx.x == 0 && blockIdx.x == 0) e[0] += 1; }
@@ -63,8 +68,9 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     static_assert(L == 3 || L == 6, "3 or 6 positions per sample");
     __shared__ uint4 Img[2][PLANE_U4];        // [plane][k-step][k-quarter][row] x 8 halfs
     __shared__ float Red[4][TM * LDR];
-    __shared__ uint4 Tile[2 * 192];           // output planes of this tile: [plane][k-quarter][row] x 8 halfs
+    __shared__ uint4 Tile[2 * 48 * 5];        // output planes of this tile: [plane][row][16 dwords + 4 pad]
 
+    if (a.dbg == 1) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * S;
@@ -72,61 +78,54 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     const int n = tid & 31, rq = tid >> 5;
     const int gn = nt * TN + n;
 
-    // ---- epilogue operands: issued first so that their latency is hidden behind everything else ----------------
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
-    const unsigned tag = a.epoch ? (unsigned)*a.epoch : 0u;
-    const float bias = a.bias ? a.bias[gn] : 0.f;
-    const float gam = a.gamma[gn], bet = a.beta[gn];
-    const float tbv = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : 0.f;
-    float bias2 = 0.f;
-    if constexpr (RES) bias2 = a.bias2 ? a.bias2[gn] : 0.f;
     // row r = rq + 8 q of the tile: S = 16: position q >> 1, sample rq + 8 (q & 1);  S = 8: position q, sample rq
     int grow[6];
     bool sok[6];
-    float rs[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int pos = (S == 16) ? (q >> 1) : q;
         const int s = (S == 16) ? rq + 8 * (q & 1) : rq;
         sok[q] = s < ns;
         grow[q] = (b0 + min(s, ns - 1)) * L + pos;
-        rs[q] = a.res ? a.res[(size_t)grow[q] * a.ldres + gn] : 0.f;
     }
 
     // ---- staging: wave w stages (and later reads) only the k-steps 4 j + w ----------------------------------------
     // item = lane + 64 i (i < 3) of a k-step: planes source: k-quarter item / 48, row item % 48 (linear copy);
-    // fp32 source: row item >> 2, k-quarter item & 3 (a row's 32 channels are one 128-byte line)
-    auto load_raw = [&](const DSrc& s, int j, uint4 (&raw)[3][2]) {
-        const int ks = 4 * j + w;
-        if (s.planes) {
-            const uint4* p = s.planes + ((size_t)mt * (s.C >> 5) + ks) * 192 + lane;
+    // fp32 source: row item >> 2, k-quarter item & 3 (a row's 32 channels are one 128-byte line).  Either way an item
+    // is two 16-byte loads from (base_i + k-step * kstride) and (.. + second): the source kind only selects addresses.
+    struct Stg { const uint4* base[3]; size_t kstride, second; int slot[3]; bool f32; };
+    auto stg_init = [&](const DSrc& s, Stg& g) {
+        g.f32 = s.planes == nullptr;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { raw[i][0] = p[64 * i]; raw[i][1] = p[s.pstride + 64 * i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int item = lane + 64 * i, row = item >> 2, kq = item & 3;
+        for (int i = 0; i < 3; ++i) {
+            const int item = lane + 64 * i;
+            if (!g.f32) {
+                const int kq = item / 48, row = item - kq * 48;
+                g.base[i] = s.planes + (size_t)mt * (s.C >> 5) * 192 + item;
+                g.slot[i] = kq * RPAD + H * S + row;
+            } else {
+                const int row = item >> 2, kq = item & 3;
                 const int sm = row % S, pos = row / S;
-                const float* p = s.f32 + (size_t)((b0 + min(sm, ns - 1)) * L + pos) * s.ld + ks * 32 + kq * 8;
-                raw[i][0] = *reinterpret_cast<const uint4*>(p);
-                raw[i][1] = *reinterpret_cast<const uint4*>(p + 4);
+                g.base[i] = reinterpret_cast<const uint4*>(s.f32 + (size_t)((b0 + min(sm, ns - 1)) * L + pos) * s.ld + kq * 8);
+                g.slot[i] = kq * RPAD + H * S + row;
             }
         }
+        g.kstride = g.f32 ? 8 : 192;
+        g.second = g.f32 ? 1 : s.pstride;
     };
-    auto store_raw = [&](const DSrc& s, int j, const uint4 (&raw)[3][2]) {
-        const int ks = 4 * j + w;
-        if (s.planes) {
+    auto load_raw = [&](const Stg& g, int j, uint4 (&raw)[3][2]) {
+        const size_t ko = (size_t)(4 * j + w) * g.kstride;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int item = lane + 64 * i, kq = item / 48, row = item - kq * 48;
-                const int slot = (ks * 4 + kq) * RPAD + H * S + row;
-                Img[0][slot] = raw[i][0];
-                Img[1][slot] = raw[i][1];
-            }
+        for (int i = 0; i < 3; ++i) { raw[i][0] = g.base[i][ko]; raw[i][1] = g.base[i][ko + g.second]; }
+    };
+    auto store_raw = [&](const Stg& g, int j, const uint4 (&raw)[3][2]) {
+        const int kb = (4 * j + w) * 4 * RPAD;
+        if (!g.f32) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Img[0][kb + g.slot[i]] = raw[i][0]; Img[1][kb + g.slot[i]] = raw[i][1]; }
         } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int item = lane + 64 * i, row = item >> 2, kq = item & 3;
                 const float4 v0 = __builtin_bit_cast(float4, raw[i][0]), v1 = __builtin_bit_cast(float4, raw[i][1]);
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 half8 hi, lo;
@@ -135,16 +134,17 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
                     hi[e] = (_Float16)v[e];
                     lo[e] = (_Float16)((v[e] - (float)hi[e]) * H3_SCALE);
                 }
-                const int slot = (ks * 4 + kq) * RPAD + H * S + row;
-                Img[0][slot] = __builtin_bit_cast(uint4, hi);
-                Img[1][slot] = __builtin_bit_cast(uint4, lo);
+                Img[0][kb + g.slot[i]] = __builtin_bit_cast(uint4, hi);
+                Img[1][kb + g.slot[i]] = __builtin_bit_cast(uint4, lo);
             }
         }
     };
 
+    Stg g0, g1;
+    stg_init(a.src[0], g0);
     uint4 raw0[KPW0][3][2];
 #pragma unroll
-    for (int j = 0; j < KPW0; ++j) load_raw(a.src[0], j, raw0[j]);
+    for (int j = 0; j < KPW0; ++j) load_raw(g0, j, raw0[j]);
 
     // B: this wave's fragments of stage ch, tap by tap; reloaded for the next stage right after their last use
     half8 breg[T][2][2];
@@ -169,9 +169,25 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     // the second source's rows are fetched now and parked in registers until the first source's k-steps are done
     uint4 raw1[KPW1 > 0 ? KPW1 : 1][3][2];
     if constexpr (KPW1 > 0) {
+        stg_init(a.src[1], g1);
 #pragma unroll
-        for (int j = 0; j < KPW1; ++j) load_raw(a.src[1], j, raw1[j]);
+        for (int j = 0; j < KPW1; ++j) load_raw(g1, j, raw1[j]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue operands: requested behind the operand streams, consumed after the K loop ------------------------
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const unsigned tag = a.epoch ? (unsigned)*a.epoch : 0u;
+    const float bias = a.bias ? a.bias[gn] : 0.f;
+    const float gam = a.gamma[gn], bet = a.beta[gn];
+    const float tbv = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : 0.f;
+    float bias2 = 0.f;
+    if constexpr (RES) bias2 = a.bias2 ? a.bias2[gn] : 0.f;
+    float rs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.res) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rs[q] = a.res[(size_t)grow[q] * a.ldres + gn];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // zero halo rows of this wave's k-steps (L = 6: one position of 8 samples on each side)
     if constexpr (H > 0) {
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < KPW0; ++j) store_raw(a.src[0], j, raw0[j]);
+    for (int j = 0; j < KPW0; ++j) store_raw(g0, j, raw0[j]);
 
     f32x4 accM[3][2], accL[3][2], accRM[3][2], accRL[3][2];
 #pragma unroll
@@ -196,8 +212,10 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
             accRM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accRL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-    // one k-step (32 channels of this wave) against all five taps: window p = 16 rows starting at image position p
-    auto kstep = [&](int j, int ch, int chn) {
+    // one k-step (32 channels of this wave) against all five taps: window p = 16 rows starting at image position p;
+    // PF: the next stage's fragments are requested tap by tap behind their last use (not on the very last k-step)
+    auto kstep = [&](int j, int chn, auto pf) {
+        constexpr bool PF = decltype(pf)::value;
         const int base = ((4 * j + w) * 4 + (lane >> 4)) * RPAD + (lane & 15);
         half8 fh[NWIN], fl[NWIN];
 #pragma unroll
@@ -233,21 +251,53 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
                     for (int nb = 0; nb < 2; ++nb)
                         accRL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], rreg[nb][0], accRL[mb][nb], 0, 0, 0);
                 }
-                load_r(chn);
+                if constexpr (PF) load_r(chn);
             }
-            load_b_tap(chn, tap);
+            if constexpr (PF) load_b_tap(chn, tap);
         }
-        (void)ch;
     };
-    const int last = a.nch - 1;
-#pragma unroll 1
-    for (int j = 0; j < KPW0; ++j) kstep(j, j, min(j + 1, last));
-    if constexpr (KPW1 > 0) {
+    if (a.dbg == 2) { if (Img[0][tid].x == 0x12345u) a.out2[0] = 1.f; return; }
+    // L2 warm-up of the next launch's weights: block b runs on XCD b % 8 (observed rule; a wrong guess only loses the
+    // benefit), the workgroups of an XCD share its regions line by line; the loaded dwords are parked until the end
+    unsigned pfv[2][2] = {{0u, 0u}, {0u, 0u}};
+    auto prefetch = [&]() {
+        if (!a.pf) return;
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, rank = lin >> 3;
+        const int nshare = (gridDim.x * gridDim.y + 7) >> 3;
+        const int lines = (int)(a.pf_tile_bytes >> 7);
+        const int per = (lines + nshare - 1) / nshare;
 #pragma unroll
-        for (int j = 0; j < KPW1; ++j) store_raw(a.src[1], j, raw1[j]);
+        for (int k = 0; k < 2; ++k) {
+            if (k >= a.pf_regions) break;
+            const char* base = a.pf + (size_t)(xcd + 8 * k) * a.pf_stride;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int li = tid + 256 * i;
+                const int line = rank * per + li;
+                if (li < per && line < lines) pfv[k][i] = *reinterpret_cast<const unsigned*>(base + ((size_t)line << 7));
+            }
+        }
+    };
+    if (a.dbg != 3) {
+        constexpr std::true_type PFY{};
+        constexpr std::false_type PFN{};
+        if constexpr (KPW1 == 0) {
 #pragma unroll 1
-        for (int j = 0; j < KPW1; ++j) kstep(j, KPW0 + j, min(KPW0 + j + 1, last));
+            for (int j = 0; j < KPW0 - 1; ++j) kstep(j, j + 1, PFY);
+            prefetch();
+            kstep(KPW0 - 1, 0, PFN);
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < KPW0; ++j) kstep(j, j + 1, PFY);
+#pragma unroll
+            for (int j = 0; j < KPW1; ++j) store_raw(g1, j, raw1[j]);
+#pragma unroll 1
+            for (int j = 0; j < KPW1 - 1; ++j) kstep(j, KPW0 + j + 1, PFY);
+            prefetch();
+            kstep(KPW1 - 1, 0, PFN);
+        }
     }
+    if (a.dbg == 4) { if (accM[0][0][0] + accL[1][1][2] + accRM[2][0][1] + accRL[0][1][3] == 123.456f) a.out2[0] = 1.f; return; }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------
     auto reduce_to = [&](const f32x4 (&m)[3][2], const f32x4 (&l)[3][2], float bs, float (&v)[6]) {
@@ -267,6 +317,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     };
     float v[6];
     reduce_to(accM, accL, bias, v);
+    if (a.dbg == 6) { if (v[0] + v[5] == 123.456f) a.out2[0] = 1.f; return; }
 
     // GroupNorm over (group columns x L positions) of each sample: this thread holds every position of its sample(s)
     constexpr int NSAMP = (S == 16) ? 2 : 1;
@@ -288,7 +339,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         if (gwt == 32) s2 = xsum16(s2);
         mean[js] = m; rstd[js] = s2;                              // rstd holds M2 until the exchange below is done
     }
-    if (a.gw == 64) {
+    if (a.gw == 64 && a.dbg != 5) {
         // the group's other 32 columns belong to the workgroup nt ^ 1 of the same m-tile: swap (mean, M2) halves
         const int sbase = ((mt * a.NT + nt) * 16) * 2, pbase = ((mt * a.NT + (nt ^ 1)) * 16) * 2;
 #pragma unroll
@@ -331,23 +382,34 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         const int js = (S == 16) ? (q & 1) : 0;
         y[q] = mish_f((v[q] - mean[js]) * rstd[js] * gam + bet) + tbv;
         if (a.res) y[q] += rs[q];
-        if (a.out_f32 && sok[q]) a.out_f32[(size_t)grow[q] * a.ldo + gn] = y[q];
     }
-    if (a.out_planes) {
-        _Float16* th = reinterpret_cast<_Float16*>(Tile);
+    if (a.dbg == 7) { if (y[0] + y[5] == 123.456f) a.out2[0] = 1.f; return; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if (a.out_f32 && sok[q]) a.out_f32[(size_t)grow[q] * a.ldo + gn] = y[q];
+    if (a.out_planes && a.dbg != 8) {
+        // planes of the tile: row-major [plane][row][32 halfs + pad] in LDS, re-read as 16-byte (row, k-quarter) items.
+        // A lane pairs with its neighbour column (DPP quad swap): the even lane writes the hi dword (own, neighbour),
+        // the odd lane the lo dword (neighbour, own) -- one 32-bit LDS store per value instead of two 16-bit ones.
+        constexpr int TP = 20;                                    // dwords per tile row (16 + 4 pad)
+        uint32_t* tw = reinterpret_cast<uint32_t*>(Tile);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int r = rq + 8 * q;
             const _Float16 hi = (_Float16)y[q];
             const _Float16 lo = (_Float16)((y[q] - (float)hi) * H3_SCALE);
-            const int off = ((n >> 3) * 48 + r) * 8 + (n & 7);
-            th[off] = hi;
-            th[192 * 8 + off] = lo;
+            const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            const uint32_t nbr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+            const bool odd = n & 1;
+            const uint32_t word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
+            tw[(odd ? 48 * TP : 0) + r * TP + (n >> 1)] = word;
         }
         __syncthreads();
         for (int i = tid; i < 384; i += 256) {
             const int pl = i >= 192 ? 1 : 0, within = i - pl * 192;
-            a.out_planes[pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within] = Tile[i];
+            const int kq = within / 48, row = within - kq * 48;
+            const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * 48 * TP + row * TP + kq * 4);
+            a.out_planes[pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within] = t4;
         }
     }
     if constexpr (RES) {
@@ -358,6 +420,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         for (int q = 0; q < 6; ++q)
             if (sok[q]) a.out2[(size_t)grow[q] * a.ldo2 + gn] = r2[q];
     }
+    if (a.pf && (pfv[0][0] ^ pfv[0][1] ^ pfv[1][0] ^ pfv[1][1]) == 0x9e3779b9u && a.err_flag) a.err_flag[1] = 1;    // keeps the warm-up loads alive
 }
 
 }  // namespace cindm
