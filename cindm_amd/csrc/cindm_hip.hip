@@ -42,7 +42,7 @@ struct Param {
     bool set = false;
 };
 
-struct Packed { size_t off = 0; int T = 0, CinP = 0, Npad = 0, N = 0, KC = 32; size_t bias_off = 0; bool has_bias = false; bool h3 = false; };
+struct Packed { size_t off = 0; size_t sz = 0; int T = 0, CinP = 0, Npad = 0, N = 0, KC = 32; size_t bias_off = 0; bool has_bias = false; bool h3 = false; };
 
 struct RtbDesc { std::string p; int cin, cout; int tb_off; };
 
@@ -73,6 +73,8 @@ struct cindm_unet1d {
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
+    struct WReg { size_t off[2]; unsigned bytes[2]; unsigned stride[2]; };      // byte offsets into blob
+    std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
     bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
@@ -290,7 +292,7 @@ static void pack_weight_h3(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
     Packed pk; pk.T = K; pk.CinP = C0p + C1p; pk.Npad = ceil_to(Co, TN); pk.N = Co; pk.KC = KC; pk.h3 = true;
     const int nch = pk.CinP / KC;
     const size_t halfs = (size_t)(pk.Npad / TN) * nch * (K * 4) * 256 * 8;
-    pk.off = bb.alloc(halfs / 2);
+    pk.sz = halfs / 2; pk.off = bb.alloc(pk.sz);
     uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
     auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
     for (int nt = 0; nt < pk.Npad / TN; ++nt)
@@ -326,7 +328,7 @@ static void pack_weight_wide(cindm_unet1d* h, BlobBuilder& bb, const std::string
     if (Ci != 64 && Ci != 128) return;
     Packed pk; pk.T = 1; pk.CinP = Ci; pk.Npad = ceil_to(Co, 64); pk.N = Co; pk.KC = Ci;
     const int NQ = Ci / 16;
-    pk.off = bb.alloc((size_t)(pk.Npad / 64) * NQ * 256 * 4);
+    pk.sz = (size_t)(pk.Npad / 64) * NQ * 256 * 4; pk.off = bb.alloc(pk.sz);
     float* base = bb.data.data() + pk.off;
     for (int it = 0; it < pk.Npad / 64; ++it)
         for (int q = 0; q < NQ; ++q)
@@ -350,7 +352,7 @@ static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
     auto frag = [&](const Param& w, int Co, int Ci, const std::string& name) {
         Packed pk; pk.T = 1; pk.CinP = Ci; pk.Npad = Co; pk.N = Co; pk.KC = Ci;
         const int K16 = Ci / 16;
-        pk.off = bb.alloc((size_t)(Co / 16) * K16 * 256);
+        pk.sz = (size_t)(Co / 16) * K16 * 256; pk.off = bb.alloc(pk.sz);
         float* base = bb.data.data() + pk.off;
         for (int t = 0; t < Co / 16; ++t)
             for (int k = 0; k < K16; ++k)
@@ -364,7 +366,7 @@ static void pack_attn_site(cindm_unet1d* h, BlobBuilder& bb, const std::string& 
     auto frag_h3 = [&](const Param& w, int Co, int Ci, const std::string& name) {
         Packed pk; pk.T = 1; pk.CinP = Ci; pk.Npad = Co; pk.N = Co; pk.KC = Ci; pk.h3 = true;
         const int K32 = Ci / 32;
-        pk.off = bb.alloc((size_t)(Co / 16) * K32 * 2 * 64 * 4);
+        pk.sz = (size_t)(Co / 16) * K32 * 2 * 64 * 4; pk.off = bb.alloc(pk.sz);
         uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
         auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
         for (int t = 0; t < Co / 16; ++t)
@@ -408,7 +410,7 @@ static bool pack_level_frag(cindm_unet1d* h, BlobBuilder& bb, const std::string&
     const int Co = want_co < 0 ? 16 : Co_;
     const int KS = (Ci + 31) / 32;
     Packed pk; pk.T = K; pk.CinP = KS * 32; pk.Npad = Co; pk.N = Co_; pk.KC = 32; pk.h3 = true;
-    pk.off = bb.alloc((size_t)(Co / 16) * K * KS * 2 * 64 * 4);
+    pk.sz = (size_t)(Co / 16) * K * KS * 2 * 64 * 4; pk.off = bb.alloc(pk.sz);
     uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
     auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
     for (int t = 0; t < Co / 16; ++t)
@@ -475,7 +477,7 @@ static void pack_weight_h3_res(cindm_unet1d* h, BlobBuilder& bb, const std::stri
     Packed pk; pk.T = 1; pk.CinP = C0p + C1p; pk.Npad = ceil_to(Co, TN); pk.N = Co; pk.KC = KC; pk.h3 = true;
     const int nch = pk.CinP / KC;
     const size_t halfs = (size_t)(pk.Npad / TN) * nch * 4 * 256 * 8;
-    pk.off = bb.alloc(halfs / 2);
+    pk.sz = halfs / 2; pk.off = bb.alloc(pk.sz);
     uint16_t* base = reinterpret_cast<uint16_t*>(bb.data.data() + pk.off);
     auto bits = [](float v) { _Float16 hv = (_Float16)v; uint16_t u; std::memcpy(&u, &hv, 2); return u; };
     for (int nt = 0; nt < pk.Npad / TN; ++nt)
@@ -520,7 +522,7 @@ static void pack_weight(cindm_unet1d* h, BlobBuilder& bb, const std::string& pre
     // value a lane feeds to v_mfma_f32_16x16x4_f32 as B[k = lane>>4][j = lane&15] of k-step (tap, cs), column block
     // nb.  Every float4 load of a wave is 1 KiB contiguous.
     const int nch = pk.CinP / KC, CPW = KC / 4, CS = CPW / 4, KS = K * CS;
-    pk.off = bb.alloc((size_t)K * pk.CinP * pk.Npad);
+    pk.sz = (size_t)K * pk.CinP * pk.Npad; pk.off = bb.alloc(pk.sz);
     float* base = bb.data.data() + pk.off;
     for (int nt = 0; nt < pk.Npad / TN; ++nt)
         for (int ch = 0; ch < nch; ++ch)
@@ -571,7 +573,49 @@ struct Emitter {
     struct ProfRec { int kind; hipEvent_t e0, e1; double flops; int gx, gy, nstage; };
     std::vector<ProfRec>* prof = nullptr;     // when set, every launch is bracketed by HIP events
     static constexpr int prof_reps = 8;
-    const char* pf_next = nullptr; size_t pf_next_bytes = 0;      // weights of the launch that follows the next block (L2 warm-up)
+    // L2 warm-up (kernels.h, Pf): every launch registers the blob ranges it streams; the table of a dry run at finalize
+    // (h->pf_table, one entry per launch in order) tells launch i what launch i + 1 will stream
+    int pf_idx = 0;
+    std::vector<cindm_unet1d::WReg>* pf_out = nullptr;
+    void pf_step(Pf& pf, const cindm_unet1d::WReg& mine) {
+        std::memset(&pf, 0, sizeof(pf));
+        if (pf_out) pf_out->push_back(mine);
+        const auto& tab = h->pf_table;
+        if (!dry && !pf_out && h->O("l2_prefetch") && !tab.empty()) {
+            const cindm_unet1d::WReg& nx = tab[(size_t)(pf_idx + 1) % tab.size()];
+            for (int k = 0; k < 2; ++k) {
+                pf.base[k] = reinterpret_cast<const char*>(h->blob) + nx.off[k];
+                pf.bytes[k] = nx.bytes[k]; pf.stride[k] = nx.stride[k];
+            }
+            pf.sink = h->epoch_dev + 2;
+        }
+        ++pf_idx;
+    }
+    // weights tiled by 32-column n-tile (conv_gemm_h3_kernel / dconv_kernel packings): tile nt is streamed by the
+    // workgroups with blockIdx.x = nt, i.e. on XCD nt % 8 when the grid's x extent is a multiple of 8
+    void pf_tiled(Pf& pf, const Packed& pk, int ntiles) {
+        cindm_unet1d::WReg r{};
+        const size_t tile = pk.sz * 4 / (size_t)(ntiles > 0 ? ntiles : 1);
+        if (ntiles % 8 == 0 && ntiles > 0) {
+            r.off[0] = pk.off * 4; r.bytes[0] = (unsigned)tile; r.stride[0] = (unsigned)tile;
+            if (ntiles >= 16) { r.off[1] = pk.off * 4 + 8 * tile; r.bytes[1] = (unsigned)tile; r.stride[1] = (unsigned)tile; }
+        } else {
+            r.off[0] = pk.off * 4; r.bytes[0] = (unsigned)std::min(pk.sz * 4, (size_t)2 << 20); r.stride[0] = 0;
+        }
+        pf_step(pf, r);
+    }
+    // weights every workgroup streams: the blob range [lo, hi) of the packed tensors `a` (region 0) and `b` (region 1)
+    void pf_all(Pf& pf, std::initializer_list<const Packed*> a0, std::initializer_list<const Packed*> b0) {
+        cindm_unet1d::WReg r{};
+        int k = 0;
+        for (const auto& lst : {a0, b0}) {
+            size_t lo = ~(size_t)0, hi = 0;
+            for (const Packed* q : lst) if (q) { lo = std::min(lo, q->off); hi = std::max(hi, q->off + q->sz); }
+            if (hi > lo) { r.off[k] = lo * 4; r.bytes[k] = (unsigned)std::min((hi - lo) * 4, (size_t)2 << 20); r.stride[k] = 0; }
+            ++k;
+        }
+        pf_step(pf, r);
+    }
     bool epoch_bumped = false;                // dconv pair exchanges: the per-forward epoch has been advanced
     std::vector<std::pair<size_t, size_t>>* xregions = nullptr;      // dry run: (offset, bytes) of the exchange regions
 
@@ -626,6 +670,23 @@ struct Emitter {
 
     void launch(int T, const GemmArgs& a) {
         ++launches;
+        if (h) {                                  // register this launch's weights, learn the next launch's (L2 warm-up)
+            cindm_unet1d::WReg r{};
+            const int ntiles = a.Npad / TN;
+            if (T > 0 && a.W && ntiles > 0) {
+                const size_t off = (size_t)(reinterpret_cast<const char*>(a.W) - reinterpret_cast<const char*>(h->blob));
+                const size_t tile = a.h3 ? (size_t)(a.CinP / 128) * T * 16384 : (size_t)T * a.CinP * TN * 4;
+                if (ntiles % 8 == 0) {
+                    r.off[0] = off; r.bytes[0] = (unsigned)tile; r.stride[0] = (unsigned)tile;
+                    if (ntiles >= 16) { r.off[1] = off + 8 * tile; r.bytes[1] = (unsigned)tile; r.stride[1] = (unsigned)tile; }
+                } else {
+                    r.off[0] = off; r.bytes[0] = (unsigned)std::min(tile * ntiles, (size_t)2 << 20);
+                }
+            }
+            pf_step(const_cast<GemmArgs&>(a).pf, r);
+        } else {
+            std::memset(&const_cast<GemmArgs&>(a).pf, 0, sizeof(Pf));
+        }
         if (dry) return;
         dim3 grid(a.Npad / TN, (unsigned)((a.Bp + a.spt - 1) / a.spt));
         {
@@ -794,11 +855,7 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
         d.W2 = reinterpret_cast<const uint4*>(E.W(rc)); d.bias2 = E.B(rc); d.out2 = r.p; d.ldo2 = r.ld;
     }
     pair_setup(d);
-    if (h->O("l2_prefetch")) {              // warm the L2s with launch B's weights (tile nt' of B runs on XCD nt' % 8)
-        d.pf = reinterpret_cast<const char*>(E.W(w1)); d.pf_regions = NT / 8; d.pf_tile_bytes = (unsigned)(w1.CinP / 128) * 20 * 256 * 16;
-        d.pf_stride = d.pf_tile_bytes;
-        if (!d.err_flag) d.err_flag = h->epoch_dev + 1;
-    }
+    E.pf_tiled(d.pf, w0, NT);
     dconv_launch(E, L, x0.C / 128, x1 ? x1->C / 128 : 0, !identity, d, 2.0 * Bp * L * cout * cin * (5.0 + (identity ? 0.0 : 1.0)));
     // B
     std::memset(&d, 0, sizeof(d));
@@ -810,11 +867,7 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
     if (identity) { d.res = x0.p; d.ldres = x0.ld; } else { d.res = r.p; d.ldres = r.ld; }
     d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
     pair_setup(d);
-    if (h->O("l2_prefetch") && E.pf_next && E.pf_next_bytes) {      // the next launch's weights (read by every workgroup of it)
-        d.pf = E.pf_next; d.pf_regions = 1; d.pf_stride = 0; d.pf_tile_bytes = (unsigned)E.pf_next_bytes;
-        if (!d.err_flag) d.err_flag = h->epoch_dev + 1;
-    }
-    E.pf_next = nullptr; E.pf_next_bytes = 0;
+    E.pf_tiled(d.pf, w1, NT);
     dconv_launch(E, L, cout / 128, 0, false, d, 2.0 * Bp * L * cout * (double)cout * 5.0);
     E.tap(p, out);
     return out;
@@ -920,8 +973,11 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
         // the whole site in one launch: one sample per workgroup (attn1d_site_kernel)
         Ten out = E.ten(L, C);
         ++E.launches;
+        Pf pfs;
+        E.pf_all(pfs, {&site->second, &h->packed.at(p + ".fn.fn.to_out#site")}, {});
         if (!E.dry) {
             AttnSiteArgs s;
+            s.pf = pfs;
             s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
             s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
             s.L = L; s.Bp = Bp;
@@ -965,6 +1021,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
         // shallow levels (C = 64 / 128): 64-row tiles, the LayerNorm-ed input tile staged once per workgroup and its
         // fragments kept in registers over a group of output tiles (the 2-D path's projection kernel on [rows, C])
         ++E.launches;
+        { Pf none; E.pf_all(none, {&wide->second}, {}); }
         if (!E.dry) {
             const int64_t rows = (int64_t)Bp * L;
             Conv2dArgs c2;
@@ -997,6 +1054,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
         E.launch(1, a);
     }
     ++E.launches;
+    { Pf none; E.pf_all(none, {}, {}); }
     if (!E.dry) {
         const size_t shm = 4 * (size_t)(3 * L * 32 + 32 * 33) * sizeof(float);
         static bool attr_set = false;
@@ -1054,9 +1112,15 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             const int L = cur.L;
             Ten h1 = E.ten(L, 64), h2 = E.ten(L, 64), sk = E.ten(L, 64), dn = E.ten(L / 2, 64);
             ++E.launches;
+            Pf pfl;
+            E.pf_all(pfl, {&h->packed.at("downs.0.0.blocks.0.block.0#lvl"), &h->packed.at("downs.0.0.blocks.1.block.0#lvl"),
+                           &h->packed.at("downs.0.1.blocks.0.block.0#lvl"), &h->packed.at("downs.0.1.blocks.1.block.0#lvl"),
+                           &h->packed.at("downs.0.0.residual_conv#lvl"), &h->packed.at("downs.0.3.conv#lvl")},
+                     {&h->packed.at("downs.0.2.fn.fn.to_qkv#site"), &h->packed.at("downs.0.2.fn.fn.to_out#site")});
             if (!E.dry) {
                 Level0Args l;
                 std::memset(&l, 0, sizeof(l));
+                l.pf = pfl;
                 l.x = cur.p; l.F = cur.C; l.h1 = h1.p; l.h2 = h2.p; l.skip = sk.p; l.down = dn.p;
                 const char* cv[4] = {"downs.0.0.blocks.0", "downs.0.0.blocks.1", "downs.0.1.blocks.0", "downs.0.1.blocks.1"};
                 for (int i = 0; i < 4; ++i) {
@@ -1088,9 +1152,15 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             const int L = cur.L;
             Ten h1 = E.ten(L, 128), h2 = E.ten(L, 128), sk = E.ten(L, 128), dn = E.ten(L / 2, 128);
             ++E.launches;
+            Pf pfl;
+            E.pf_all(pfl, {&h->packed.at("downs.1.0.blocks.0.block.0#lvl"), &h->packed.at("downs.1.0.blocks.1.block.0#lvl"),
+                           &h->packed.at("downs.1.1.blocks.0.block.0#lvl"), &h->packed.at("downs.1.1.blocks.1.block.0#lvl"),
+                           &h->packed.at("downs.1.0.residual_conv#lvl"), &h->packed.at("downs.1.3.conv#lvl")},
+                     {&h->packed.at("downs.1.2.fn.fn.to_qkv#site"), &h->packed.at("downs.1.2.fn.fn.to_out#site")});
             if (!E.dry) {
                 Level1Args l;
                 std::memset(&l, 0, sizeof(l));
+                l.pf = pfl;
                 l.x = cur.p; l.h1 = h1.p; l.h2 = h2.p; l.skip = sk.p; l.down = dn.p;
                 const char* cv[4] = {"downs.1.0.blocks.0", "downs.1.0.blocks.1", "downs.1.1.blocks.0", "downs.1.1.blocks.1"};
                 for (int i = 0; i < 4; ++i) {
@@ -1140,9 +1210,15 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             const int L = cur.L;
             Ten h1 = E.ten(L, 128), h2 = E.ten(L, 64), h3 = E.ten(L, 64), up = E.ten(2 * L, 64), ypre = E.ten(2 * L, 64);
             ++E.launches;
+            Pf pfl;
+            E.pf_all(pfl, {&h->packed.at(p + ".0.blocks.0.block.0#lvl"), &h->packed.at(p + ".0.blocks.1.block.0#lvl"), &h->packed.at(p + ".0.residual_conv#lvl"),
+                           &h->packed.at(p + ".1.blocks.0.block.0#lvl"), &h->packed.at(p + ".1.blocks.1.block.0#lvl"), &h->packed.at(p + ".1.residual_conv#lvl"),
+                           &h->packed.at("final_conv.0.block.0#lvl"), &h->packed.at(p + ".3.conv#lvl"), &h->packed.at("final_conv.1#lvl")},
+                     {&h->packed.at(p + ".2.fn.fn.to_qkv#site"), &h->packed.at(p + ".2.fn.fn.to_out#site")});
             if (!E.dry) {
                 UpsLastArgs l;
                 std::memset(&l, 0, sizeof(l));
+                l.pf = pfl;
                 l.x = cur.p; l.skip = skip.p; l.h1 = h1.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p; l.ypre = ypre.p; l.eps = eps; l.F = d.transition_dim;
                 const std::string cv[5] = {p + ".0.blocks.0", p + ".0.blocks.1", p + ".1.blocks.0", p + ".1.blocks.1", "final_conv.0"};
                 for (int i = 0; i < 5; ++i) {
@@ -1165,17 +1241,6 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre);
             return 0;
         }
-        if (h->O("ups_tail") && ind == nres - 3 && h->ups_tail_ok && h->packed.count(p + ".1.blocks.0.block.0#lvl")) {
-            // the level-tail kernel that follows streams these weights in every workgroup: have the block warm the L2s
-            size_t lo = ~(size_t)0, hi = 0;
-            for (const std::string& k : {p + ".1.blocks.0.block.0#lvl", p + ".1.blocks.1.block.0#lvl", p + ".1.residual_conv#lvl", p + ".3.conv#lvl"}) {
-                auto it = h->packed.find(k);
-                if (it == h->packed.end()) continue;
-                const Packed& pk = it->second;
-                lo = std::min(lo, pk.off); hi = std::max(hi, pk.off + (size_t)(pk.Npad / 16) * pk.T * (pk.CinP / 32) * 2 * 64 * 4);
-            }
-            if (hi > lo && hi <= h->blob_floats) { E.pf_next = reinterpret_cast<const char*>(h->blob + lo); E.pf_next_bytes = std::min((hi - lo) * 4, (size_t)2 << 20); }
-        }
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
         const int upt = h->O("ups_tail");
         if (upt && ind == nres - 3 && h->ups_tail_ok && att && cur.L <= 8 && cur.C == 256 && cur.ld == 256 && ci == 128 &&
@@ -1184,9 +1249,14 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             const int L = cur.L;
             Ten h2 = E.ten(L, 128), h3 = E.ten(L, 128), up = E.ten(2 * L, 128);
             ++E.launches;
+            Pf pfl;
+            E.pf_all(pfl, {&h->packed.at(p + ".1.blocks.0.block.0#lvl"), &h->packed.at(p + ".1.blocks.1.block.0#lvl"),
+                           &h->packed.at(p + ".1.residual_conv#lvl"), &h->packed.at(p + ".3.conv#lvl")},
+                     {&h->packed.at(p + ".2.fn.fn.to_qkv#site"), &h->packed.at(p + ".2.fn.fn.to_out#site")});
             if (!E.dry) {
                 UpsTailArgs l;
                 std::memset(&l, 0, sizeof(l));
+                l.pf = pfl;
                 l.x = cur.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p;
                 const std::string cv[2] = {p + ".1.blocks.0", p + ".1.blocks.1"};
                 for (int i = 0; i < 2; ++i) {
@@ -1239,6 +1309,7 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     REQUIRE(h, "null handle");
     hipStream_t stream = (hipStream_t)stream_;
     for (auto& p : h->params) if (!p.set) return fail("missing key in state_dict: " + p.name);
+    h->pf_table.clear();                   // (offsets into the blob that is rebuilt below)
     const auto& d = h->d;
     const int T = d.timesteps, dim = d.dim;
     if (h->sinus.empty()) {
@@ -1333,10 +1404,14 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     if (E.err != hipSuccess) return fail(std::string("finalize launch: ") + hipGetErrorString(E.err));
     HIPCHK(hipStreamSynchronize(stream));
     (void)hipFree(sin_d); (void)hipFree(y1); (void)hipFree(temb);
-    // count launches of one forward
+    // count launches of one forward; collect what each of them streams (L2 warm-up table)
+    h->pf_table.clear();
+    std::vector<cindm_unet1d::WReg> regs;
     Emitter D{h, nullptr, true, nullptr, 0, 1, nullptr, 0};
+    D.pf_out = &regs;
     emit_forward(D, nullptr, nullptr);
     h->launches = D.launches;
+    h->pf_table = regs;
     h->finalized = true;
     return 0;
 }

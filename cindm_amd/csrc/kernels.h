@@ -68,6 +68,36 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
     return v;
 }
 
+// L2 warm-up of the NEXT launch's weights.  Measured (profiles/r02_*): a launch whose weights come from the Infinity
+// Cache instead of its XCD's L2 streams them at 74 instead of 117 GB/s per CU, 65 us per reverse step in total; a side
+// stream cannot do the warm-up (cross-stream graph edges cost more than they save).  So every launch touches, one dword
+// per 128-byte line, the weights the launch AFTER it will stream: up to two regions, region k of XCD x = base[k] +
+// x * stride[k] (tiled weights: the n-tiles an XCD will own; stride 0: weights every workgroup reads).  Block b runs on
+// XCD b % 8 (observed dispatch rule; a wrong guess only loses the benefit).  The loaded dwords are parked in registers
+// and "used" at the very end of the kernel, so the loads cost no wait.
+struct Pf { const char* base[2]; unsigned bytes[2]; unsigned stride[2]; int* sink; };
+struct PfRegs { unsigned v[2][2]; };
+__device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, xcd = lin & 7, rank = lin >> 3;
+    const int nshare = (int)((gridDim.x * gridDim.y * gridDim.z + 7) >> 3);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int lines = (int)(p.bytes[k] >> 7);
+        const int per = (lines + nshare - 1) / nshare;
+        const char* base = p.base[k] + (size_t)xcd * p.stride[k];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int li = (int)threadIdx.x + (int)blockDim.x * i;
+            const int line = rank * per + li;
+            r.v[k][i] = 0u;
+            if (li < per && line < lines) r.v[k][i] = *reinterpret_cast<const unsigned*>(base + ((size_t)line << 7));
+        }
+    }
+}
+__device__ __forceinline__ void l2_prefetch_done(const Pf& p, const PfRegs& r) {
+    if (p.sink && (r.v[0][0] ^ r.v[0][1] ^ r.v[1][0] ^ r.v[1][1]) == 0x9e3779b9u) p.sink[0] = 1;    // keeps the loads alive
+}
+
 constexpr int TM = 48;        // tile rows
 constexpr int TN = 32;        // tile cols
 constexpr int MAXR = 96;      // max input rows per tile (stride-2 conv: 2 * 48)
@@ -115,6 +145,7 @@ struct GemmArgs {
     // second GEMM riding on the centre tap of a k=5 convolution (the block's 1x1 residual_conv reads the same staged
     // rows): out2 = W2 . x + bias2; W2 packed as split fp16 [n-tile][stage][q = nb*2 + plane][thread][8 halfs]
     const float* W2; const float* bias2; float* out2; int ldo2;
+    Pf pf;                                               // (registered by the host; these kernels issue no warm-up: measured +1 us per launch)
 };
 
 __device__ __forceinline__ float mish_f(float x) {
@@ -933,6 +964,7 @@ struct AttnSiteArgs {
                            // every per-sample reduction (hence every bit of the result) is independent of the slot
     int Bp;                // samples in the batch
     int dbg;               // timing ablations (wrong results): 1 no qkv loop, 2 no projection, 3 no core
+    Pf pf;                 // L2 warm-up for the next launch
 };
 
 // Core of a site for the head of this wave, per sample s of the workgroup: q *= 32^-1/2 ; k = softmax over the sample's
@@ -1221,6 +1253,8 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
                 wr[p][s][pl] = (p < K32) ? Wq4[(((size_t)tile[s] * K32 + p) * 2 + pl) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
 
     // ---- LayerNorm (as in attn1d_site_kernel), result split into the two fp16 planes ----
     {
@@ -1403,6 +1437,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             }
         }
     }
+    l2_prefetch_done(a.pf, pfr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1425,6 +1460,7 @@ struct Level0Args {
     const float* Wd; const float* bd;      // Downsample1d (k = 3, stride 2, pad 1)
     const int* t_ptr; int t_imm;
     int L;
+    Pf pf;                                 // L2 warm-up for the next launch
 };
 
 // one 16-channel x (NT*16)-position tile of a k-tap convolution: A = this wave's weight fragments [tap][k32][plane],
@@ -1526,6 +1562,8 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     const int L = a.L, b = blockIdx.x;
     const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
     const int c0 = w * 16;                                               // this wave's channels
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
     const int cl = c0 + lq * 4;                                          // this lane's four channels
     // ---- stage x (zero halo, zero pad channels / positions); clear the halos of the activation planes ----
     {
@@ -1713,6 +1751,7 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
         d[0][0] += bd.x; d[0][1] += bd.y; d[0][2] += bd.z; d[0][3] += bd.w;
         lvl_store<1>(d, a.down + (size_t)b * (L / 2) * C, c0, L / 2, lane);
     }
+    l2_prefetch_done(a.pf, pfr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1731,6 +1770,7 @@ struct Level1Args {
     const int* t_ptr; int t_imm;
     int L, Bp;
     int dbg;                               // timing ablation: return after phase dbg (wrong results)
+    Pf pf;                                 // L2 warm-up for the next launch
 };
 
 // MT x NT tiles of a k-tap convolution.  The weight fragments stream through a register ring of RING taps that the
@@ -1843,6 +1883,8 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     LvlRing<2, 2> ring_r;                                                // residual_conv fragments (one tap)
     lvlm_prefetch<2, 5, 2, 4>(ring, wbase(a.Wc[0], 5, 2), lane);
     lvlm_prefetch<2, 1, 2, 2>(ring_r, wbase(a.Wr, 1, 2), lane);
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
     if (tid < C) {
         const float* src[17] = {a.bc[0], a.bc[1], a.bc[2], a.bc[3], a.gam[0], a.gam[1], a.gam[2], a.gam[3], a.bet[0], a.bet[1], a.bet[2], a.bet[3],
                                 a.tb0 + (size_t)t_now * a.tb_ld, a.tb1 + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bd};
@@ -2078,6 +2120,7 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
         add4(d, 16);
         store(d, a.down, L / 2);
     }
+    l2_prefetch_done(a.pf, pfr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2097,6 +2140,7 @@ struct UpsLastArgs {
     const float* Wf; const float* bf;                    // final 1x1, one 16-channel tile (rows >= F are zero)
     const int* t_ptr; int t_imm;
     int L;
+    Pf pf;                                               // L2 warm-up for the next launch (the next step's first kernel)
 };
 
 __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
@@ -2123,6 +2167,8 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     auto wtile = [&](const float* W, int tile, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)tile * taps * ks * 2 * 64; };
     lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), lane);
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), lane);
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
     if (tid < CB) {
         const float* src[8] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb0 + (size_t)t_now * a.tb_ld, a.br0};
 #pragma unroll
@@ -2340,6 +2386,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
                     make_float4(e[0][nt][0] + bf.x, e[0][nt][1] + bf.y, e[0][nt][2] + bf.z, e[0][nt][3] + bf.w);
         }
     }
+    l2_prefetch_done(a.pf, pfr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2358,6 +2405,7 @@ struct UpsTailArgs {
     const float* Wu; const float* bu;
     const int* t_ptr; int t_imm;
     int L;
+    Pf pf;                                 // L2 warm-up for the next launch
 };
 
 __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
@@ -2379,6 +2427,8 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     LvlRing<1, 8> ring, ring_r;
     lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), lane);
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), lane);
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
     if (tid < C) {
         const float* src[10] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bu};
 #pragma unroll
@@ -2566,6 +2616,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
         add4(u[0], pv4(9, 0)); add4(u[1], pv4(9, 1));
         store(u, a.up, L2);
     }
+    l2_prefetch_done(a.pf, pfr);
 }
 
 // ---------------------------------------------------------------------------------------------

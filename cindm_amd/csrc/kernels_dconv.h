@@ -45,9 +45,7 @@ struct DconvArgs {
     uint4* out_planes; size_t out_pstride;      // planes output (tiled) or null
     const uint4* W2; const float* bias2; float* out2; int ldo2;     // riding 1x1 residual_conv: out2 = W2 . x + bias2
     unsigned long long* xchg; const int* epoch; int* err_flag;     // gw == 64: pair exchange of GroupNorm halves
-    // L2 warm-up for the NEXT launch: its weight tiles (pf_regions of pf_tile_bytes each, tile index = this
-    // workgroup's XCD + 8 k) are touched one dword per 128-byte line while this launch runs; null = none
-    const char* pf; int pf_regions; unsigned pf_tile_bytes; unsigned pf_stride;    // region k of XCD x: pf + (x + 8 k) * pf_stride
+    Pf pf;                                      // L2 warm-up for the next launch (kernels.h)
     int dbg;                                    // timing ablations (wrong results): 1 return at entry, 2 after staging,
                                                 // 3 no K loop, 4 no epilogue, 5 no pair exchange, 6 return after the cross-wave reduce, 7 before the stores, 8 no planes store
 };
@@ -257,34 +255,15 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         }
     };
     if (a.dbg == 2) { if (Img[0][tid].x == 0x12345u) a.out2[0] = 1.f; return; }
-    // L2 warm-up of the next launch's weights: block b runs on XCD b % 8 (observed rule; a wrong guess only loses the
-    // benefit), the workgroups of an XCD share its regions line by line; the loaded dwords are parked until the end
-    unsigned pfv[2][2] = {{0u, 0u}, {0u, 0u}};
-    auto prefetch = [&]() {
-        if (!a.pf) return;
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, rank = lin >> 3;
-        const int nshare = (gridDim.x * gridDim.y + 7) >> 3;
-        const int lines = (int)(a.pf_tile_bytes >> 7);
-        const int per = (lines + nshare - 1) / nshare;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k >= a.pf_regions) break;
-            const char* base = a.pf + (size_t)(xcd + 8 * k) * a.pf_stride;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int li = tid + 256 * i;
-                const int line = rank * per + li;
-                if (li < per && line < lines) pfv[k][i] = *reinterpret_cast<const unsigned*>(base + ((size_t)line << 7));
-            }
-        }
-    };
+    PfRegs pfr;
+    pfr.v[0][0] = pfr.v[0][1] = pfr.v[1][0] = pfr.v[1][1] = 0u;
     if (a.dbg != 3) {
         constexpr std::true_type PFY{};
         constexpr std::false_type PFN{};
         if constexpr (KPW1 == 0) {
 #pragma unroll 1
             for (int j = 0; j < KPW0 - 1; ++j) kstep(j, j + 1, PFY);
-            prefetch();
+            l2_prefetch(a.pf, pfr);
             kstep(KPW0 - 1, 0, PFN);
         } else {
 #pragma unroll 1
@@ -293,7 +272,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
             for (int j = 0; j < KPW1; ++j) store_raw(g1, j, raw1[j]);
 #pragma unroll 1
             for (int j = 0; j < KPW1 - 1; ++j) kstep(j, KPW0 + j + 1, PFY);
-            prefetch();
+            l2_prefetch(a.pf, pfr);
             kstep(KPW1 - 1, 0, PFN);
         }
     }
@@ -420,7 +399,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         for (int q = 0; q < 6; ++q)
             if (sok[q]) a.out2[(size_t)grow[q] * a.ldo2 + gn] = r2[q];
     }
-    if (a.pf && (pfv[0][0] ^ pfv[0][1] ^ pfv[1][0] ^ pfv[1][1]) == 0x9e3779b9u && a.err_flag) a.err_flag[1] = 1;    // keeps the warm-up loads alive
+    l2_prefetch_done(a.pf, pfr);
 }
 
 }  // namespace cindm
