@@ -162,6 +162,7 @@ static const OptDef kUnet1dOpts[] = {
     {"ups_tail", 1, "CINDM_UPS_TAIL"},
     {"h3_resample", 1, "CINDM_H3_RESAMPLE"},   // resampling convolutions on the split-fp16 kernel
     {"site_pack", 1, "CINDM_SITE_PACK"},   // several samples per attention-site workgroup
+    {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
@@ -626,6 +627,14 @@ struct Emitter {
         t.pst = tiles * (size_t)(t.C / 32) * 192;
         t.pl = reinterpret_cast<uint4*>(alloc(t.pst * 2 * 4));
     }
+    // the in-kernel exchanges of one forward are tagged with its epoch: advance it once, before the first of them
+    void need_epoch() {
+        if (epoch_bumped) return;
+        epoch_bumped = true;
+        if (!dry && h->epoch_prebumped) { h->epoch_prebumped = false; return; }    // done by the previous step's counter kernel
+        ++launches;
+        if (!dry) hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, stream, h->epoch_dev);
+    }
     unsigned long long* xchg(size_t granules) {
         const size_t off = ws_off;
         float* p = alloc(granules * 2);
@@ -829,15 +838,7 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
         if (gw != 64) return;
         d.xchg = E.xchg((size_t)tiles * NT * 32);
         d.epoch = h->epoch_dev; d.err_flag = h->epoch_dev + 1;
-        if (!E.epoch_bumped) {              // the exchanges of one forward are tagged with its epoch
-            E.epoch_bumped = true;
-            if (!E.dry && h->epoch_prebumped) {
-                h->epoch_prebumped = false; // advanced by the previous step's counter kernel (sample loops)
-            } else {
-                ++E.launches;
-                if (!E.dry) hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, E.stream, h->epoch_dev);
-            }
-        }
+        E.need_epoch();
     };
     auto src = [](DSrc& s, const Ten& t) { s.f32 = t.pl ? nullptr : t.p; s.planes = t.pl; s.pstride = t.pst; s.C = t.C; s.ld = t.ld; };
     const double cin = (double)x0.C + (x1 ? (double)x1->C : 0.0);
@@ -969,6 +970,37 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
     Ten qkv = E.ten(L, 384), att = E.ten(L, 128), out = E.ten(L, C);
     GemmArgs a;
     auto site = h->packed.find(p + ".fn.fn.to_qkv#site");
+    if (site != h->packed.end() && site->second.h3 && h->O("attn_head") && (C == 512 || (C == 256 && (L <= 4 || h->O("attn_head") > 1))) && L <= 16 && x.ld == C) {
+        // (at C = 256 with two samples per group the site kernel is faster: 10.6 vs 12.2 us, measured; attn_head = 2 forces this path)
+        // heads split over workgroups (attn1d_head_kernel): grid (4 heads, sample groups)
+        Ten out = E.ten(L, C);
+        const int slot = ceil_to(L, 4), S = 16 / slot, groups = (Bp + S - 1) / S;
+        unsigned long long* xg = E.xchg((size_t)groups * 2048);
+        E.need_epoch();
+        ++E.launches;
+        Pf pfs;
+        E.pf_all(pfs, {&site->second, &h->packed.at(p + ".fn.fn.to_out#site")}, {});
+        if (!E.dry) {
+            AttnHeadArgs s;
+            std::memset(&s, 0, sizeof(s));
+            s.pf = pfs;
+            s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
+            s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
+            s.L = L; s.S = S; s.slot = slot; s.Bp = Bp;
+            s.xchg = xg; s.epoch = h->epoch_dev; s.err_flag = h->epoch_dev + 1;
+            const dim3 grid(4, (unsigned)groups);
+            E.prof_begin(5, 2.0 * Bp * L * 1024.0 * C + (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));
+            for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
+                if (C == 256) hipLaunchKernelGGL(attn1d_head_kernel<256>, grid, dim3(256), 0, E.stream, s);
+                else hipLaunchKernelGGL(attn1d_head_kernel<512>, grid, dim3(256), 0, E.stream, s);
+            }
+            E.prof_end();
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess && E.err == hipSuccess) E.err = e;
+        }
+        E.tap(p, out);
+        return out;
+    }
     if (site != h->packed.end() && L <= 32) {
         // the whole site in one launch: one sample per workgroup (attn1d_site_kernel)
         Ten out = E.ten(L, C);

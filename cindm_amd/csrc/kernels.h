@@ -971,8 +971,8 @@ struct AttnSiteArgs {
 // positions ; ctx_s = k v^T ; att = ctx_s^T q.  qa: rows = channels, cols = positions; ka, va: rows = positions, cols =
 // channels (accumulator layouts of the 16x16 MFMAs); att: rows = e, cols = positions.
 template <int NT>
-__device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[NT][2], f32x4 (&va)[NT][2], f32x4 (&att)[2][NT],
-                                               int s_here, int nend, int slot, int L, int lq, int lr) {
+__device__ __forceinline__ void attn_site_core_range(f32x4 (&qa)[2][NT], f32x4 (&ka)[NT][2], f32x4 (&va)[NT][2], f32x4 (&att)[2][NT],
+                                                     int s_begin, int s_end, int nend, int slot, int L, int lq, int lr) {
     const float scale = 0.17677669529663687f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -992,7 +992,7 @@ __device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[N
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) att[et][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int s = 0; s < s_here; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         f32x4 ks[NT][2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -1040,6 +1040,12 @@ __device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[N
                         att[et][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ctx[dt][et][i], mine ? qa[dt][nt][i] : 0.f, att[et][nt], 0, 0, 0);
             }
     }
+}
+
+template <int NT>
+__device__ __forceinline__ void attn_site_core(f32x4 (&qa)[2][NT], f32x4 (&ka)[NT][2], f32x4 (&va)[NT][2], f32x4 (&att)[2][NT],
+                                               int s_here, int nend, int slot, int L, int lq, int lr) {
+    attn_site_core_range<NT>(qa, ka, va, att, 0, s_here, nend, slot, L, lq, lr);
 }
 
 template <int C, int NT, int PF>

@@ -402,4 +402,263 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     l2_prefetch_done(a.pf, pfr);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn1d_head_kernel<C>: Residual(PreNorm(LinearAttentionTemporal)) (model/diffusion_1d.py:75-81, :123-142, :272-291) of
+// the deep levels (C = 256 / 512, at most 16 positions per sample group) with the HEADS SPLIT OVER WORKGROUPS.
+// attn1d_site_h3_kernel runs a whole site in one workgroup per 4 samples: 64 workgroups, each streaming all of Wqkv and
+// Wo (1 MB at C = 512) through one CU's 117 GB/s -- 9 us of pure weight streaming on a quarter of the chip.  Here the
+// workgroup (sample group g, head h) streams only head h's q|k|v rows (196 KB) and, after the four heads of a group
+// have swapped their 32 x 16 attention tiles through {value, tag} granules (the pair-exchange protocol of
+// dconv_kernel, four-way), the output-projection rows [h C/4, (h+1) C/4) (64 KB): 256 workgroups, 4x fewer bytes each.
+//   LayerNorm (every head workgroup recomputes it: 16 x C values) -> y planes in LDS
+//   q|k|v of head h: K split over the four waves (k32 steps w, w+4, ..), partial accumulators summed through LDS in a
+//     fixed order, so every wave ends with the complete q, k, v tiles in the accumulator layouts of attn_site_core
+//   core: wave w handles sample w of the group (S = 16 / slot samples, 4-aligned slots as in the site kernel)
+//   exchange, then z = Wo[rows of h] att + bo + x
+struct AttnHeadArgs {
+    const float* x; int ldx;
+    float* out; int ldo;
+    const float* g;
+    const float* Wqkv; const float* Wo; const float* bo;      // the "#site" split-fp16 fragment packings
+    int L, S, slot, Bp;
+    unsigned long long* xchg; const int* epoch; int* err_flag;
+    Pf pf;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) {
+    constexpr int NP = 16, K32 = C / 32, KPW = K32 / 4, CT4 = C / 64;      // CT4: 16-channel output tiles per head workgroup
+    constexpr int YPB = 2 * C + 16;                      // bytes per position per plane
+    constexpr int APB = 2 * 128 + 16;
+    constexpr int CH = (C + 255) / 256;
+    constexpr int RW = NP / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NP * YPB];
+    __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NP * APB];
+    __shared__ __attribute__((aligned(16))) float Part[4][24][64];             // per-wave q|k|v partial accumulators
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int hd = blockIdx.x, grp = blockIdx.y;
+    const int L = a.L, slot = a.slot;
+    const int s_here = min(a.S, a.Bp - grp * a.S);
+    const int nend = s_here * slot;
+    const size_t row0 = (size_t)grp * a.S * L;
+    const unsigned tag = (unsigned)*a.epoch;
+    const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+    int tile[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) tile[s] = (s >> 1) * 8 + 2 * hd + (s & 1);
+    // this wave's k32 steps of the head's six tiles: everything in flight at once (KPW * 12 KiB per wave)
+    float4 wr[KPW][6][2];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                wr[j][s][pl] = Wq4[(((size_t)tile[s] * K32 + (4 * j + w)) * 2 + pl) * 64 + lane];
+    // output-projection fragments of this wave's tiles (rows hd * C/4 + ..): CT4 tiles per workgroup, CT4 / 4 per wave
+    constexpr int TPW = CT4 / 4;
+    static_assert(CT4 % 4 == 0, "output tiles split evenly over the waves");
+    const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
+    float4 wo[TPW][4][2];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                wo[t][k][pl] = Wo4[(((size_t)(hd * CT4 + w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane];
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
+
+    // ---- LayerNorm of the group's positions -> split-fp16 planes (as attn1d_site_h3_kernel) ----
+    {
+        constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;
+        constexpr int RPP = 64 / LPR;
+        constexpr int NPASS = (RW + RPP - 1) / RPP;
+        const int lrow = lane / LPR, lcol = lane % LPR;
+        float4 xr[NPASS][CH];
+        bool okr[NPASS];
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
+            okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
+#pragma unroll
+            for (int m = 0; m < CH; ++m)
+                xr[r][m] = okr[r] ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + 4 * (lcol + LPR * m)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 gv[CH];
+#pragma unroll
+        for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int n = w * RW + r * RPP + lrow;
+            float s1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
+            s1 = rowgroup_sum<LPR>(s1);
+            const float mean = s1 * (1.0f / C);
+            float s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                const float d0 = xr[r][m].x - mean, d1 = xr[r][m].y - mean, d2 = xr[r][m].z - mean, d3 = xr[r][m].w - mean;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            s2 = rowgroup_sum<LPR>(s2);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+            if (r * RPP + lrow < RW) {
+#pragma unroll
+                for (int m = 0; m < CH; ++m) {
+                    float4 y;
+                    y.x = (xr[r][m].x - mean) * rstd * gv[m].x; y.y = (xr[r][m].y - mean) * rstd * gv[m].y;
+                    y.z = (xr[r][m].z - mean) * rstd * gv[m].z; y.w = (xr[r][m].w - mean) * rstd * gv[m].w;
+                    if (!okr[r]) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    half4v hi, lo;
+                    hi[0] = (_Float16)y.x; hi[1] = (_Float16)y.y; hi[2] = (_Float16)y.z; hi[3] = (_Float16)y.w;
+                    lo[0] = (_Float16)((y.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((y.y - (float)hi[1]) * H3_SCALE);
+                    lo[2] = (_Float16)((y.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((y.w - (float)hi[3]) * H3_SCALE);
+                    const int off = n * YPB + 8 * (lcol + LPR * m);
+                    *reinterpret_cast<half4v*>(&Yp[0][off]) = hi;
+                    *reinterpret_cast<half4v*>(&Yp[1][off]) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave's K share of q, k, v of head hd ----
+    f32x4 qM[2], qL[2], kM[2], kL[2], vM[2], vL[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        qM[i] = f32x4{0.f, 0.f, 0.f, 0.f}; qL[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kM[i] = f32x4{0.f, 0.f, 0.f, 0.f}; kL[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vM[i] = f32x4{0.f, 0.f, 0.f, 0.f}; vL[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int k32 = 4 * j + w;
+        const int off = lr * YPB + k32 * 64 + lq * 16;
+        const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+        const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const half8 qh = __builtin_bit_cast(half8, wr[j][i][0]), ql = __builtin_bit_cast(half8, wr[j][i][1]);
+            const half8 kh = __builtin_bit_cast(half8, wr[j][2 + i][0]), kl = __builtin_bit_cast(half8, wr[j][2 + i][1]);
+            const half8 vh = __builtin_bit_cast(half8, wr[j][4 + i][0]), vl = __builtin_bit_cast(half8, wr[j][4 + i][1]);
+            qM[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, yh, qM[i], 0, 0, 0);
+            qL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, yl, qL[i], 0, 0, 0);
+            qL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql, yh, qL[i], 0, 0, 0);
+            kM[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, kh, kM[i], 0, 0, 0);
+            kL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, kl, kL[i], 0, 0, 0);
+            kL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, kh, kL[i], 0, 0, 0);
+            vM[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, vh, vM[i], 0, 0, 0);
+            vL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, vl, vL[i], 0, 0, 0);
+            vL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, vh, vL[i], 0, 0, 0);
+        }
+    }
+    // cross-wave sum in the fixed order (w0 + w1) + (w2 + w3): every wave ends with the complete tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Part[w][i * 4 + r][lane] = qM[i][r] + qL[i][r] * H3_INV;
+            Part[w][8 + i * 4 + r][lane] = kM[i][r] + kL[i][r] * H3_INV;
+            Part[w][16 + i * 4 + r][lane] = vM[i][r] + vL[i][r] * H3_INV;
+        }
+    __syncthreads();
+    f32x4 qa[2][1], ka[1][2], va[1][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            qa[i][0][r] = (Part[0][i * 4 + r][lane] + Part[1][i * 4 + r][lane]) + (Part[2][i * 4 + r][lane] + Part[3][i * 4 + r][lane]);
+            ka[0][i][r] = (Part[0][8 + i * 4 + r][lane] + Part[1][8 + i * 4 + r][lane]) + (Part[2][8 + i * 4 + r][lane] + Part[3][8 + i * 4 + r][lane]);
+            va[0][i][r] = (Part[0][16 + i * 4 + r][lane] + Part[1][16 + i * 4 + r][lane]) + (Part[2][16 + i * 4 + r][lane] + Part[3][16 + i * 4 + r][lane]);
+        }
+
+    // ---- core: wave w owns sample w of the group ----
+    f32x4 att[2][1];
+    attn_site_core_range<1>(qa, ka, va, att, w, min(w + 1, s_here), nend, slot, L, lq, lr);
+    // publish this wave's sample columns (positions [w * slot, (w + 1) * slot)) of the head's 32 x 16 tile, and keep a
+    // copy for the own projection.  Granule (hd, e, n) of group grp: value att[e][n], tag = epoch.
+    unsigned long long* gx = a.xchg + (size_t)grp * 4 * 512;
+    const bool mycol = (lr / slot) == w && w < a.S;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = et * 16 + lq * 4 + i;
+            if (mycol) {
+                const float val = att[et][0][i];
+                __hip_atomic_store(gx + hd * 512 + e * 16 + lr, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, val),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    // columns of samples beyond S (slot * S < 16) belong to nobody: publish zeros once (wave 0)
+    if (w == 0 && lr >= a.S * slot) {
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __hip_atomic_store(gx + hd * 512 + (et * 16 + lq * 4 + i) * 16 + lr, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // gather all four heads' tiles (own head included: one code path) -> att planes [position][128 channels]
+    {
+        unsigned long long gq[8];
+        int spins = 0;
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gq[j] = __hip_atomic_load(gx + tid + 256 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(gq[j] >> 32) == tag;
+            }
+            if (__all(ok)) break;
+            if (++spins > (1 << 18)) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, h2 = idx >> 9, e = (idx >> 4) & 31, n = idx & 15;
+            const float val = __builtin_bit_cast(float, (unsigned)gq[j]);
+            const _Float16 hi = (_Float16)val;
+            const _Float16 lo = (_Float16)((val - (float)hi) * H3_SCALE);
+            const int off = n * APB + 2 * (h2 * 32 + e);
+            *reinterpret_cast<_Float16*>(&Ap[0][off]) = hi;
+            *reinterpret_cast<_Float16*>(&Ap[1][off]) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- out rows [hd * C/4, (hd + 1) * C/4): z = Wo att + bo + x ----
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int ct = hd * CT4 + w * TPW + t;
+        f32x4 zM = f32x4{0.f, 0.f, 0.f, 0.f}, zL = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half8 wh = __builtin_bit_cast(half8, wo[t][k][0]), wl = __builtin_bit_cast(half8, wo[t][k][1]);
+            const int off = lr * APB + k * 64 + lq * 16;
+            const half8 ah = *reinterpret_cast<const half8*>(&Ap[0][off]);
+            const half8 al = *reinterpret_cast<const half8*>(&Ap[1][off]);
+            zM = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, zM, 0, 0, 0);
+            zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, zL, 0, 0, 0);
+            zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, zL, 0, 0, 0);
+        }
+        const int c = ct * 16 + lq * 4;
+        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+        const f32x4 z = zM + zL * H3_INV;
+        const int n = lr, sn = n / slot, pn = n - sn * slot;
+        if (n < nend && pn < L) {
+            const size_t row = row0 + sn * L + pn;
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+            float4 o;
+            o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
+            *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
+        }
+    }
+    l2_prefetch_done(a.pf, pfr);
+}
+
 }  // namespace cindm
