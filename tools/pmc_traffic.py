@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --output-format csv), as
 MI355X_MICROARCH.md's HBM section prescribes: the counters are in KiB per dispatch; on gfx950 FETCH_SIZE reports half
 of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is (uncalibrated per the guide).
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json"""
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [steps] > profiles/r02_pmc_traffic.json"""
 import csv
 import glob
 import json
@@ -31,7 +31,9 @@ def main():
         wr = wtot * 1024 / wn if wn else 0.0
         out[k] = {"launches": n, "fetch_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
-    json.dump({"note": "FETCH_SIZE (KiB) x2 (gfx950: reports half of wide coalesced reads) + WRITE_SIZE (KiB), mean per launch; "
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # reverse steps the traced command ran (incl. warm-up)
+    per_step = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in out.values()) / steps) if steps else None
+    json.dump({"bytes_per_step": per_step, "steps_traced": steps, "note": "FETCH_SIZE (KiB) x2 (gfx950: reports half of wide coalesced reads) + WRITE_SIZE (KiB), mean per launch; "
                        "Infinity-Cache hits are included in these memory-side counters", "kernels": out}, sys.stdout, indent=1)
 
 
