@@ -64,6 +64,7 @@ SIGNATURES = {
     "cindm_unet1d_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "cindm_unet1d_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "cindm_unet2d_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "cindm_unet2d_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "cindm_unet1d_create": (C.c_int, [C.POINTER(UnetDesc), C.POINTER(_vp)]),
     "cindm_unet1d_destroy": (None, [_vp]),
     "cindm_unet1d_num_params": (C.c_int, [_vp]),

@@ -78,6 +78,7 @@ struct cindm_unet1d {
     std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
+    bool force_f32 = false;                // calibration forward overflowed on the split-fp16 kernels: fp32 MFMA kernels in use
     bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
     // kernel-path options (cindm_unet1d_set_option; defaults = the fast path, overridable by CINDM_* at create)
     std::map<std::string, int> opt;
@@ -168,6 +169,7 @@ static const OptDef kUnet1dOpts[] = {
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
+    {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
     {"dbg", 0, "CINDM_DBG"}, {"dbg3", 0, "CINDM_DBG3"}, {"dbg4", 0, "CINDM_DBG4"},   // timing ablations (wrong results)
 };
 static void unet1d_default_options(cindm_unet1d* h) {
@@ -1348,7 +1350,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
     return 0;
 }
 
-extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
+static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
     REQUIRE(h, "null handle");
     hipStream_t stream = (hipStream_t)stream_;
     for (auto& p : h->params) if (!p.set) return fail("missing key in state_dict: " + p.name);
@@ -1369,7 +1371,22 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
             }
     }
     BlobBuilder bb;
-    h->use_h3 = !h->O("mfma_f32");
+    h->use_h3 = !h->O("mfma_f32") && !h->force_f32;
+    // Range rule of the split-fp16 products (hi = fp16(w), lo = fp16((w - hi) * 2^11)): every element of a weight
+    // tensor is represented to 2^-24 of the tensor's largest magnitude M as long as 2^-12 <= M <= 2^15 (below, hi and lo
+    // fall into fp16's subnormals together; above, hi overflows).  A checkpoint with a conv / projection weight outside
+    // that window runs on the exact fp32 MFMA kernels instead ("range_fallback" reads 1); "auto_range" = 0 disables
+    // the check.  Activations need no rule: they are GroupNorm / LayerNorm outputs of O(gamma), and an input beyond
+    // 65504 shows up as inf / nan in the output rather than as a silent loss.
+    h->opt["range_fallback"] = h->force_f32 ? 2 : 0;
+    if (h->use_h3 && h->O("auto_range")) {
+        for (const auto& p : h->params) {
+            if (p.shape.size() < 2 || p.name.find("time_mlp") != std::string::npos) continue;      // time path: fp32 kernels at finalize
+            float M = 0.f;
+            for (float v : p.host) M = std::max(M, std::fabs(v));
+            if (M > 32768.0f || (M < 1.0f / 4096.0f && M > 0.f) || !(M == M)) { h->use_h3 = false; h->opt["range_fallback"] = 1; break; }
+        }
+    }
     h->use_local_gn = h->O("local_gn") != 0;
     h->use_wide_qkv = h->O("wide_qkv") != 0;
     h->use_attn_site = h->O("attn_site") != 0;
@@ -1456,6 +1473,51 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     h->launches = D.launches;
     h->pf_table = regs;
     h->finalized = true;
+    return 0;
+}
+
+extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t rows);
+extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int32_t* t_dev,
+                                    float* eps, int64_t rows, void* ws, size_t ws_bytes, void* stream);
+
+// Repack + time tables (unet1d_finalize_pack), then -- on the split-fp16 kernels with "auto_range" -- ONE calibration
+// forward per timestep in {0, T/2, T-1} on a fixed unit-scale batch: an activation that leaves fp16's exponent range
+// (large un-normalised residual streams, huge projection weights) shows up as inf / nan in eps, and the handle is
+// repacked for the exact fp32 MFMA kernels ("range_fallback" reads 2; 1 = the weight-window rule fired).
+extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
+    REQUIRE(h, "null handle");
+    h->force_f32 = false;
+    if (unet1d_finalize_pack(h, stream_) != 0) return -1;
+    if (!h->use_h3 || !h->O("auto_range")) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t rows = 4;
+    const size_t n = (size_t)rows * h->d.horizon * h->d.transition_dim;
+    std::vector<float> hx(n), he(n);
+    uint32_t st = 0x2545F491u;
+    for (auto& v : hx) {                       // sum of four uniforms: unit-variance bell, |v| < 3.5
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) { st = st * 1664525u + 1013904223u; a += (float)(st >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+        v = a * 1.7320508f;
+    }
+    const size_t wsb = cindm_unet1d_workspace_bytes(h, rows);
+    float *dx = nullptr, *de = nullptr; void* ws = nullptr;
+    HIPCHK(hipMalloc((void**)&dx, n * 4)); HIPCHK(hipMalloc((void**)&de, n * 4)); HIPCHK(hipMalloc(&ws, wsb));
+    HIPCHK(hipMemcpyAsync(dx, hx.data(), n * 4, hipMemcpyHostToDevice, stream));
+    bool finite = true;
+    const int T = h->d.timesteps;
+    for (int t : {0, T / 2, T - 1}) {
+        if (cindm_unet1d_forward(h, dx, t, nullptr, de, rows, ws, wsb, stream_) != 0) { finite = false; break; }
+        HIPCHK(hipMemcpyAsync(he.data(), de, n * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (float v : he) if (!std::isfinite(v)) { finite = false; break; }
+        if (!finite) break;
+    }
+    (void)hipFree(dx); (void)hipFree(de); (void)hipFree(ws);
+    h->seen_ws = nullptr; h->seen_rows = 0; h->taps.clear();
+    if (!finite) {
+        h->force_f32 = true;
+        if (unet1d_finalize_pack(h, stream_) != 0) return -1;
+    }
     return 0;
 }
 

@@ -131,6 +131,14 @@ class Unet(nn.Module):
         self._ws = None
         return self
 
+    def get_option(self, key):
+        """Current value of a kernel-path option; ``get_option("range_fallback")`` is 1 after the weights were found outside
+        the split-fp16 window and the exact fp32 kernels were selected (evaluated when the weights are synchronised)."""
+        self.sync_weights()
+        v = C.c_int32()
+        _ffi.check(_ffi.lib().cindm_unet2d_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def workspace(self, images, device):
         if self._ws is None or self._ws_images < images or self._ws.device != device:
             nbytes = _ffi.lib().cindm_unet2d_workspace_bytes(self._h, images)

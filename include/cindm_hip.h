@@ -80,7 +80,9 @@ int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
 /* Kernel-path selection for this handle (before *_finalize; changing an option un-finalizes the handle).  Every
  * alternative path computes the same function (the parity suite runs all of them); defaults are the fast path.
  * Keys: "mfma_f32" (1 = exact fp32 MFMA kernels instead of the split-fp16 ones), "local_gn", "attn_site",
- * "wide_qkv", "level0", "level1", "ups_last", "ups_tail", "h3_resample", "site_pack", "auto_range",
+ * "wide_qkv", "level0", "level1", "ups_last", "ups_tail", "h3_resample", "site_pack", "dconv", "dconv_pair",
+ * "attn_head", "l2_prefetch", "auto_range" (1 = a checkpoint whose conv / projection weights leave the split-fp16 window
+ * 2^-12 <= max|w| <= 2^15 runs on the fp32 kernels; "range_fallback" then reads 1),
  * "dbg"/"dbg3"/"dbg4" (timing ablations, wrong results).  No reference counterpart (PyTorch picks its own kernels). */
 int  cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value);
 int  cindm_unet1d_get_option(const cindm_unet1d* h, const char* key, int32_t* value);
@@ -298,6 +300,7 @@ int  cindm_unet2d_set_sinusoid_table(cindm_unet2d* h, const float* table, int64_
  * :205-208) evaluated for every timestep into a device table. */
 /* Kernel-path selection, as cindm_unet1d_set_option.  Keys: "mfma_f32", "la_site", "auto_range", "dbg2"/"dbg3". */
 int  cindm_unet2d_set_option(cindm_unet2d* h, const char* key, int32_t value);
+int  cindm_unet2d_get_option(const cindm_unet2d* h, const char* key, int32_t* value);
 int  cindm_unet2d_finalize(cindm_unet2d* h, void* stream);
 int  cindm_unet2d_padded_channels(const cindm_unet2d* h);
 size_t cindm_unet2d_workspace_bytes(const cindm_unet2d* h, int64_t images);

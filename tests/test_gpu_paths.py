@@ -1,0 +1,178 @@
+"""GPU (MI355X): every selectable kernel path of the library, and the bench-size shapes, under the driver-run suite.
+
+1. Kernel paths.  libcindm_hip.so keeps alternative implementations of most layers (exact fp32-MFMA kernels, per-layer
+   launches instead of level kernels, three-launch attention, the conv_gemm_h3 path instead of dconv_kernel, ...),
+   selected per model handle with ``set_option`` (cindm_unet1d_set_option / cindm_unet2d_set_option).  Each option set
+   below runs the U-Net forward goldens, the per-block goldens and a 100-step free-running chain against the reference's
+   vectors, at the same tolerances as the default path.
+2. Branches the first fixture set did not reach (tests/golden/steps_1d_r2.npz, oracle/make_golden_r2.py):
+   objective pred_x0 / pred_v, eight bodies (28 pairs), initialization_mode 1 / 2.
+3. Bench-size shapes: config 4 at 128 designs per GPU (768 pair rows + 512 single rows) and config 5 at 64 designs x 2
+   boundaries -- rows against the oracle on a subset, bitwise independence of the partition, shared states."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cindm_amd
+import cindm_oracle as O
+from test_gpu_parity import TOL_CHAIN, TOL_FWD, TOL_STEP, _tape, build_unet, rel
+
+pytestmark = pytest.mark.gpu
+
+PATHS_1D = [
+    {"mfma_f32": 1},                      # every product on the exact fp32 MFMA kernels
+    {"local_gn": 0},                      # consumer-side GroupNorm (A / B / C launches), no fused levels
+    {"attn_site": 0},                     # three-launch attention (wide qkv, core, out projection)
+    {"attn_site": 0, "wide_qkv": 0},      # ... with the qkv projection on the K-split GEMM kernel
+    {"level0": 0},                        # no level kernels: per-layer launches at every level
+    {"level1": 2},                        # two samples per workgroup in level1_down_kernel
+    {"level1": 0}, {"ups_last": 0}, {"ups_tail": 0},
+    {"dconv": 0},                         # deep levels on conv_gemm_h3_kernel
+    {"dconv_pair": 0},                    # dconv only where GroupNorm groups are tile-local (C_out <= 256)
+    {"attn_head": 0},                     # deep attention sites on attn1d_site_h3_kernel
+    {"attn_head": 2},                     # ... all of them on attn1d_head_kernel
+    {"l2_prefetch": 0}, {"h3_resample": 0}, {"site_pack": 0},
+    {"dconv": 0, "level0": 0, "attn_head": 0},      # the round-1 per-layer path
+]
+IDS_1D = ["-".join(f"{k}{v}" for k, v in p.items()) for p in PATHS_1D]
+
+
+def build_with(device, opts, **kw):
+    m, sd = build_unet(device, **kw)
+    for k, v in opts.items():
+        m.set_option(k, v)
+    return m, sd
+
+
+@pytest.mark.parametrize("opts", PATHS_1D, ids=IDS_1D)
+def test_unet1d_paths_golden(gold_dir, device, opts):
+    g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
+    m, _ = build_with(device, opts)
+    x = torch.from_numpy(g["x"]).to(device)
+    for t in (0, 500, 999):
+        assert rel(m(x, torch.full((4,), t, device=device)), g[f"eps_t{t}"]) < TOL_FWD, (opts, t)
+    m(x[:2], torch.full((2,), 500, device=device))
+    for k in ("downs.0.1", "downs.0.3", "downs.1.0", "downs.2.1", "downs.3.2", "mid_block1", "mid_attn", "mid_block2", "ups.0.0",
+              "ups.0.3", "ups.1.1", "ups.2.2", "ups.2.3"):
+        assert rel(m.tap(k, 2), g["tap." + k]) < TOL_FWD, (opts, k)
+
+
+@pytest.mark.parametrize("opts", PATHS_1D, ids=IDS_1D)
+def test_unet1d_paths_chain_and_ragged(gold_dir, device, opts):
+    """100 free-running steps of config 1 against the reference's checkpoint at t = 900, and a ragged batch vs the oracle."""
+    g = np.load(os.path.join(gold_dir, "chains_1d.npz"))
+    m, sd = build_with(device, opts)
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    ts = list(g["cfg1.ckpt_t"])
+    part = d.sample(batch_size=4, n_composed=0, compose_n_bodies=2, noise=_tape(1234, (4, 24, 8), 1000), t_stop=900)
+    assert rel(part, g["cfg1.ckpt"][ts.index(900)]) < TOL_CHAIN, opts
+    x = torch.randn((19, 24, 8), generator=torch.Generator().manual_seed(5))
+    ref = O.unet1d_forward(sd, x, torch.full((19,), 611, dtype=torch.long))
+    assert rel(m(x.to(device), torch.full((19,), 611, device=device)), ref) < TOL_FWD, opts
+    assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
+
+
+@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}], ids=["mfma_f32", "la_site0"])
+def test_unet2d_paths_golden(gold_dir, device, opts):
+    from test_gpu_parity_2d import build_unet2d
+    g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
+    m, _ = build_unet2d(device)
+    for k, v in opts.items():
+        m.set_option(k, v)
+    x = torch.from_numpy(g["x"]).to(device)
+    for t in (0, 500, 999):
+        assert rel(m(x, torch.full((2,), t, device=device)), g[f"eps_t{t}"]) < TOL_FWD, (opts, t)
+
+
+# ------------------------------------------------------------------ branches of round 2's fixtures
+@pytest.fixture(scope="module")
+def unet8(device):
+    return build_unet(device)
+
+
+@pytest.mark.parametrize("obj", ["pred_x0", "pred_v"])
+def test_objective_steps_golden(gold_dir, device, unet8, obj):
+    """objective = pred_x0 / pred_v (model/diffusion_1d.py:1018-1027): x_{t-1} and x0 of single steps."""
+    g = np.load(os.path.join(gold_dir, "steps_1d_r2.npz"))
+    d = cindm_amd.GaussianDiffusion1D(unet8[0], image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000,
+                                      objective=obj).to(device)
+    kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+    kw3 = dict(compose_mode="mean-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2)
+    for tag, fn, kws, ts in ((f"{obj}.outside_mean", d.p_sample_compose_outside, kw, (999, 500, 1, 0)),
+                             (f"{obj}.inside_w3", d.p_sample_compose_inside, kw3, (500, 0))):
+        for t in ts:
+            x = torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device)
+            nz = torch.from_numpy(g[f"{tag}.t{t}.noise"]).to(device)
+            out, x0 = fn(x, None, t, noise=nz, **kws)
+            assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP, (tag, t)
+            assert rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (tag, t)
+
+
+@pytest.mark.parametrize("tag,ncomp", [("nb8", 0), ("nb8_w2", 1)])
+def test_eight_bodies_step_golden(gold_dir, device, unet8, tag, ncomp):
+    """compose_n_bodies = 8: 28 pair evaluations per window (scripts_paper/1D/cindm.sh:19-20; loop :977-990)."""
+    g = np.load(os.path.join(gold_dir, "steps_1d_r2.npz"))
+    d = cindm_amd.GaussianDiffusion1D(unet8[0], image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    kw8 = dict(compose_mode="mean-inside", n_composed=ncomp, compose_start_step=10, single_model_step=24, compose_n_bodies=8)
+    for t in (500, 0):
+        x = torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device)
+        nz = torch.from_numpy(g[f"{tag}.t{t}.noise"]).to(device)
+        out, x0 = d.p_sample_compose_inside(x, None, t, noise=nz, **kw8)
+        assert tuple(out.shape) == tuple(x.shape) and x.shape[-1] == 32
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP, (tag, t)
+        assert rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (tag, t)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_initialization_modes_chain_golden(gold_dir, device, unet8, mode):
+    """p_sample_loop's initialization_mode 1 (start from the image) / 2 (image + noise), :1672-1678: 1000-step chains."""
+    g = np.load(os.path.join(gold_dir, "steps_1d_r2.npz"))
+    d = cindm_amd.GaussianDiffusion1D(unet8[0], image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    img = torch.from_numpy(g["init.img"]).to(device)
+    out = d.sample(batch_size=1, cond=None, n_composed=0, compose_n_bodies=2, initialization_mode=mode, initialization_img=img,
+                   noise=_tape(1300 + mode, (1, 24, 8), 1000))
+    assert rel(out, g[f"init_mode{mode}.final"]) < TOL_CHAIN
+
+
+# ------------------------------------------------------------------ bench-size shapes
+def test_cfg4_at_128_designs(device, unet8):
+    """Config 4's per-GPU share: 128 four-body designs = 768 pair rows + 512 single-body rows per step.  (1) three steps
+    with explicit noise: designs 5, 40, 77, 127 against the oracle run on just those designs (rows are independent);
+    (2) the full 400-step chain: finite, deterministic, and bitwise equal to a 4-design run of designs 40..43."""
+    m8, sd8 = unet8
+    m4, sd4 = build_unet(device, F=4)
+    d = cindm_amd.GaussianDiffusion1D(m8, image_size=20, conditioned_steps=4, timesteps=1000, sampling_timesteps=1000).to(device)
+    d.model_unconditioned = m4
+    B, N = 128, 400
+    g = torch.Generator().manual_seed(404)
+    cond = torch.rand((B, 4, 16), generator=g)
+    tape = O.NoiseTape(torch.randn((B, 20, 16), generator=g), torch.randn((N, B, 20, 16), generator=g))
+    out = d.sample_compose_multibodies(cond.to(device), N, 0, 4, noise=cindm_amd.NoiseTape(tape.init, tape.step), t_stop=N - 3)
+    rows = [5, 40, 77, 127]
+    od = O.Diffusion1D(sd8, image_size=20, conditioned_steps=4, sd_uncond=sd4)
+    sub = O.NoiseTape(tape.init[rows], tape.step[:, rows])
+    ref = O.sample_compose_multibodies(od, cond[rows], N, sub, t_stop=N - 3)
+    assert rel(out[rows], ref) < TOL_STEP
+    a = d.sample_compose_multibodies(cond.to(device), N, 0, 4, seed=9)
+    b = d.sample_compose_multibodies(cond.to(device), N, 0, 4, seed=9)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all()) and tuple(a.shape) == (B, 20, 16)
+    part = d.sample_compose_multibodies(cond[40:44].to(device), N, 0, 4, seed=9, sample_offset=40)
+    assert torch.equal(a[40:44], part)
+    assert cindm_amd._ffi.lib().cindm_unet1d_status(m8._h, None) == 0
+
+
+def test_cfg5_at_64x2(device):
+    """Config 5 at the bench shape (64 designs x 2 boundaries = 128 images per step), 6 reverse steps: 4 designs of the 64
+    bitwise equal to a 4-design run, states shared across the boundary copies, boundary channels not, finite."""
+    from test_gpu_parity_2d import build_unet2d
+    m, _ = build_unet2d(device)
+    d = cindm_amd.GaussianDiffusion(m, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                    loss_type="l2").to(device)
+    full = d.sample(batch_size=64, num_boundaries=2, seed=21, t_stop=994)
+    part = d.sample(batch_size=4, num_boundaries=2, seed=21, sample_offset=30, t_stop=994)
+    assert tuple(full.shape) == (64, 2, 21, 64, 64) and bool(torch.isfinite(full).all())
+    assert torch.equal(full[30:34], part)
+    assert torch.equal(full[:, 0, :-3], full[:, 1, :-3])
+    assert not torch.equal(full[:, 0, -3:], full[:, 1, -3:])

@@ -108,6 +108,31 @@ def test_single_steps(gold_dir, sd8, tag):
         assert rel(out, g[f"{tag}.t{t}.out"]) < TOL and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL, (tag, t)
 
 
+R2_CASES = {
+    "pred_x0.outside_mean": ("pred_x0", "outside", dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2), (999, 500, 1, 0)),
+    "pred_x0.inside_w3": ("pred_x0", "inside", dict(compose_mode="mean-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2), (500, 0)),
+    "pred_v.outside_mean": ("pred_v", "outside", dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2), (999, 500, 1, 0)),
+    "pred_v.inside_w3": ("pred_v", "inside", dict(compose_mode="mean-inside", n_composed=2, compose_start_step=16, single_model_step=24, compose_n_bodies=2), (500, 0)),
+    "nb8": ("pred_noise", "inside", dict(compose_mode="mean-inside", n_composed=0, compose_start_step=10, single_model_step=24, compose_n_bodies=8), (500, 0)),
+    "nb8_w2": ("pred_noise", "inside", dict(compose_mode="mean-inside", n_composed=1, compose_start_step=10, single_model_step=24, compose_n_bodies=8), (0,)),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(R2_CASES))
+def test_single_steps_round2(gold_dir, sd8, tag):
+    """Objectives pred_x0 / pred_v (model/diffusion_1d.py:1018-1027) and eight bodies (28 pairs, :977-990); vectors
+    captured from the reference by oracle/make_golden_r2.py."""
+    g = np.load(os.path.join(gold_dir, "steps_1d_r2.npz"))
+    obj, kind, kw, ts = R2_CASES[tag]
+    d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0, objective=obj)
+    fn = O.p_sample_compose_inside if kind == "inside" else O.p_sample_compose_outside
+    for t in ts:
+        x = torch.from_numpy(g[f"{tag}.t{t}.x"])
+        nz = torch.from_numpy(g[f"{tag}.t{t}.noise"])
+        out, x0 = fn(d, x, None, t, nz, **kw)
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL, (tag, t)
+
+
 def test_guided_steps(gold_dir, sd8):
     g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
     d = O.Diffusion1D(sd8, image_size=24, conditioned_steps=0)
