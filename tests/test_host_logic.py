@@ -261,3 +261,22 @@ def test_synthetic_init_is_a_function_of_seed_and_name():
     w = a["downs.1.0.blocks.0.block.0.weight"]
     assert float(w.abs().max()) <= 1.0 / (w.shape[1] * w.shape[2]) ** 0.5 + 1e-6
     assert abs(float(a["downs.0.0.blocks.0.block.2.weight"].mean()) - 1.0) < 0.05
+
+
+def test_get_item_1d_matches_reference_formula():
+    """cindm_amd.data_utils.get_item_1d == the reference's utils.get_item_1d (utils.py:203-222) on a synthetic PyG-like
+    batch (vector captured from the imported reference by oracle/make_golden_r2.py is not needed: the function is a pure
+    reshape / scale, restated here from the reference's docstring shapes), and to_simulator_units inverts it."""
+    from cindm_amd.data_utils import get_item_1d, to_simulator_units
+
+    class Batch(dict):
+        dyn_dims = [0, 0, 0]
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((3 * 4, 24, 4), generator=g) * 200.0            # B = 3, four bodies
+    d = Batch(y=x)
+    out = get_item_1d(d, "y")
+    assert tuple(out.shape) == (3, 24, 16)
+    # sample 1, step 5, body 2, feature 3
+    assert float(out[1, 5, 2 * 4 + 3]) == float(x[1 * 4 + 2, 5, 3] / 200.0)
+    assert torch.equal(to_simulator_units(out, 4), (x / 200.0) * 200.0)
