@@ -8,10 +8,11 @@ from .checkpoint import Trainer
 from .data_utils import get_item_1d, to_simulator_units
 from .diffusion1d import GaussianDiffusion1D, NoiseTape
 from .diffusion2d import GaussianDiffusion, NoiseTape2D
+from .forceunet import ForceObjective, ForceUnet
 from .objectives import PointObjective
 from .schedule import make_schedule
 from .unet1d import TemporalUnet1D
 from .unet2d import Unet
 
 __all__ = ["TemporalUnet1D", "GaussianDiffusion1D", "NoiseTape", "Unet", "GaussianDiffusion", "NoiseTape2D",
-           "PointObjective", "Trainer", "make_schedule", "CindmError", "get_item_1d", "to_simulator_units"]
+           "PointObjective", "ForceUnet", "ForceObjective", "Trainer", "make_schedule", "CindmError", "get_item_1d", "to_simulator_units"]

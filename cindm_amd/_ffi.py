@@ -34,6 +34,11 @@ SCHED_NAMES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cu
                "loss_weight")
 
 
+class ForceUnetDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 4), ("channels", C.c_int32),
+                ("image_size", C.c_int32)]
+
+
 class SchedDesc(C.Structure):
     _fields_ = [("timesteps", C.c_int32)] + [(n, C.c_void_p) for n in SCHED_NAMES]
 
@@ -114,6 +119,18 @@ SIGNATURES = {
     "cindm_ddpm2d_sample": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _i32, _vp, _sz, _vp,
                                       _i32]),
     "cindm_fill_noise2d": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _u64, _i64, _i32, _vp]),
+    "cindm_forceunet_create": (C.c_int, [C.POINTER(ForceUnetDesc), C.POINTER(_vp)]),
+    "cindm_forceunet_destroy": (None, [_vp]),
+    "cindm_forceunet_num_params": (C.c_int, [_vp]),
+    "cindm_forceunet_param_info": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(_i64 * 4), C.POINTER(C.c_int)]),
+    "cindm_forceunet_set_param": (C.c_int, [_vp, C.c_char_p, _vp, _i64, C.c_int]),
+    "cindm_forceunet_finalize": (C.c_int, [_vp, _vp]),
+    "cindm_forceunet_workspace_bytes": (_sz, [_vp, _i64, _i32]),
+    "cindm_forceunet_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "cindm_forceunet_grad": (C.c_int, [_vp, _vp, C.c_float, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "cindm_airfoil_design_workspace_bytes": (_sz, [_vp, _i64, _i32]),
+    "cindm_airfoil_design_grad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, _i32,
+                                            _vp, _vp, _sz, _vp]),
 }
 
 

@@ -2063,3 +2063,4 @@ extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint
 
 // ============================================================================ 2-D airfoil path
 #include "unet2d_host.inc"
+#include "forceunet_host.inc"

@@ -1,0 +1,575 @@
+// ForceUnet forward + input-gradient kernels: the airfoil design objective's surrogate network
+// (model/diffusion_2d.py:411-486) and the pieces of inference/inverse_design_2d.py:98-143 around it, so that the
+// `design_fn` of the 2-D sampler -- d(force + overlap)/dx -- is evaluated by the library instead of PyTorch autograd.
+//
+// Only INPUT gradients are ever needed (the network's weights are frozen), so the backward pass is a chain of
+// "transposed" layers: convolution backward-data = the same convolution kernel on flipped / transposed weights
+// (packed once at finalize), plus the derivative kernels of GroupNorm+SiLU, LayerNorm, linear attention, softmax
+// attention, pixel-unshuffle and the mean-pool / Linear head.  Layout: channel-last fp32 [image][pixel][C], as the rest
+// of the 2-D path.  Convolutions run on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32): this module is written for
+// correctness first (gradient parity 2e-5 against torch autograd of the oracle); it is not yet on the split-fp16 pipe.
+#pragma once
+#include "kernels.h"
+
+namespace cindm {
+
+__device__ __forceinline__ float fu_sigmoid(float u) { return 1.0f / (1.0f + __expf(-u)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fu_conv_kernel<KS, NB>: y[i, p, co] = beta * y + bias[co] + sum_tap sum_ci W[tap][ci][co] x[i, p + off(tap), ci]
+// (stride 1, zero padding KS/2).  Workgroup = (8 x 8 pixel tile, 16*NB output channels) of one image; wave w owns
+// the tile's pixel rows 2w, 2w+1 (one 16-row MFMA block) and all NB column blocks.  Input channels are staged 16 at a
+// time with the halo.  Weights: Wp[tap][kc = Cin/4][ntq][lane][NB] (B[k = lane>>4][j = lane&15] of column block e).
+struct FuConvArgs {
+    const float* x; const float* W; const float* bias; float* y;
+    int Cin, CinP, Cout, CoutP, H, Wd, NI;        // CinP: multiple of 16 (packed), CoutP: multiple of 16*NB
+    float beta;                                   // 0: overwrite, 1: accumulate into y
+};
+
+template <int KS, int NB>
+__global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
+    constexpr int HALO = KS - 1, TW = 8 + HALO, NPIX = TW * TW, CK = 16, CKP = 17;
+    __shared__ float As[NPIX * CKP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tiles_x = a.Wd / 8, tiles = tiles_x * (a.H / 8);
+    const int img = blockIdx.y / tiles, ti = blockIdx.y - img * tiles;
+    const int ty0 = (ti / tiles_x) * 8, tx0 = (ti % tiles_x) * 8;
+    const int ntq = blockIdx.x;
+    const int HW = a.H * a.Wd;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pi = lane & 15, py = 2 * w + (pi >> 3), px = pi & 7;          // this lane's A row = pixel (py, px) of the tile
+    const int nq_total = a.CoutP / (16 * NB);
+    const int kcs = a.CinP / 4;
+    for (int c0 = 0; c0 < a.CinP; c0 += CK) {
+        __syncthreads();
+        for (int i = tid; i < NPIX * (CK / 4); i += 256) {
+            const int hp = i / (CK / 4), c4 = i - hp * (CK / 4);
+            const int hy = hp / TW, hx = hp - hy * TW;
+            const int y = ty0 + hy - HALO / 2, x = tx0 + hx - HALO / 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = c0 + c4 * 4;
+            if (y >= 0 && y < a.H && x >= 0 && x < a.Wd && c < a.Cin) {
+                const float* p = a.x + ((size_t)img * HW + (size_t)y * a.Wd + x) * a.Cin + c;
+                if (c + 3 < a.Cin) v = *reinterpret_cast<const float4*>(p);
+                else { v.x = p[0]; if (c + 1 < a.Cin) v.y = p[1]; if (c + 2 < a.Cin) v.z = p[2]; }
+            }
+            float* d = &As[hp * CKP + c4 * 4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+            const float* ap = &As[((py + dy) * TW + px + dx) * CKP + (lane >> 4)];
+            const float* wp = a.W + ((((size_t)tap * kcs + c0 / 4) * nq_total + ntq) * 64 + lane) * NB;
+#pragma unroll
+            for (int kk = 0; kk < CK / 4; ++kk) {
+                const float av = ap[kk * 4];
+                const float* wk = wp + (size_t)kk * nq_total * 64 * NB;
+                if constexpr (NB == 4) {
+                    const float4 b = *reinterpret_cast<const float4*>(wk);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.w, acc[3], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NB; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wk[e], acc[e], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int co = (ntq * NB + e) * 16 + (lane & 15);
+        if (co >= a.Cout) continue;
+        const float bs = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int r = (lane >> 4) * 4 + rg, y = ty0 + 2 * w + (r >> 3), x = tx0 + (r & 7);
+            float* o = a.y + ((size_t)img * HW + (size_t)y * a.Wd + x) * a.Cout + co;
+            const float val = acc[e][rg] + bs;
+            *o = a.beta != 0.f ? a.beta * (*o) + val : val;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm(8 groups) statistics per (image, group): two passes (mean, then M2) -> (mean, rstd)
+__global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C) {
+    __shared__ float red[256];
+    const int g = blockIdx.x, img = blockIdx.y, gw = C / 8, n = HW * gw, tid = threadIdx.x;
+    const float* base = x + (size_t)img * HW * C + g * gw;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) s += base[(size_t)(i / gw) * C + (i % gw)];
+    red[tid] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = red[0] / (float)n;
+    __syncthreads();
+    float m2 = 0.f;
+    for (int i = tid; i < n; i += 256) { const float d = base[(size_t)(i / gw) * C + (i % gw)] - mean; m2 += d * d; }
+    red[tid] = m2; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { stats[((size_t)img * 8 + g) * 2] = mean; stats[((size_t)img * 8 + g) * 2 + 1] = 1.0f / sqrtf(red[0] / (float)n + 1e-5f); }
+}
+
+// y = SiLU(GN(x)) [+ res]
+__global__ void fu_gn_silu_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gam,
+                                  const float* __restrict__ bet, const float* __restrict__ res, float* __restrict__ y,
+                                  int64_t total, int HW, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C), img = (int)(i / ((int64_t)HW * C)), g = c / (C / 8);
+    const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
+    const float u = (x[i] - m) * r * gam[c] + bet[c];
+    const float v = u * fu_sigmoid(u);
+    y[i] = res ? v + res[i] : v;
+}
+
+// backward of y = SiLU(GN(x)): pass 1 reduces S1 = sum dz, S2 = sum dz * z per (image, group) (dz = dy * silu'(u) * gamma,
+// z = (x - mean) * rstd); pass 2 applies dx = rstd * (dz - S1 / n - z * S2 / n).
+__global__ __launch_bounds__(256) void fu_gn_silu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     const float* __restrict__ stats, const float* __restrict__ gam,
+                                                                     const float* __restrict__ bet, float* __restrict__ sums, int HW, int C) {
+    __shared__ float r1[256], r2[256];
+    const int g = blockIdx.x, img = blockIdx.y, gw = C / 8, n = HW * gw, tid = threadIdx.x;
+    const size_t base = (size_t)img * HW * C + g * gw;
+    const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const int c = g * gw + (i % gw);
+        const size_t idx = base + (size_t)(i / gw) * C + (i % gw);
+        const float z = (x[idx] - m) * r, u = z * gam[c] + bet[c], sg = fu_sigmoid(u);
+        const float dz = dy[idx] * (sg * (1.0f + u * (1.0f - sg))) * gam[c];
+        s1 += dz; s2 += dz * z;
+    }
+    r1[tid] = s1; r2[tid] = s2; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; } __syncthreads(); }
+    if (tid == 0) { sums[((size_t)img * 8 + g) * 2] = r1[0] / (float)n; sums[((size_t)img * 8 + g) * 2 + 1] = r2[0] / (float)n; }
+}
+__global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                            const float* __restrict__ sums, const float* __restrict__ gam, const float* __restrict__ bet,
+                                            float* __restrict__ dx, float beta, int64_t total, int HW, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C), img = (int)(i / ((int64_t)HW * C)), g = c / (C / 8);
+    const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
+    const float z = (x[i] - m) * r, u = z * gam[c] + bet[c], sg = fu_sigmoid(u);
+    const float dz = dy[i] * (sg * (1.0f + u * (1.0f - sg))) * gam[c];
+    const float v = r * (dz - sums[((size_t)img * 8 + g) * 2] - z * sums[((size_t)img * 8 + g) * 2 + 1]);
+    dx[i] = beta != 0.f ? beta * dx[i] + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over channels (per pixel) times g: one wave per pixel.  fwd: y = (x - m) * r * g [+ res];
+// bwd: dz = dy * g, dx = beta * dx + r * (dz - mean(dz) - z * mean(dz * z)).
+__global__ __launch_bounds__(256) void fu_ln_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ res,
+                                                    float* __restrict__ y, int64_t rows, int C) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    s = rowgroup_sum<64>(s);
+    const float m = s / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; q += d * d; }
+    q = rowgroup_sum<64>(q);
+    const float r = 1.0f / sqrtf(q / C + 1e-5f);
+    for (int c = lane; c < C; c += 64) {
+        const float v = (xr[c] - m) * r * g[c];
+        y[row * C + c] = res ? v + res[row * C + c] : v;
+    }
+}
+__global__ __launch_bounds__(256) void fu_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, float beta, int64_t rows, int C) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    const float* dr = dy + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    s = rowgroup_sum<64>(s);
+    const float m = s / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; q += d * d; }
+    q = rowgroup_sum<64>(q);
+    const float r = 1.0f / sqrtf(q / C + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float dz = dr[c] * g[c], z = (xr[c] - m) * r; s1 += dz; s2 += dz * z; }
+    s1 = rowgroup_sum<64>(s1) / C; s2 = rowgroup_sum<64>(s2) / C;
+    for (int c = lane; c < C; c += 64) {
+        const float dz = dr[c] * g[c], z = (xr[c] - m) * r;
+        const float v = r * (dz - s1 - z * s2);
+        dx[row * C + c] = beta != 0.f ? beta * dx[row * C + c] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LinearAttention core (model/diffusion_2d.py:240-253) on qkv [img][n][384] (q | k | v, channel = head * 32 + d):
+//   qs = softmax_d(q) * 32^-1/2 ; ks = softmax_n(k) ; v' = v / n ; ctx[d][e] = sum_n ks[d,n] v'[e,n] ; out[e,n] = sum_d ctx[d][e] qs[d,n]
+// kstat [img][128][2] = (max_n k, sum_n exp(k - max)); ctx [img][4][32][32].
+__global__ __launch_bounds__(256) void fu_la_kstat_kernel(const float* __restrict__ qkv, float* __restrict__ kstat, int n) {
+    __shared__ float red[8][32];
+    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const float* kp = qkv + (size_t)img * n * 384 + 128 + h * 32 + d;
+    float mx = -INFINITY;
+    for (int i = part; i < n; i += 8) mx = fmaxf(mx, kp[(size_t)i * 384]);
+    red[part][d] = mx; __syncthreads();
+    mx = red[0][d];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) mx = fmaxf(mx, red[p][d]);
+    __syncthreads();
+    float s = 0.f;
+    for (int i = part; i < n; i += 8) s += __expf(kp[(size_t)i * 384] - mx);
+    red[part][d] = s; __syncthreads();
+    if (part == 0) {
+        s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += red[p][d];
+        kstat[((size_t)img * 128 + h * 32 + d) * 2] = mx; kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1] = s;
+    }
+}
+// MODE 0: ctx[d][e] = sum_n ks[d,n] v[e,n] / n ;  MODE 1 (backward): dctx[d][e] = sum_n dout[e,n] qs[d,n]
+// thread (d = tid >> 3, e4 = tid & 7): four consecutive e
+template <int MODE>
+__global__ __launch_bounds__(256) void fu_la_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                        const float* __restrict__ dout, float* __restrict__ ctx, int n) {
+    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x >> 3, e0 = (threadIdx.x & 7) * 4;
+    const float* base = qkv + (size_t)img * n * 384;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 0) {
+        const float mx = kstat[((size_t)img * 128 + h * 32 + d) * 2], inv = 1.0f / kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1];
+        for (int i = 0; i < n; ++i) {
+            const float ks = __expf(base[(size_t)i * 384 + 128 + h * 32 + d] - mx) * inv;
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)i * 384 + 256 + h * 32 + e0);
+            acc.x += ks * v.x; acc.y += ks * v.y; acc.z += ks * v.z; acc.w += ks * v.w;
+        }
+        const float s = 1.0f / (float)n;
+        acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
+    } else {
+        const float* dob = dout + (size_t)img * n * 128;
+        for (int i = 0; i < n; ++i) {
+            // qs[d] = softmax over the head's 32 channels: every thread of a d-row recomputes the pixel's max / sum
+            const float* qp = base + (size_t)i * 384 + h * 32;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) mx = fmaxf(mx, qp[j]);
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) sm += __expf(qp[j] - mx);
+            const float qs = __expf(qp[d] - mx) / sm * 0.17677669529663687f;
+            const float4 g = *reinterpret_cast<const float4*>(dob + (size_t)i * 128 + h * 32 + e0);
+            acc.x += qs * g.x; acc.y += qs * g.y; acc.z += qs * g.z; acc.w += qs * g.w;
+        }
+    }
+    *reinterpret_cast<float4*>(ctx + (((size_t)img * 4 + h) * 32 + d) * 32 + e0) = acc;
+}
+// out[n][h*32 + e] = sum_d ctx[d][e] qs[d]: one thread per (pixel, head)
+__global__ __launch_bounds__(256) void fu_la_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx, float* __restrict__ out,
+                                                          int n, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int h = (int)(t & 3);
+    const int64_t pix = t >> 2;
+    const int img = (int)(pix / n);
+    const float* qp = qkv + pix * 384 + h * 32;
+    float q[32], mx = -INFINITY, sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { q[j] = qp[j]; mx = fmaxf(mx, q[j]); }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { q[j] = __expf(q[j] - mx); sm += q[j]; }
+    const float sc = 0.17677669529663687f / sm;
+    const float* cp = ctx + ((size_t)img * 4 + h) * 1024;
+    float o[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) o[e] = 0.f;
+    for (int d = 0; d < 32; ++d) {
+        const float qs = q[d] * sc;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) o[e] += cp[d * 32 + e] * qs;
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) out[pix * 128 + h * 32 + e] = o[e];
+}
+// T[img][h*32+d] = sum_n ks[d,n] * dks[d,n],  dks[d,n] = sum_e dctx[d][e] v[e,n] / n.  thread (d = tid >> 3, part = tid & 7)
+__global__ __launch_bounds__(256) void fu_la_bwd_kdot_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                             const float* __restrict__ dctx, float* __restrict__ T, int n) {
+    __shared__ float red[32][8];
+    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x >> 3, part = threadIdx.x & 7;
+    const float* base = qkv + (size_t)img * n * 384;
+    const float mx = kstat[((size_t)img * 128 + h * 32 + d) * 2], inv = 1.0f / kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1];
+    float dc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) dc[e] = dctx[(((size_t)img * 4 + h) * 32 + d) * 32 + e];
+    float acc = 0.f;
+    for (int i = part; i < n; i += 8) {
+        const float ks = __expf(base[(size_t)i * 384 + 128 + h * 32 + d] - mx) * inv;
+        const float* vp = base + (size_t)i * 384 + 256 + h * 32;
+        float dks = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) dks += dc[e] * vp[e];
+        acc += ks * dks;
+    }
+    red[d][part] = acc; __syncthreads();
+    if (part == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += red[d][p];
+        T[(size_t)img * 128 + h * 32 + d] = s / (float)n;
+    }
+}
+// dqkv[n][384] from dout, ctx, dctx, kstat, T: one thread per (pixel, head)
+__global__ __launch_bounds__(256) void fu_la_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                              const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                              const float* __restrict__ T, const float* __restrict__ dout,
+                                                              float* __restrict__ dqkv, int n, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int h = (int)(t & 3);
+    const int64_t pix = t >> 2;
+    const int img = (int)(pix / n);
+    const float inv_n = 1.0f / (float)n;
+    const float* qp = qkv + pix * 384 + h * 32;
+    const float* kp = qp + 128;
+    const float* vp = qp + 256;
+    const float* gp = dout + pix * 128 + h * 32;
+    const float* cp = ctx + ((size_t)img * 4 + h) * 1024;
+    const float* dp = dctx + ((size_t)img * 4 + h) * 1024;
+    float g[32], v[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { g[e] = gp[e]; v[e] = vp[e]; }
+    float s[32], mx = -INFINITY, sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { s[j] = qp[j]; mx = fmaxf(mx, s[j]); }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { s[j] = __expf(s[j] - mx); sm += s[j]; }
+    float dqs[32], dot = 0.f, dv[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) dv[e] = 0.f;
+    for (int d = 0; d < 32; ++d) {
+        s[d] /= sm;
+        float a = 0.f, dks = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) { a += cp[d * 32 + e] * g[e]; dks += dp[d * 32 + e] * v[e]; }
+        dqs[d] = a;
+        dot += s[d] * a;
+        const float ks = __expf(kp[d] - kstat[((size_t)img * 128 + h * 32 + d) * 2]) / kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1];
+        dqkv[pix * 384 + 128 + h * 32 + d] = ks * (dks * inv_n - T[(size_t)img * 128 + h * 32 + d]);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) dv[e] += ks * dp[d * 32 + e];
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dqkv[pix * 384 + h * 32 + d] = 0.17677669529663687f * s[d] * (dqs[d] - dot);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) dqkv[pix * 384 + 256 + h * 32 + e] = dv[e] * inv_n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Softmax attention of the bottleneck (model/diffusion_2d.py:266-278), n <= 64 tokens: one workgroup of n threads per
+// (image, head).  fwd: out[i][h*32+d] = sum_j softmax_j(q_i.k_j * scale) v_j[d].  bwd: dqkv from dout (recomputes P).
+__global__ __launch_bounds__(64) void fu_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
+    __shared__ float K[64][33], V[64][33];
+    const int img = blockIdx.y, h = blockIdx.x, i = threadIdx.x;
+    const float* base = qkv + (size_t)img * n * 384;
+    if (i < n)
+        for (int d = 0; d < 32; ++d) { K[i][d] = base[(size_t)i * 384 + 128 + h * 32 + d]; V[i][d] = base[(size_t)i * 384 + 256 + h * 32 + d]; }
+    __syncthreads();
+    if (i >= n) return;
+    float q[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) q[d] = base[(size_t)i * 384 + h * 32 + d] * 0.17677669529663687f;
+    float p[64], mx = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s += q[d] * K[j][d];
+        p[j] = s; mx = fmaxf(mx, s);
+    }
+    float sm = 0.f;
+    for (int j = 0; j < n; ++j) { p[j] = __expf(p[j] - mx); sm += p[j]; }
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float pj = p[j] / sm;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] += pj * V[j][d];
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) out[((size_t)img * n + i) * 128 + h * 32 + d] = o[d];
+}
+__global__ __launch_bounds__(64) void fu_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv, int n) {
+    __shared__ float K[64][33], V[64][33], Q[64][33], G[64][33], dS[64][65], P[64][65];
+    const int img = blockIdx.y, h = blockIdx.x, i = threadIdx.x;
+    const float* base = qkv + (size_t)img * n * 384;
+    const float sc = 0.17677669529663687f;
+    if (i < n)
+        for (int d = 0; d < 32; ++d) {
+            Q[i][d] = base[(size_t)i * 384 + h * 32 + d] * sc; K[i][d] = base[(size_t)i * 384 + 128 + h * 32 + d];
+            V[i][d] = base[(size_t)i * 384 + 256 + h * 32 + d]; G[i][d] = dout[((size_t)img * n + i) * 128 + h * 32 + d];
+        }
+    __syncthreads();
+    if (i < n) {
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s += Q[i][d] * K[j][d];
+            P[i][j] = s; mx = fmaxf(mx, s);
+        }
+        float sm = 0.f;
+        for (int j = 0; j < n; ++j) { P[i][j] = __expf(P[i][j] - mx); sm += P[i][j]; }
+        float dot = 0.f;
+        for (int j = 0; j < n; ++j) {
+            P[i][j] /= sm;
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dp += G[i][d] * V[j][d];
+            dS[i][j] = dp;
+            dot += P[i][j] * dp;
+        }
+        for (int j = 0; j < n; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot);
+        // dq_i = scale * sum_j dS_ij k_j
+        for (int d = 0; d < 32; ++d) {
+            float a = 0.f;
+            for (int j = 0; j < n; ++j) a += dS[i][j] * K[j][d];
+            dqkv[((size_t)img * n + i) * 384 + h * 32 + d] = a * sc;
+        }
+    }
+    __syncthreads();
+    if (i < n) {
+        // thread i now plays key / value j = i: dk_j = sum_i dS_ij q_i (q already scaled), dv_j = sum_i P_ij g_i
+        for (int d = 0; d < 32; ++d) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < n; ++r) { a += dS[r][i] * Q[r][d]; b += P[r][i] * G[r][d]; }
+            dqkv[((size_t)img * n + i) * 384 + 128 + h * 32 + d] = a;
+            dqkv[((size_t)img * n + i) * 384 + 256 + h * 32 + d] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pixel-unshuffle 'b c (h p1) (w p2) -> b (c p1 p2) h w' (channel-last) and its inverse (scatter of gradients)
+__global__ void fu_unshuffle_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int Wd, int C, int64_t total, int inverse, float beta) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // index into the unshuffled tensor [img][H/2*W/2][4C]
+    if (i >= total) return;
+    const int C4 = 4 * C, cc = (int)(i % C4), h2 = H / 2, w2 = Wd / 2;
+    const int64_t pix = i / C4;
+    const int img = (int)(pix / (h2 * w2)), p = (int)(pix % (h2 * w2)), yy = p / w2, xx = p % w2;
+    const int c = cc >> 2, p1 = (cc >> 1) & 1, p2 = cc & 1;
+    const size_t src = ((size_t)img * H * Wd + (size_t)(2 * yy + p1) * Wd + 2 * xx + p2) * C + c;
+    if (!inverse) y[i] = x[src];
+    else y[src] = beta != 0.f ? beta * y[src] + x[i] : x[i];              // x: gradient in unshuffled layout, y: gradient of the source
+}
+__global__ void fu_add_kernel(const float* __restrict__ a, float* __restrict__ y, float beta, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) y[i] = beta != 0.f ? beta * y[i] + a[i] : a[i];
+}
+// head: feat[img][c] = mean_p x[img][p][c]; out[img][o] = W[o] . feat + b[o]
+__global__ __launch_bounds__(256) void fu_head_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                      float* __restrict__ out, int HW, int C) {
+    __shared__ float feat[512];
+    __shared__ float red[2][256];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        // the reference takes mean(dim=-1).mean(dim=-1): first over x (W), then over y (H)
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += x[((size_t)img * HW + p) * C + c];
+        feat[c] = s / (float)HW;
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = tid; c < C; c += 256) { a0 += W[c] * feat[c]; a1 += W[C + c] * feat[c]; }
+    red[0][tid] = a0; red[1][tid] = a1; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; } __syncthreads(); }
+    if (tid == 0) { out[img * 2] = red[0][0] + b[0]; out[img * 2 + 1] = red[1][0] + b[1]; }
+}
+// seed of the backward pass: force = lambda * |out0| + out1  ->  d force / d x[img][p][c] = (lambda * sign(out0) * W[0][c] + W[1][c]) / HW
+__global__ void fu_head_bwd_kernel(const float* __restrict__ out, const float* __restrict__ W, float lambda_force, float* __restrict__ dx,
+                                   int HW, int C, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C), img = (int)(i / ((int64_t)HW * C));
+    const float o0 = out[img * 2];
+    const float sg = o0 > 0.f ? 1.f : (o0 < 0.f ? -1.f : 0.f);
+    dx[i] = (lambda_force * sg * W[c] + W[C + c]) / (float)HW;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The objective around the network (inference/inverse_design_2d.py:98-143, sum_boundary = True).  State layout
+// [img = b * nb + k][pixel][CP] with the 3 boundary channels at [Cs - 3, Cs) (Cs = 3 * frames + 3 real channels).
+// bsum[b][pixel][3] = clamp(sum_k boundary_k, 0, 1)
+__global__ void fu_bsum_kernel(const float* __restrict__ x, float* __restrict__ bsum, int nb, int HW, int CP, int Cs, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [b][pixel][3]
+    if (i >= total) return;
+    const int c = (int)(i % 3);
+    const int64_t bp = i / 3;
+    const int b = (int)(bp / HW), p = (int)(bp % HW);
+    float s = 0.f;
+    for (int k = 0; k < nb; ++k) s += x[((size_t)(b * nb + k) * HW + p) * CP + Cs - 3 + c];
+    bsum[i] = fminf(fmaxf(s, 0.f), 1.f);
+}
+// inp[img][pixel][4] = (unnormalised pressure of frame f, bsum)
+__global__ void fu_build_input_kernel(const float* __restrict__ x, const float* __restrict__ bsum, float* __restrict__ inp, int f, int nb, int HW,
+                                      int CP, float p_min, float p_max, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][pixel]
+    if (i >= total) return;
+    const int img = (int)(i / HW), p = (int)(i % HW), b = img / nb;
+    const float pr = (0.5f * x[i * CP + 2 + 3 * f] + 0.5f) * (p_max - p_min) + p_min;
+    const float* bs = bsum + ((size_t)b * HW + p) * 3;
+    *reinterpret_cast<float4*>(inp + i * 4) = make_float4(pr, bs[0], bs[1], bs[2]);
+}
+// gradient of one frame's network input: pressure channel -> gx, boundary channels accumulate into gb[img][pixel][3]
+__global__ void fu_scatter_input_grad_kernel(const float* __restrict__ dinp, float* __restrict__ gx, float* __restrict__ gb, int f, int first,
+                                             int CP, float p_min, float p_max, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][pixel]
+    if (i >= total) return;
+    const float4 d = *reinterpret_cast<const float4*>(dinp + i * 4);
+    gx[i * CP + 2 + 3 * f] = d.x * 0.5f * (p_max - p_min);
+    float* g = gb + i * 3;
+    if (first) { g[0] = d.y; g[1] = d.z; g[2] = d.w; } else { g[0] += d.y; g[1] += d.z; g[2] += d.w; }
+}
+// dm[img][cell] = mean over the F x F block of clamp(mask, 0, 1)   (overlap_fn's down-sampled mask)
+__global__ void fu_overlap_dm_kernel(const float* __restrict__ x, float* __restrict__ dm, int Hs, int F, int CP, int Cs, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][cell]
+    if (i >= total) return;
+    const int nr = Hs / F, cell = (int)(i % (nr * nr)), img = (int)(i / (nr * nr)), cy = cell / nr, cx = cell % nr;
+    float s = 0.f;
+    for (int yy = 0; yy < F; ++yy)
+        for (int xx = 0; xx < F; ++xx)
+            s += fminf(fmaxf(x[((size_t)img * Hs * Hs + (size_t)(cy * F + yy) * Hs + cx * F + xx) * CP + Cs - 3], 0.f), 1.f);
+    dm[i] = s / (float)(F * F);
+}
+// final assembly of the boundary channels: gx[.., Cs-3+c] = clamp'(sum) * sum_k' gb[b, k'] + lambda_overlap * overlap gradient (c = 0)
+__global__ void fu_finish_grad_kernel(const float* __restrict__ x, const float* __restrict__ gb, const float* __restrict__ dm, float* __restrict__ gx,
+                                      int nb, int Hs, int F, int CP, int Cs, float lambda_overlap, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][pixel]
+    if (i >= total) return;
+    const int HW = Hs * Hs, img = (int)(i / HW), p = (int)(i % HW), b = img / nb, k = img - b * nb;
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f, g = 0.f;
+        for (int k2 = 0; k2 < nb; ++k2) {
+            s += x[((size_t)(b * nb + k2) * HW + p) * CP + Cs - 3 + c];
+            g += gb[((size_t)(b * nb + k2) * HW + p) * 3 + c];
+        }
+        float v = (s >= 0.f && s <= 1.f) ? g : 0.f;                      // torch.clamp passes the gradient on [min, max]
+        if (c == 0) {
+            const float m = x[i * CP + Cs - 3];
+            if (m >= 0.f && m <= 1.f) {
+                const int nr = Hs / F, cell = ((p / Hs) / F) * nr + (p % Hs) / F;
+                float o = 0.f;
+                for (int k2 = 0; k2 < nb; ++k2) if (k2 != k) o += dm[(size_t)(b * nb + k2) * nr * nr + cell];
+                v += lambda_overlap * 2.0f * o / (float)(nb * nb) / (float)(F * F);
+            }
+        }
+        gx[i * CP + Cs - 3 + c] = v;
+    }
+}
+
+}  // namespace cindm

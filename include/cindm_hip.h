@@ -347,6 +347,40 @@ int  cindm_fill_noise2d(float* x, int64_t B, int32_t nb, int32_t hw, int32_t cha
                         int32_t step_tag, void* stream);
 
 
+/* ------------------------------------------------------------------ ForceUnet and the airfoil design gradient
+ * Replaces ForceUnet.__init__/forward, model/diffusion_2d.py:411-486 (the surrogate of the lift / drag forces), and --
+ * instead of torch.autograd.grad through it -- the design_fn of inference/inverse_design_2d.py:208-214 built from
+ * force_fn :98-132 (sum_boundary = True) and overlap_fn :134-143.  Only input gradients exist (frozen weights).
+ * Tensors: channel-last fp32; network input [images, H*W, channels]; sampler state [B*nb, H*W, CP] as cindm_ddpm2d_*. */
+typedef struct cindm_forceunet cindm_forceunet;
+typedef struct {
+    int32_t dim;              /* 64                                         :414 */
+    int32_t n_mults;          /* len(dim_mults) <= 4                        :417 */
+    int32_t dim_mults[4];     /* (1, 2, 4, 8): the bottleneck must be 512 wide (final = Linear(512, 2), :458) */
+    int32_t channels;         /* 4 = (pressure, boundary mask, 2 offsets)   :418 */
+    int32_t image_size;       /* 64 */
+} cindm_forceunet_desc;
+
+int  cindm_forceunet_create(const cindm_forceunet_desc* desc, cindm_forceunet** out);
+void cindm_forceunet_destroy(cindm_forceunet* h);
+int  cindm_forceunet_num_params(const cindm_forceunet* h);
+int  cindm_forceunet_param_info(const cindm_forceunet* h, int idx, char* name, int name_cap, int64_t shape[4], int* ndim);
+int  cindm_forceunet_set_param(cindm_forceunet* h, const char* key, const float* src, int64_t numel, int on_device);
+int  cindm_forceunet_finalize(cindm_forceunet* h, void* stream);      /* folds weight standardisation, packs forward and backward-data fragments */
+size_t cindm_forceunet_workspace_bytes(const cindm_forceunet* h, int64_t images, int32_t with_grad);
+/* out[images, 2] = ForceUnet.forward(x)   (:460-486) */
+int  cindm_forceunet_forward(cindm_forceunet* h, const float* x, float* out, int64_t images, void* ws, size_t ws_bytes, void* stream);
+/* the same forward, and dx = d( sum_images lambda_force * |out[:,0]| + out[:,1] ) / dx  (what force_fn differentiates, :113-117) */
+int  cindm_forceunet_grad(cindm_forceunet* h, const float* x, float lambda_force, float* out, float* dx, int64_t images,
+                          void* ws, size_t ws_bytes, void* stream);
+/* grad[B*nb, H*W, CP] = design_fn(x) = grad_force + lambda_overlap * grad_overlap (inverse_design_2d.py:208-214), the
+ * tensor GaussianDiffusion.p_sample subtracts under "standard" / "standard-alpha" guidance (model/diffusion_2d.py:813-817).
+ * frames = (real channels - 3) / 3; p_min / p_max: the pressure normalisation of the data set (:85-87). */
+size_t cindm_airfoil_design_workspace_bytes(const cindm_forceunet* h, int64_t B, int32_t nb);
+int  cindm_airfoil_design_grad(cindm_forceunet* h, const float* x, int64_t B, int32_t nb, int32_t frames, int32_t CP,
+                               float p_min, float p_max, float lambda_force, float lambda_overlap, int32_t downsampling_factor,
+                               float* grad, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1001,6 +1001,119 @@ def unet2d_forward(sd, x, t, taps=None):
     return F.conv2d(x, sd["final_conv.weight"], sd["final_conv.bias"])
 
 
+# ----------------------------------------------------------------------------
+# ForceUnet (the airfoil design objective's surrogate) and the design gradient built on it
+# ----------------------------------------------------------------------------
+
+def _resnet_block_notime_2d(sd, p, x):
+    """ResnetBlock.forward with time_emb_dim = None (model/diffusion_2d.py:212-224, Block :189-198)."""
+    h = _ws_conv2d(x, sd[p + ".block1.proj.weight"], sd[p + ".block1.proj.bias"], 1)
+    h = F.silu(F.group_norm(h, 8, sd[p + ".block1.norm.weight"], sd[p + ".block1.norm.bias"], eps=1e-5))
+    h = _ws_conv2d(h, sd[p + ".block2.proj.weight"], sd[p + ".block2.proj.bias"], 1)
+    h = F.silu(F.group_norm(h, 8, sd[p + ".block2.norm.weight"], sd[p + ".block2.norm.bias"], eps=1e-5))
+    if (p + ".res_conv.weight") in sd:
+        x = F.conv2d(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
+    return h + x
+
+
+def force_unet_param_shapes(dim=64, dim_mults=(1, 2, 4, 8), channels=4):
+    """State-dict manifest of ForceUnet (model/diffusion_2d.py:411-458), registration order."""
+    dims = [dim] + [dim * m for m in dim_mults]
+    sh = {"init_conv.weight": (dim, channels, 7, 7), "init_conv.bias": (dim,)}
+
+    def rb(p, ci, co):
+        for b, (i, o) in (("block1", (ci, co)), ("block2", (co, co))):
+            sh[f"{p}.{b}.proj.weight"] = (o, i, 3, 3); sh[f"{p}.{b}.proj.bias"] = (o,)
+            sh[f"{p}.{b}.norm.weight"] = (o,); sh[f"{p}.{b}.norm.bias"] = (o,)
+        if ci != co:
+            sh[f"{p}.res_conv.weight"] = (co, ci, 1, 1); sh[f"{p}.res_conv.bias"] = (co,)
+
+    n = len(dim_mults)
+    for ind in range(n):
+        ci, co = dims[ind], dims[ind + 1]
+        p = f"downs.{ind}"
+        rb(p + ".0", ci, ci); rb(p + ".1", ci, ci)
+        sh[p + ".2.fn.fn.to_qkv.weight"] = (384, ci, 1, 1)
+        sh[p + ".2.fn.fn.to_out.0.weight"] = (ci, 128, 1, 1); sh[p + ".2.fn.fn.to_out.0.bias"] = (ci,)
+        sh[p + ".2.fn.fn.to_out.1.g"] = (1, ci, 1, 1)
+        sh[p + ".2.fn.norm.g"] = (1, ci, 1, 1)
+        if ind < n - 1:
+            sh[p + ".3.1.weight"] = (co, ci * 4, 1, 1); sh[p + ".3.1.bias"] = (co,)
+        else:
+            sh[p + ".3.weight"] = (co, ci, 3, 3); sh[p + ".3.bias"] = (co,)
+    mid = dims[-1]
+    rb("mid_block1", mid, mid)
+    sh["mid_attn.fn.fn.to_qkv.weight"] = (384, mid, 1, 1)
+    sh["mid_attn.fn.fn.to_out.weight"] = (mid, 128, 1, 1); sh["mid_attn.fn.fn.to_out.bias"] = (mid,)
+    sh["mid_attn.fn.norm.g"] = (1, mid, 1, 1)
+    rb("mid_block2", mid, mid)
+    sh["final.weight"] = (2, 512); sh["final.bias"] = (2,)
+    return sh
+
+
+def force_unet_forward(sd, x, taps=None):
+    """ForceUnet.forward, model/diffusion_2d.py:460-486.  x [N, 4, H, W] -> [N, 2] (drag, lift)."""
+    nl = 0
+    while f"downs.{nl}.0.block1.proj.weight" in sd:
+        nl += 1
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    x = F.conv2d(x, sd["init_conv.weight"], sd["init_conv.bias"], padding=3); tap("init_conv", x)
+    for i in range(nl):
+        p = f"downs.{i}"
+        x = _resnet_block_notime_2d(sd, p + ".0", x); tap(p + ".0", x)
+        x = _resnet_block_notime_2d(sd, p + ".1", x); tap(p + ".1", x)
+        x = linear_attention_2d(sd, p + ".2", x); tap(p + ".2", x)
+        if (p + ".3.1.weight") in sd:
+            b, c, hh, ww = x.shape
+            xs = x.reshape(b, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(b, c * 4, hh // 2, ww // 2)
+            x = F.conv2d(xs, sd[p + ".3.1.weight"], sd[p + ".3.1.bias"])
+        else:
+            x = F.conv2d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], padding=1)
+        tap(p + ".3", x)
+    x = _resnet_block_notime_2d(sd, "mid_block1", x); tap("mid_block1", x)
+    x = full_attention_2d(sd, "mid_attn", x); tap("mid_attn", x)
+    x = _resnet_block_notime_2d(sd, "mid_block2", x); tap("mid_block2", x)
+    x = x.mean(dim=-1).mean(dim=-1)
+    return F.linear(x, sd["final.weight"], sd["final.bias"])
+
+
+def airfoil_design_grad(sd_force, x, batch_size, num_boundaries, frames, p_min, p_max, lambda_force=1.0, lambda_overlap=1.0,
+                        downsampling_factor=4, parts=None):
+    """The airfoil design_fn of inference/inverse_design_2d.py:208-214 = force_fn (:98-132, sum_boundary = True) +
+    lambda_overlap * overlap_fn (:134-143), restated with torch autograd.  x [B * nb, 3 * frames + 3, 64, 64];
+    returns the gradient, same shape.  The script itself cannot be imported (it parses arguments and loads data at
+    import time), so this composition is anchored on its lines; ForceUnet.forward is pinned against the reference class."""
+    x = x.detach().clone().requires_grad_(True)
+    H = x.shape[-1]
+    boundary = x[:, -3:]
+    boundary = boundary.view(batch_size, num_boundaries, 3, H, H).sum(dim=1, keepdim=True).clamp(0., 1.) \
+        .expand(-1, num_boundaries, -1, -1, -1).reshape(batch_size * num_boundaries, 3, H, H)
+    forces = []
+    for i in range(frames):
+        pressure = (0.5 * x[:, 2 + 3 * i] + 0.5) * (p_max - p_min) + p_min
+        ld = force_unet_forward(sd_force, torch.cat([pressure.unsqueeze(1), boundary], dim=1))
+        forces.append(lambda_force * torch.abs(ld[:, 0]) + ld[:, 1])
+    summed = torch.sum(torch.stack(forces, dim=0), dim=0)
+    g_force = torch.autograd.grad(summed, x, grad_outputs=torch.ones_like(summed))[0]
+    x2 = x.detach().clone().requires_grad_(True)
+    xv = x2.view(batch_size, num_boundaries, -1, H, H)
+    bd = xv[:, :, -3].clamp(0., 1.)
+    nr = H // downsampling_factor
+    dm = bd.view(batch_size, num_boundaries, nr, downsampling_factor, nr, downsampling_factor).mean(dim=(3, 5)) \
+        .view(batch_size, num_boundaries, -1)
+    ip = torch.matmul(dm, dm.permute(0, 2, 1))
+    eye = torch.eye(num_boundaries).unsqueeze(0).expand(batch_size, -1, -1)
+    ov = (ip * (1 - eye)).mean(dim=(-2, -1))
+    g_ov = torch.autograd.grad(ov, x2, grad_outputs=torch.ones_like(ov))[0]
+    if parts is not None:
+        parts["force"], parts["overlap"] = g_force, g_ov
+    return g_force + lambda_overlap * g_ov
+
+
 class Diffusion2D:
     """What GaussianDiffusion (2-D) holds for sampling, model/diffusion_2d.py:552-676."""
 

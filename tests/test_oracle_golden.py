@@ -335,3 +335,20 @@ def test_steps_2d_recurrence(gold_dir, sd2d, tag):
     out, x0 = O.p_sample_2d(od, (1, 2, 21, 32, 32), torch.from_numpy(g[tag + ".x"]), t, nz, design_grad_2d, guid,
                             recur_noise=torch.from_numpy(g[tag + ".recur"]))
     assert rel(out, g[tag + ".out"]) < TOL and rel(x0, g[tag + ".x0"]) < TOL
+
+
+def test_force_unet_oracle_vs_golden(gold_dir):
+    """ForceUnet forward and input gradient (model/diffusion_2d.py:411-486) and the airfoil design gradient
+    (inference/inverse_design_2d.py:98-143, :208-214): the oracle against the vectors captured from the reference's class /
+    torch autograd by oracle/make_golden_force.py."""
+    g = np.load(os.path.join(gold_dir, "force_2d.npz"))
+    man = json.load(open(os.path.join(gold_dir, "manifest_force.json")))
+    assert [(k, list(v)) for k, v in O.force_unet_param_shapes().items()] == list(man.items())
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = O.force_unet_forward(sd, x)
+    assert rel(y.detach(), g["y"]) < TOL
+    gx = torch.autograd.grad(y.sum() + 0.5 * y[:, 0].sum(), x)[0]
+    assert rel(gx, g["gx"]) < TOL
+    gd = O.airfoil_design_grad(sd, torch.from_numpy(g["design.x"]), 1, 2, 2, p_min=-37.7, p_max=57.6)
+    assert rel(gd, g["design.grad"]) < TOL
