@@ -7,7 +7,7 @@
 // (packed once at finalize), plus the derivative kernels of GroupNorm+SiLU, LayerNorm, linear attention, softmax
 // attention, pixel-unshuffle and the mean-pool / Linear head.  Layout: channel-last fp32 [image][pixel][C], as the rest
 // of the 2-D path.  Convolutions run on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32): this module is written for
-// correctness first (gradient parity 2e-5 against torch autograd of the oracle); it is not yet on the split-fp16 pipe.
+// correctness first (gradient parity 2e-5 against torch autograd of the CPU restatement); it is not yet on the split-fp16 pipe.
 #pragma once
 #include "kernels.h"
 
@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void fu_ln_bwd_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LinearAttention core (model/diffusion_2d.py:240-253) on qkv [img][n][384] (q | k | v, channel = head * 32 + d):
-//   qs = softmax_d(q) * 32^-1/2 ; ks = softmax_n(k) ; v' = v / n ; ctx[d][e] = sum_n ks[d,n] v'[e,n] ; out[e,n] = sum_d ctx[d][e] qs[d,n]
-// kstat [img][128][2] = (max_n k, sum_n exp(k - max)); ctx [img][4][32][32].
+//   qs = softmax_d(q) * 32^-1/2 ; ks = softmax_n(k) ; ctx[d][e] = sum_n ks[n,d] v[n,e] / n ; out[n,e] = sum_d qs[n,d] ctx[d][e]
+// decomposed into (1) column statistics of k, (2) an elementwise pass that materialises qs and ks [img][n][128] (kept for
+// the backward pass), and two small fp32-MFMA GEMM shapes shared by forward and backward:
+//   fu_la_outer_kernel:  M[d][e] = alpha * sum_n X[n,d] Y[n,e]          (ctx = ks^T v / n ; dctx = qs^T dout)
+//   fu_la_rowmat_kernel: Z[n,e]  = alpha * sum_d X[n,d] M[d][e] (or M^T) (out = qs ctx ; dqs = dout ctx^T ; dks = v dctx^T ; dv = ks dctx)
 __global__ __launch_bounds__(256) void fu_la_kstat_kernel(const float* __restrict__ qkv, float* __restrict__ kstat, int n) {
     __shared__ float red[8][32];
     const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -235,44 +238,9 @@ __global__ __launch_bounds__(256) void fu_la_kstat_kernel(const float* __restric
         kstat[((size_t)img * 128 + h * 32 + d) * 2] = mx; kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1] = s;
     }
 }
-// MODE 0: ctx[d][e] = sum_n ks[d,n] v[e,n] / n ;  MODE 1 (backward): dctx[d][e] = sum_n dout[e,n] qs[d,n]
-// thread (d = tid >> 3, e4 = tid & 7): four consecutive e
-template <int MODE>
-__global__ __launch_bounds__(256) void fu_la_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
-                                                        const float* __restrict__ dout, float* __restrict__ ctx, int n) {
-    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x >> 3, e0 = (threadIdx.x & 7) * 4;
-    const float* base = qkv + (size_t)img * n * 384;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 0) {
-        const float mx = kstat[((size_t)img * 128 + h * 32 + d) * 2], inv = 1.0f / kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1];
-        for (int i = 0; i < n; ++i) {
-            const float ks = __expf(base[(size_t)i * 384 + 128 + h * 32 + d] - mx) * inv;
-            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)i * 384 + 256 + h * 32 + e0);
-            acc.x += ks * v.x; acc.y += ks * v.y; acc.z += ks * v.z; acc.w += ks * v.w;
-        }
-        const float s = 1.0f / (float)n;
-        acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
-    } else {
-        const float* dob = dout + (size_t)img * n * 128;
-        for (int i = 0; i < n; ++i) {
-            // qs[d] = softmax over the head's 32 channels: every thread of a d-row recomputes the pixel's max / sum
-            const float* qp = base + (size_t)i * 384 + h * 32;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) mx = fmaxf(mx, qp[j]);
-            float sm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) sm += __expf(qp[j] - mx);
-            const float qs = __expf(qp[d] - mx) / sm * 0.17677669529663687f;
-            const float4 g = *reinterpret_cast<const float4*>(dob + (size_t)i * 128 + h * 32 + e0);
-            acc.x += qs * g.x; acc.y += qs * g.y; acc.z += qs * g.z; acc.w += qs * g.w;
-        }
-    }
-    *reinterpret_cast<float4*>(ctx + (((size_t)img * 4 + h) * 32 + d) * 32 + e0) = acc;
-}
-// out[n][h*32 + e] = sum_d ctx[d][e] qs[d]: one thread per (pixel, head)
-__global__ __launch_bounds__(256) void fu_la_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx, float* __restrict__ out,
-                                                          int n, int64_t total) {
+// qs[n][h*32+d] = softmax_d(q) * scale ; ks[n][h*32+d] = exp(k - max_n) / sum_n: one thread per (pixel, head)
+__global__ __launch_bounds__(256) void fu_la_prep_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
+                                                         float* __restrict__ qs, float* __restrict__ ks, int n, int64_t total) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int h = (int)(t & 3);
@@ -281,93 +249,117 @@ __global__ __launch_bounds__(256) void fu_la_apply_kernel(const float* __restric
     const float* qp = qkv + pix * 384 + h * 32;
     float q[32], mx = -INFINITY, sm = 0.f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) { q[j] = qp[j]; mx = fmaxf(mx, q[j]); }
+    for (int j = 0; j < 32; j += 4) { const float4 v = *reinterpret_cast<const float4*>(qp + j); q[j] = v.x; q[j + 1] = v.y; q[j + 2] = v.z; q[j + 3] = v.w; }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) mx = fmaxf(mx, q[j]);
 #pragma unroll
     for (int j = 0; j < 32; ++j) { q[j] = __expf(q[j] - mx); sm += q[j]; }
     const float sc = 0.17677669529663687f / sm;
-    const float* cp = ctx + ((size_t)img * 4 + h) * 1024;
-    float o[32];
+    const float* st = kstat + ((size_t)img * 128 + h * 32) * 2;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) o[e] = 0.f;
-    for (int d = 0; d < 32; ++d) {
-        const float qs = q[d] * sc;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) o[e] += cp[d * 32 + e] * qs;
+    for (int j = 0; j < 32; j += 4) {
+        *reinterpret_cast<float4*>(qs + pix * 128 + h * 32 + j) = make_float4(q[j] * sc, q[j + 1] * sc, q[j + 2] * sc, q[j + 3] * sc);
+        const float4 kv = *reinterpret_cast<const float4*>(qp + 128 + j);
+        float4 o;
+        o.x = __expf(kv.x - st[2 * j]) / st[2 * j + 1]; o.y = __expf(kv.y - st[2 * j + 2]) / st[2 * j + 3];
+        o.z = __expf(kv.z - st[2 * j + 4]) / st[2 * j + 5]; o.w = __expf(kv.w - st[2 * j + 6]) / st[2 * j + 7];
+        *reinterpret_cast<float4*>(ks + pix * 128 + h * 32 + j) = o;
     }
-#pragma unroll
-    for (int e = 0; e < 32; ++e) out[pix * 128 + h * 32 + e] = o[e];
 }
-// T[img][h*32+d] = sum_n ks[d,n] * dks[d,n],  dks[d,n] = sum_e dctx[d][e] v[e,n] / n.  thread (d = tid >> 3, part = tid & 7)
-__global__ __launch_bounds__(256) void fu_la_bwd_kdot_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
-                                                             const float* __restrict__ dctx, float* __restrict__ T, int n) {
-    __shared__ float red[32][8];
-    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x >> 3, part = threadIdx.x & 7;
-    const float* base = qkv + (size_t)img * n * 384;
-    const float mx = kstat[((size_t)img * 128 + h * 32 + d) * 2], inv = 1.0f / kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1];
-    float dc[32];
+// M[img][h][d][e] = alpha * sum_n X[img][n][xoff + h*32 + d] * Y[img][n][yoff + h*32 + e]; workgroup = (head, image), the
+// four waves split n, fp32 MFMA 16x16x4 (A[i = d][k = pixel], B[k = pixel][j = e]), partial tiles summed through LDS.
+__global__ __launch_bounds__(256) void fu_la_outer_kernel(const float* __restrict__ X, int ldx, int xoff, const float* __restrict__ Y, int ldy, int yoff,
+                                                          float* __restrict__ M, float alpha, int n) {
+    __shared__ float red[4][1024];
+    const int img = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* xp = X + (size_t)img * n * ldx + xoff + h * 32 + (lane & 15);
+    const float* yp = Y + (size_t)img * n * ldy + yoff + h * 32 + (lane & 15);
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) dc[e] = dctx[(((size_t)img * 4 + h) * 32 + d) * 32 + e];
-    float acc = 0.f;
-    for (int i = part; i < n; i += 8) {
-        const float ks = __expf(base[(size_t)i * 384 + 128 + h * 32 + d] - mx) * inv;
-        const float* vp = base + (size_t)i * 384 + 256 + h * 32;
-        float dks = 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 32; ++e) dks += dc[e] * vp[e];
-        acc += ks * dks;
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int per = n / 4;                                  // n is a multiple of 64
+    for (int p0 = w * per; p0 < (w + 1) * per; p0 += 4) {
+        const size_t r = (size_t)(p0 + (lane >> 4));
+        const float a0 = xp[r * ldx], a1 = xp[r * ldx + 16];
+        const float b0 = yp[r * ldy], b1 = yp[r * ldy + 16];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    red[d][part] = acc; __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) red[w][(i * 16 + (lane >> 4) * 4 + rg) * 32 + j * 16 + (lane & 15)] = acc[i][j][rg];
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256)
+        M[((size_t)img * 4 + h) * 1024 + i] = alpha * ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+}
+// Z[img][n][zoff + h*32 + e] = alpha * sum_d X[img][n][xoff + h*32 + d] * (TRANS ? M[e][d] : M[d][e]); one wave per 16 pixels
+// of one head: A[i = pixel][k = d], B[k = d][j = e]
+template <bool TRANS>
+__global__ __launch_bounds__(256) void fu_la_rowmat_kernel(const float* __restrict__ X, int ldx, int xoff, const float* __restrict__ M,
+                                                           float* __restrict__ Z, int ldz, int zoff, float alpha, int n) {
+    const int img = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w;      // wave = head
+    const int p0 = blockIdx.x * 16;
+    const float* mp = M + ((size_t)img * 4 + h) * 1024;
+    const float* xp = X + ((size_t)img * n + p0 + (lane & 15)) * ldx + xoff + h * 32 + (lane >> 4);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const float av = xp[kk * 4];
+        const int d = kk * 4 + (lane >> 4), e = lane & 15;
+        const float b0 = TRANS ? mp[e * 32 + d] : mp[d * 32 + e];
+        const float b1 = TRANS ? mp[(e + 16) * 32 + d] : mp[d * 32 + e + 16];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            Z[((size_t)img * n + p0 + (lane >> 4) * 4 + rg) * ldz + zoff + h * 32 + j * 16 + (lane & 15)] = alpha * acc[j][rg];
+}
+// T[img][h*32+d] = sum_n ks[n,d] * dks[n,d] (dks already carries the 1/n of v' = v / n)
+__global__ __launch_bounds__(256) void fu_la_bwd_kdot_kernel(const float* __restrict__ ks, const float* __restrict__ dks, float* __restrict__ T, int n) {
+    __shared__ float red[8][32];
+    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const size_t base = (size_t)img * n * 128 + h * 32 + d;
+    float s = 0.f;
+    for (int i = part; i < n; i += 8) s += ks[base + (size_t)i * 128] * dks[base + (size_t)i * 128];
+    red[part][d] = s; __syncthreads();
     if (part == 0) {
-        float s = 0.f;
+        s = 0.f;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) s += red[d][p];
-        T[(size_t)img * 128 + h * 32 + d] = s / (float)n;
+        for (int p = 0; p < 8; ++p) s += red[p][d];
+        T[(size_t)img * 128 + h * 32 + d] = s;
     }
 }
-// dqkv[n][384] from dout, ctx, dctx, kstat, T: one thread per (pixel, head)
-__global__ __launch_bounds__(256) void fu_la_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
-                                                              const float* __restrict__ ctx, const float* __restrict__ dctx,
-                                                              const float* __restrict__ T, const float* __restrict__ dout,
+// dqkv[n][384]: dq = s (dqs - sum_d s dqs) with s = softmax(q) = qs / scale (dqs already scaled by nothing: the scale
+// sits in qs), dk = ks (dks - T), dv as given.  One thread per (pixel, head); dqs / dks / dv are [img][n][128].
+__global__ __launch_bounds__(256) void fu_la_bwd_apply_kernel(const float* __restrict__ qs, const float* __restrict__ ks, const float* __restrict__ dqs,
+                                                              const float* __restrict__ dks, const float* __restrict__ dv, const float* __restrict__ T,
                                                               float* __restrict__ dqkv, int n, int64_t total) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int h = (int)(t & 3);
     const int64_t pix = t >> 2;
     const int img = (int)(pix / n);
-    const float inv_n = 1.0f / (float)n;
-    const float* qp = qkv + pix * 384 + h * 32;
-    const float* kp = qp + 128;
-    const float* vp = qp + 256;
-    const float* gp = dout + pix * 128 + h * 32;
-    const float* cp = ctx + ((size_t)img * 4 + h) * 1024;
-    const float* dp = dctx + ((size_t)img * 4 + h) * 1024;
-    float g[32], v[32];
+    const size_t o = pix * 128 + h * 32;
+    float dot = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { g[e] = gp[e]; v[e] = vp[e]; }
-    float s[32], mx = -INFINITY, sm = 0.f;
+    for (int d = 0; d < 32; ++d) dot += qs[o + d] * dqs[o + d];              // = scale * sum_d s_d dqs_d
 #pragma unroll
-    for (int j = 0; j < 32; ++j) { s[j] = qp[j]; mx = fmaxf(mx, s[j]); }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { s[j] = __expf(s[j] - mx); sm += s[j]; }
-    float dqs[32], dot = 0.f, dv[32];
-#pragma unroll
-    for (int e = 0; e < 32; ++e) dv[e] = 0.f;
     for (int d = 0; d < 32; ++d) {
-        s[d] /= sm;
-        float a = 0.f, dks = 0.f;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) { a += cp[d * 32 + e] * g[e]; dks += dp[d * 32 + e] * v[e]; }
-        dqs[d] = a;
-        dot += s[d] * a;
-        const float ks = __expf(kp[d] - kstat[((size_t)img * 128 + h * 32 + d) * 2]) / kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1];
-        dqkv[pix * 384 + 128 + h * 32 + d] = ks * (dks * inv_n - T[(size_t)img * 128 + h * 32 + d]);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) dv[e] += ks * dp[d * 32 + e];
+        // q_s = scale * s  =>  dq_d = scale * s_d * (dqs_d - sum_j s_j dqs_j) = qs_d * (dqs_d - dot / scale)
+        dqkv[pix * 384 + h * 32 + d] = qs[o + d] * (dqs[o + d] - dot * 5.656854249492381f);
+        dqkv[pix * 384 + 128 + h * 32 + d] = ks[o + d] * (dks[o + d] - T[(size_t)img * 128 + h * 32 + d]);
+        dqkv[pix * 384 + 256 + h * 32 + d] = dv[o + d];
     }
-#pragma unroll
-    for (int d = 0; d < 32; ++d) dqkv[pix * 384 + h * 32 + d] = 0.17677669529663687f * s[d] * (dqs[d] - dot);
-#pragma unroll
-    for (int e = 0; e < 32; ++e) dqkv[pix * 384 + 256 + h * 32 + e] = dv[e] * inv_n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
