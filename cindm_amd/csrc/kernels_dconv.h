@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
             Img[1][(ks * 4 + kq) * RPAD + row] = z;
         }
     }
-#pragma unroll
-    for (int j = 0; j < KPW0; ++j) store_raw(g0, j, raw0[j]);
+    // (the staged rows are written to LDS k-step by k-step inside the K loop: the MFMAs of k-step 0 start as soon as its
+    // six loads have landed, the rest of the tile streams in behind them)
 
     f32x4 accM[3][2], accL[3][2], accRM[3][2], accRL[3][2];
 #pragma unroll
@@ -261,18 +261,18 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         constexpr std::true_type PFY{};
         constexpr std::false_type PFN{};
         if constexpr (KPW1 == 0) {
-#pragma unroll 1
-            for (int j = 0; j < KPW0 - 1; ++j) kstep(j, j + 1, PFY);
+#pragma unroll
+            for (int j = 0; j < KPW0 - 1; ++j) { store_raw(g0, j, raw0[j]); kstep(j, j + 1, PFY); }
             l2_prefetch(a.pf, pfr);
+            store_raw(g0, KPW0 - 1, raw0[KPW0 - 1]);
             kstep(KPW0 - 1, 0, PFN);
         } else {
-#pragma unroll 1
-            for (int j = 0; j < KPW0; ++j) kstep(j, j + 1, PFY);
 #pragma unroll
-            for (int j = 0; j < KPW1; ++j) store_raw(g1, j, raw1[j]);
-#pragma unroll 1
-            for (int j = 0; j < KPW1 - 1; ++j) kstep(j, KPW0 + j + 1, PFY);
+            for (int j = 0; j < KPW0; ++j) { store_raw(g0, j, raw0[j]); kstep(j, j + 1, PFY); }
+#pragma unroll
+            for (int j = 0; j < KPW1 - 1; ++j) { store_raw(g1, j, raw1[j]); kstep(j, KPW0 + j + 1, PFY); }
             l2_prefetch(a.pf, pfr);
+            store_raw(g1, KPW1 - 1, raw1[KPW1 - 1]);
             kstep(KPW1 - 1, 0, PFN);
         }
     }
