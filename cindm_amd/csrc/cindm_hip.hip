@@ -78,6 +78,7 @@ struct cindm_unet1d {
     std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
+    int generation = 0;                    // bumped by every (re)pack: captured graphs that embed this handle's pointers check it
     bool force_f32 = false;                // calibration forward overflowed on the split-fp16 kernels: fp32 MFMA kernels in use
     bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
     // kernel-path options (cindm_unet1d_set_option; defaults = the fast path, overridable by CINDM_* at create)
@@ -1472,6 +1473,7 @@ static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
     emit_forward(D, nullptr, nullptr);
     h->launches = D.launches;
     h->pf_table = regs;
+    ++h->generation;
     h->finalized = true;
     return 0;
 }
@@ -1649,6 +1651,19 @@ struct cindm_ddpm1d {
     int* t_dev = nullptr;        // device step state used by the sample loops: [0] = t, [1] = block counter, [2] = DDIM step index
     hipStream_t own = nullptr;   // capture stream used when the caller passes the legacy default stream
     float* ddim_buf = nullptr; int ddim_cap = 0;      // DDIM tables: [cap][4] floats then [cap] ints
+    // the instantiated graph of the last captured step and everything it embeds (handles + their pack generation,
+    // descriptor, tensor / workspace pointers, batch): a loop with the same key replays it without a new capture
+    std::vector<unsigned char> gkey; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    void drop_graph() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        gexec = nullptr; graph = nullptr; gkey.clear();
+    }
+};
+
+struct KeyBuilder {
+    std::vector<unsigned char> k;
+    template <typename T> KeyBuilder& operator()(const T& v) { const auto* p = reinterpret_cast<const unsigned char*>(&v); k.insert(k.end(), p, p + sizeof(T)); return *this; }
 };
 
 extern "C" int cindm_ddpm1d_create(const cindm_sched_desc* d, cindm_ddpm1d** out) {
@@ -1675,6 +1690,7 @@ extern "C" void cindm_ddpm1d_destroy(cindm_ddpm1d* h) {
     if (!h) return;
     if (h->tab) (void)hipFree(h->tab);
     if (h->t_dev) (void)hipFree(h->t_dev);
+    h->drop_graph();
     if (h->own) (void)hipStreamDestroy(h->own);
     if (h->ddim_buf) (void)hipFree(h->ddim_buf);
     delete h;
@@ -1759,6 +1775,7 @@ struct StepIO {
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
     int dec_t;              // sample loop: decrement the device step counter at the end of the step
     const float* ddim_tab; const int* ddim_tnext;      // DDIM loop: per-step coefficient / time_next tables (device)
+    const unsigned long long* dyn;                     // sample loops: (seed, sample_off) live in device memory
     const cindm_design_desc* dz;                       // built-in design objective (guided loop) or null
     int relax; const float* recur_noise; int64_t recur_t_stride; uint32_t recur_tag;
     const float* iso; int iso_steps;
@@ -1807,6 +1824,7 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.t_ptr = t_dev; a.t_imm = t;
     a.mean_out = io.mean_out; a.x0_out = io.x0_out; a.eps_out = io.eps_out; a.x_out = io.x_out;
     a.noise = io.noise; a.noise_t_stride = io.noise_t_stride; a.seed = io.seed; a.sample_off = io.sample_off; a.add_noise = io.add_noise;
+    a.dyn = io.dyn;
     a.inp_cond = io.inp_cond; a.inp_steps = io.inp_steps; a.inp_noise = io.inp_noise; a.inp_noise_t_stride = io.inp_noise_t_stride;
     if (io.ddim_tab) { a.ddim_tab = io.ddim_tab; a.ddim_tnext = io.ddim_tnext; a.step_idx = h->t_dev + 2; }
     const bool guided = io.dz && io.x_out;
@@ -1865,19 +1883,64 @@ extern "C" int cindm_ddpm1d_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet
     return run_step(h, pair, uncond, c, io, t, t_dev, B, ws, ws_bytes, (hipStream_t)stream);
 }
 
-__global__ void set_counter_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = v; p[1] = 0; p[2] = 0; } }
+// t_dev block: [0] t, [1] unused, [2] DDIM step index; bytes 64..79: (seed, sample_off) read by the update kernel of a loop
+__global__ void set_counter_kernel(int* p, int v, unsigned long long seed, long long sample_off) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        p[0] = v; p[1] = 0; p[2] = 0;
+        unsigned long long* dyn = reinterpret_cast<unsigned long long*>(p + 16);
+        dyn[0] = seed; dyn[1] = (unsigned long long)sample_off;
+    }
+}
 // the sample loops end with a handle whose epoch has been advanced for a step that never runs: harmless (the next
 // forward simply uses that epoch), but the flag must describe the stream-ordered truth, so loops clear nothing.
 
 
 // start of a sample loop: set the device step counter and advance the U-Nets' exchange epochs once, eagerly, so that the
 // captured step carries no epoch launch (its counter kernel advances them for the following step)
-static void start_loop(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c, int t0, hipStream_t stream) {
-    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, t0);
+static void start_loop(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c, int t0, hipStream_t stream,
+                       uint64_t seed = 0, int64_t sample_off = 0) {
+    hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, t0, (unsigned long long)seed, (long long)sample_off);
     if (pair->epoch_dev) { hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, stream, pair->epoch_dev); pair->epoch_prebumped = true; }
     if (c->mode == CINDM_COMPOSE_MULTIBODY && uncond && uncond->epoch_dev) {
         hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, stream, uncond->epoch_dev); uncond->epoch_prebumped = true;
     }
+}
+
+// run one captured step n times (graph) or launch it n times (stream); shared tail of the sample loops.  The
+// instantiated graph is kept in the handle and reused while `key` (everything the captured launches embed) is unchanged.
+template <typename StepFn>
+static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, hipStream_t stream, int nsteps, int use_graph, StepFn step) {
+    if (!use_graph) {
+        for (int i = 0; i < nsteps; ++i) if (step() != 0) return -1;
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (!(h->gexec && h->gkey == key)) {
+        h->drop_graph();
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = step();
+        hipError_t ce = hipStreamEndCapture(stream, &graph);
+        if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
+        if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        h->graph = graph; h->gexec = exec; h->gkey = key;
+    }
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < nsteps && le == hipSuccess; ++i) le = hipGraphLaunch(h->gexec, stream);
+    hipError_t se = hipStreamSynchronize(stream);
+    if (le != hipSuccess) { h->drop_graph(); return fail(std::string("hipGraphLaunch: ") + hipGetErrorString(le)); }
+    if (se != hipSuccess) { h->drop_graph(); return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se)); }
+    return 0;
+}
+
+static void key_common(KeyBuilder& K, int kind, const cindm_unet1d* pair, const cindm_unet1d* uncond, const cindm_compose_desc* c, const StepIO& io,
+                       int64_t B, const void* ws, size_t ws_bytes) {
+    K(kind)(pair)(pair->generation)(uncond)(uncond ? uncond->generation : 0)(*c)(B)(ws)(ws_bytes);
+    K(io.x)(io.cond)(io.x_out)(io.noise)(io.noise_t_stride)(io.add_noise)(io.inp_cond)(io.inp_steps)(io.inp_noise)(io.inp_noise_t_stride);
+    K(io.ddim_tab)(io.ddim_tnext)(io.iso)(io.iso_steps)(io.recur_t_stride);
 }
 
 extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -1904,60 +1967,12 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1;
     if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
-    start_loop(h, pair, uncond, c, (int)t_start, stream);
-    const int nsteps = t_start - t_end + 1;
-    if (!use_graph) {
-        for (int i = 0; i < nsteps; ++i) {
-            if (run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream) != 0) return -1;
-        }
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    int rc = run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream);
-    hipError_t ce = hipStreamEndCapture(stream, &graph);
-    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
-    if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-    hipError_t le = hipSuccess;
-    for (int i = 0; i < nsteps && le == hipSuccess; ++i) le = hipGraphLaunch(exec, stream);
-    // the exec object must outlive its launches: wait before destroying it
-    hipError_t se = hipStreamSynchronize(stream);
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
-    if (le != hipSuccess) return fail(std::string("hipGraphLaunch: ") + hipGetErrorString(le));
-    if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
-    return 0;
-}
-
-// run one captured step n times (graph) or launch it n times (stream); shared tail of the sample loops
-template <typename StepFn>
-static int replay_steps(hipStream_t stream, int nsteps, int use_graph, StepFn step) {
-    if (!use_graph) {
-        for (int i = 0; i < nsteps; ++i) if (step() != 0) return -1;
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    int rc = step();
-    hipError_t ce = hipStreamEndCapture(stream, &graph);
-    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
-    if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-    hipError_t le = hipSuccess;
-    for (int i = 0; i < nsteps && le == hipSuccess; ++i) le = hipGraphLaunch(exec, stream);
-    hipError_t se = hipStreamSynchronize(stream);
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
-    if (le != hipSuccess) return fail(std::string("hipGraphLaunch: ") + hipGetErrorString(le));
-    if (se != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
-    return 0;
+    io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
+    start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
+    KeyBuilder K;
+    key_common(K, 0, pair, uncond, c, io, B, ws, ws_bytes);
+    return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph,
+                        [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
 }
 
 extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -1998,8 +2013,11 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
     if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
-    start_loop(h, pair, uncond, c, (int)times[0], stream);
-    return replay_steps(stream, n_steps, use_graph,
+    io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
+    start_loop(h, pair, uncond, c, (int)times[0], stream, seed, sample_offset);
+    KeyBuilder K;
+    key_common(K, 1, pair, uncond, c, io, B, ws, ws_bytes);
+    return replay_steps(h, K.k, stream, n_steps, use_graph,
                         [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
 }
 
@@ -2033,7 +2051,8 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
     io.dz = dz; io.iso = initial_state_overwrite; io.iso_steps = initial_state_overwrite ? overwrite_steps : 0;
     io.recur_t_stride = (int64_t)(R > 0 ? R : 1) * B * Ltot * F;
     if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
-    start_loop(h, pair, uncond, c, (int)t_start, stream);
+    io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
+    start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
     // one reverse step (:1286-1370): R x [p_mean_variance, mean - grad, overwrite, relaxation]; the last iteration's
     // relaxation is never used by the reference, its pred + sigma z is the step's result
     auto step = [&]() -> int {
@@ -2048,7 +2067,10 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
         }
         return 0;
     };
-    return replay_steps(stream, t_start - t_end + 1, use_graph, step);
+    KeyBuilder K;
+    key_common(K, 2, pair, uncond, c, io, B, ws, ws_bytes);
+    K(*dz)(recur_noise_steps)(R);
+    return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph, step);
 }
 
 extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed, int64_t sample_offset,

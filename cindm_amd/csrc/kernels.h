@@ -2703,6 +2703,7 @@ struct ComposeArgs {
     float* x_out;                                      // step: x_{t-1} (may alias x)
     const float* noise; int64_t noise_t_stride;        // explicit noise (+ t * stride), or null
     uint64_t seed; int64_t sample_off; int add_noise;
+    const unsigned long long* dyn;      // sample loops: (seed, sample_off) in device memory, so that a captured step is reusable across calls
     const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
     int* t_dec; unsigned* done;     // unused by the kernel: the host launches step_counter_kernel after the update
     // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
@@ -2772,6 +2773,8 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
     const int sidx = a.ddim_tab ? *a.step_idx : 0;
+    const uint64_t dseed = a.dyn ? (uint64_t)a.dyn[0] : a.seed;
+    const int64_t dsoff = a.dyn ? (int64_t)a.dyn[1] : a.sample_off;
     if (i < a.B * (int64_t)a.Ltot * a.F) {
     const int f = (int)(i % a.F);
     const int lx = (int)((i / a.F) % a.Ltot);
@@ -2887,19 +2890,19 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         if (a.relax) {
             const float ratio = a.ac[t] / a.acp[t];
             const float z = a.recur_noise ? a.recur_noise[(size_t)t * a.recur_t_stride + i]
-                                          : counter_normal(a.seed ^ 0x7f4a7c15u, (uint64_t)(a.sample_off + b), a.recur_tag + (uint32_t)t, el);
+                                          : counter_normal(dseed ^ 0x7f4a7c15u, (uint64_t)(dsoff + b), a.recur_tag + (uint32_t)t, el);
             v = sqrtf(ratio) * pred + sqrtf(1.0f - ratio) * z;
         } else {
             v = pred;
             if (a.add_noise && t > 0) {
                 const float z = a.noise ? a.noise[(size_t)t * a.noise_t_stride + i]
-                                        : counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                                        : counter_normal(dseed, (uint64_t)(dsoff + b), (uint32_t)t, el);
                 v += expf(0.5f * a.logvar[t]) * z;
             }
             if (a.inp_cond && lx < a.inp_steps) {
                 const size_t ci = ((size_t)b * a.inp_steps + lx) * a.F + f;
                 const float z = a.inp_noise ? a.inp_noise[(size_t)t * a.inp_noise_t_stride + ci]
-                                            : counter_normal(a.seed ^ 0x5bd1e995u, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                                            : counter_normal(dseed ^ 0x5bd1e995u, (uint64_t)(dsoff + b), (uint32_t)t, el);
                 v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z;
             }
         }
@@ -2912,12 +2915,12 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         if (tn >= 0) {
             const float san = a.ddim_tab[4 * sidx], cc = a.ddim_tab[4 * sidx + 1], sg = a.ddim_tab[4 * sidx + 2];
             const float z = a.noise ? a.noise[(size_t)sidx * a.noise_t_stride + i]
-                            : (sg != 0.f ? counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, el) : 0.f);
+                            : (sg != 0.f ? counter_normal(dseed, (uint64_t)(dsoff + b), (uint32_t)t, el) : 0.f);
             v = __fadd_rn(__fadd_rn(__fmul_rn(x0, san), __fmul_rn(cc, eps)), __fmul_rn(sg, z));
             if (a.inp_cond && lx < a.inp_steps) {      // inpainting overwrite with q_sample(cond, time) (:1790-1793)
                 const size_t ci = ((size_t)b * a.inp_steps + lx) * a.F + f;
                 const float z2 = a.inp_noise ? a.inp_noise[(size_t)sidx * a.inp_noise_t_stride + ci]
-                                             : counter_normal(a.seed ^ 0x5bd1e995u, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                                             : counter_normal(dseed ^ 0x5bd1e995u, (uint64_t)(dsoff + b), (uint32_t)t, el);
                 v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z2;
             }
         }
@@ -2927,13 +2930,13 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         const uint32_t el = (uint32_t)(lx * a.F + f);
         if (a.add_noise && t > 0) {
             const float z = a.noise ? a.noise[(size_t)t * a.noise_t_stride + i]
-                                    : counter_normal(a.seed, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                                    : counter_normal(dseed, (uint64_t)(dsoff + b), (uint32_t)t, el);
             v += expf(0.5f * a.logvar[t]) * z;
         }
         if (a.inp_cond && lx < a.inp_steps) {      // inpainting overwrite (:1715-1718)
             const size_t ci = ((size_t)b * a.inp_steps + lx) * a.F + f;
             const float z = a.inp_noise ? a.inp_noise[(size_t)t * a.inp_noise_t_stride + ci]
-                                        : counter_normal(a.seed ^ 0x5bd1e995u, (uint64_t)(a.sample_off + b), (uint32_t)t, el);
+                                        : counter_normal(dseed ^ 0x5bd1e995u, (uint64_t)(dsoff + b), (uint32_t)t, el);
             v = a.sqrt_ac[t] * a.inp_cond[ci] + a.sqrt_1mac[t] * z;
         }
         a.x_out[i] = v;
