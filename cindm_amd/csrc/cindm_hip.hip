@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "kernels_dconv.h"
 #include "kernels2d.h"
+#include "kernels2d_v2.h"
 #include "../../include/cindm_hip.h"
 
 #include <hip/hip_ext.h>

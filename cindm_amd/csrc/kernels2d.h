@@ -37,7 +37,7 @@ struct Conv2dArgs {
     int tiles_x, tpi;     // tiles per image row / per image
     float* out; int ldo;
     const float* res; int ldres;
-    const float* e_y; int e_ld; const float* e_stats; int e_gw; float e_cnt; const float* e_gamma; const float* e_beta;
+    const float* e_y; int e_ld; const float* e_stats; int e_P; int e_gw; float e_cnt; const float* e_gamma; const float* e_beta;
     float* stats_out; int so_gw;        // GroupNorm (mean, M2) partials per tile: [NI][8][tpi][2]
     float* ln_out;                      // LayerNorm partials per pixel and 32-column block: [rows][Npad/32][2]
     const int* t_ptr; int t_imm;
@@ -52,6 +52,39 @@ __device__ __forceinline__ float silu_f(float x) {
     // x * sigmoid(x); exp2-based, one v_exp_f32 + one v_rcp_f32
     const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Wave-parallel merge of the P equal-count (mean, M2) partials of the 8 groups of one image: st = [8][P][2], lane =
+// group * 8 + j, every lane returns its group's (mean, rstd).  Same formula as merge_stats.
+__device__ __forceinline__ void merge_stats8(const float* __restrict__ st, int P, float cnt, int lane, float& mean, float& rstd) {
+    const float2* p = reinterpret_cast<const float2*>(st) + (size_t)(lane >> 3) * P;
+    const int j = lane & 7;
+    float s = 0.f;
+    for (int t = j; t < P; t += 8) s += p[t].x;
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    const float m = s / (float)P;
+    float q = 0.f;
+    for (int t = j; t < P; t += 8) { const float2 v = p[t]; const float d = v.x - m; q += v.y + cnt * d * d; }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    mean = m;
+    rstd = 1.0f / sqrtf(q / (cnt * (float)P) + 1e-5f);
+}
+
+// Value of lane 8 i + 7 (i = 0 .. 7 may differ per lane) without LDS-pipeline instructions: eight v_readlane + a select
+// chain.  With seg_total(v, 8) in front this is "the total of 8-lane group i" -- the shuffle-free twin of merge_stats8's
+// butterflies, used by the memory waves of conv2d_ws_kernel (their ds_bpermutes would queue behind the matrix waves'
+// fragment reads).  No arrays: a dynamically indexed private array is promoted to LDS by the compiler.
+__device__ __forceinline__ float group8_total(float v, int i) {
+    const int b = __builtin_bit_cast(int, v);
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 7));
+    r = (i == 1) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 15)) : r;
+    r = (i == 2) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 23)) : r;
+    r = (i == 3) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 31)) : r;
+    r = (i == 4) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 39)) : r;
+    r = (i == 5) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 47)) : r;
+    r = (i == 6) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 55)) : r;
+    r = (i == 7) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 63)) : r;
+    return r;
 }
 
 template <int KIND> struct Cfg2 {
@@ -291,16 +324,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_tile_kernel(const Conv2dArgs a)
 
     if constexpr (MODE == SRC2_GN_SS_SILU) {
         const Src& s = a.src[0];
-        if (tid < 8) {
+        if (w == 0) {                                          // per-tile partials [img][8][P][2], merged here
             float m, r;
-            merge_stats(s.stats + ((size_t)img * 8 + tid) * 2, 1, s.cnt, 1e-5f, m, r);
-            tabA[2 * tid] = m; tabA[2 * tid + 1] = r;
+            merge_stats8(s.stats + (size_t)img * 8 * s.P * 2, s.P, s.cnt, lane, m, r);
+            if ((lane & 7) == 0) { tabA[2 * (lane >> 3)] = m; tabA[2 * (lane >> 3) + 1] = r; }
         }
     }
-    if (a.e_y && tid >= 64 && tid < 72) {
+    if (a.e_y && w == 1) {
         float m, r;
-        merge_stats(a.e_stats + ((size_t)img * 8 + (tid - 64)) * 2, 1, a.e_cnt, 1e-5f, m, r);
-        tabE[2 * (tid - 64)] = m; tabE[2 * (tid - 64) + 1] = r;
+        merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
+        if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
     }
     const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
 
@@ -543,16 +576,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
     load_a(0);
     if constexpr (MODE == SRC2_GN_SS_SILU) {
         const Src& s = a.src[0];
-        if (tid < 8) {
+        if (w == 0) {                                          // per-tile partials [img][8][P][2], merged here
             float m, r;
-            merge_stats(s.stats + ((size_t)img * 8 + tid) * 2, 1, s.cnt, 1e-5f, m, r);
-            tabA[2 * tid] = m; tabA[2 * tid + 1] = r;
+            merge_stats8(s.stats + (size_t)img * 8 * s.P * 2, s.P, s.cnt, lane, m, r);
+            if ((lane & 7) == 0) { tabA[2 * (lane >> 3)] = m; tabA[2 * (lane >> 3) + 1] = r; }
         }
     }
-    if (a.e_y && tid >= 64 && tid < 72) {
+    if (a.e_y && w == 1) {
         float m, r;
-        merge_stats(a.e_stats + ((size_t)img * 8 + (tid - 64)) * 2, 1, a.e_cnt, 1e-5f, m, r);
-        tabE[2 * (tid - 64)] = m; tabE[2 * (tid - 64) + 1] = r;
+        merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
+        if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
     }
     const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
 
@@ -846,10 +879,10 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
     };
     load_w(it_lo, wA);
     if constexpr (EPI) {
-        if (a.e_y && tid >= 64 && tid < 72) {
+        if (a.e_y && w == 1) {
             float m, r;
-            merge_stats(a.e_stats + ((size_t)img * 8 + (tid - 64)) * 2, 1, a.e_cnt, 1e-5f, m, r);
-            tabE[2 * (tid - 64)] = m; tabE[2 * (tid - 64) + 1] = r;
+            merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
+            if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
         }
     }
     // staging: all global loads first (registers), then -- LayerNorm mode -- one statistics merge per row into an LDS

@@ -1,0 +1,366 @@
+// conv2d_ws_kernel<KIND, MODE>: second generation of the 2-D 3x3 convolution (model/diffusion_2d.py:182-198 Block.proj,
+// :99-103 Upsample's conv over the nearest-x2 source) on the split-fp16 products of kernels.h.  gfx950 only.
+//
+// What round 2's profile of conv2d_h3_kernel showed (profiles/r02_cfg5_phases.txt): prologue (load + split, 1.0 ms per
+// step), main loop (2.2 ms) and epilogue (0.8 ms) ADD UP -- two co-resident workgroups of 4 waves do not overlap their
+// memory phases with each other's MFMA phase; the main loop itself is short (1.4 us of matrix work per 64-pixel tile)
+// against ~5 us of load latency + split + store per tile.  A larger tile in the same structure (8 x 16 pixels, measured:
+// 165 -> 148 us per 64 -> 64 layer at 64 x 64) does not change that.  Hence a persistent, wave-specialised kernel:
+//
+//  * one workgroup of 8 waves per CU, 256 workgroups, each looping over its list of (pixel tile, n-tile, chunk) items;
+//  * waves 0-3 ("matrix waves", one per SIMD) only multiply: output tile 8 x 16 pixels x 64 channels, wave = (k-group,
+//    column half), 8 pixel blocks per wave (every B fragment fetched from L2 feeds 16 MFMA triples), A fragments from
+//    the LDS planes one pixel block at a time, two blocks ahead, B in a 3-tap register ring that runs across items; the
+//    accumulators are defined by tap 0 of a tile's first chunk (zero C operand), so nothing is initialised;
+//  * waves 4-7 ("memory waves", one per SIMD) do everything else WHILE the matrix waves multiply item k, two items deep:
+//    normalise / SiLU / split item k+1's window (10 x 18 pixels x 64 channels, loaded during phase k-1) into the other LDS
+//    plane buffer, THEN issue item k+2's global loads into the same registers, THEN write the finished tile of the
+//    previous item from LDS to HBM as float4 rows (+ its GroupNorm partials).  vmcnt retires in order, so with the
+//    stores issued after the loads no wait for a load ever covers a store (with the stores first, staging waited for
+//    HBM write acknowledgements: 138 -> 123 us per layer);
+//  * three workgroup barriers per finished tile: [multiply | stage-load-store] -> kg = 1 waves park their partial tile in
+//    LDS -> kg = 0 waves add theirs + bias in place -> next item;
+//  * GroupNorm statistics travel as per-(tile, memory wave) partials (32 pixels each; no cross-wave reduction in the
+//    store path) and the consumer merges them itself -- the gn_merge_kernel launches are gone.  Inside this kernel the
+//    merge uses DPP row sums + v_readlane + a select chain (group8_total), NOT ds_bpermute shuffles: with __shfl in the
+//    memory waves, one run in ~5 staged a stale window pixel (3 wrong output pixels per incident, tools/dbg_ws2.py
+//    reproduces it with conv_ws = 1 and merge_stats8); without LDS-pipeline instructions in that path, 0 of 450 runs;
+//  * XCD x (workgroup % 8) owns a contiguous eighth of the tile list, its 32 workgroups walk it side by side, so halos
+//    and both n-tiles' input hit that XCD's L2.
+// LDS: 2 plane buffers x 51 840 B + 34 816 B output tile = 138.5 KB.
+//
+// Measured (config 5, 128 images, wall_clock64 inside the kernel, per 64 x 64 layer of 16 tiles per workgroup): plain
+// source: multiply 78-82 us (3.6 us per tile when a workgroup has ONE tile, 5 us with the memory waves active),
+// reduce 28 us, barrier wait 9 us; memory waves 85 us of work.  GroupNorm + SiLU on load: the staging VALU /
+// transcendental work (84 us) is the long pole and the matrix waves wait 55 us -- s_setprio on either side changes
+// nothing.  Layer times: 64 -> 64 plain 165 -> 123 us, GroupNorm 197 -> 176 us, 128 -> 64 240 -> 198 us.
+#pragma once
+#include "kernels2d.h"
+#include <type_traits>
+
+namespace cindm {
+
+constexpr int V2Y = 8, V2X = 16, V2M = V2Y * V2X;          // output pixel tile
+constexpr int V2SW = 18, V2R = 10 * V2SW;                   // staged window 10 x 18 pixels
+constexpr int V2PITCH = 144, V2PLANE = V2R * V2PITCH;       // bytes per staged pixel and plane (64 halfs + 16 B pad)
+constexpr int V2LDT = 68;                                   // output tile pitch (floats)
+constexpr int WS_GRID = 256;                                // one persistent workgroup per CU
+constexpr int WS_SPT = 4;                                   // GroupNorm partials per tile (one per memory wave, 32 pixels)
+constexpr int WS_MAXP = 128;                                // most GroupNorm partials per (image, group) the consumer side holds
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
+    constexpr int KC = 64, NP = 12;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * V2PLANE];   // [buffer][plane hi/lo][V2R][V2PITCH]
+    __shared__ __attribute__((aligned(16))) float Tile[V2M * V2LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = w >> 2, lw = w & 3;
+    // ---- this workgroup's items -----------------------------------------------------------------------------------
+    const int ntiles = a.Npad / T2N, nch = a.CinP / KC, ipt = ntiles * nch;      // items per pixel tile
+    const int MT = a.NI * a.tpi;
+    const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int lo = (int)(((long long)xcd * MT) >> 3), hi = (int)(((long long)(xcd + 1) * MT) >> 3);
+    const int mine = hi - lo > wj ? (hi - lo - wj + wpx - 1) / wpx : 0;
+    if (mine == 0) return;
+    const int nitems = mine * ipt;
+    const int HWi = a.Hin * a.Win;
+    const int nch0 = (a.src[0].C + KC - 1) / KC;
+    auto decode = [&](int k, int& mt, int& nt, int& ch) {
+        const int tl = k / ipt, rem = k - tl * ipt;
+        nt = rem / nch; ch = rem - nt * nch;
+        mt = lo + wj + tl * wpx;
+    };
+
+    if (role == 0) {
+        // =========================================== matrix waves ==================================================
+        const int kg = lw & 1, nh = lw >> 1;
+        if (MODE != SRC2_GN_SS_SILU) __builtin_amdgcn_s_setprio(3);   // plain source: the matrix pipe is the long pole -> it goes first
+        f32x4 accM[8][2], accL[8][2];
+        half8 breg[3][2][2];
+        // B: [n-tile][chunk][tap][q = nb*2 + plane][thread][8 halfs] (the pack of conv2d_h3_kernel: same wave roles)
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + lw * 64 + lane;
+        auto load_b = [&](int nt, int ch, int tap, int slot_) {
+            const uint4* wp = wbase + ((size_t)(nt * nch + ch) * 9 + tap) * 4 * 256;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) breg[slot_][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+        };
+        const int foff = (lane & 15) * V2PITCH + kg * 64 + (lane >> 4) * 16;
+        // 72 steps (tap, pixel block); fragments of step s + 2 are read while step s multiplies
+        auto compute = [&](const unsigned char* P0, int nt, int ch, int nt2, int ch2, auto FIRST_) {
+            constexpr bool FIRST = decltype(FIRST_)::value;
+            const unsigned char* P1 = P0 + V2PLANE;
+            half8 fh[3], fl[3];
+            auto read_frag = [&](int s, int slot_) {
+                const int tap = s >> 3, mb = s & 7;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                fh[slot_] = *reinterpret_cast<const half8*>(P0 + ((mb + dy) * V2SW + dx) * V2PITCH);
+                fl[slot_] = *reinterpret_cast<const half8*>(P1 + ((mb + dy) * V2SW + dx) * V2PITCH);
+            };
+            read_frag(0, 0); read_frag(1, 1);
+#pragma unroll
+            for (int s = 0; s < 72; ++s) {
+                const int tap = s >> 3, mb = s & 7, bs = tap % 3, fs = s % 3;
+                if (s + 2 < 72) read_frag(s + 2, (s + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bool z = FIRST && tap == 0;
+                // the two products into accL of one column block are kept three instructions apart
+                accM[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][0][0], z ? zero : accM[mb][0], 0, 0, 0);
+                accL[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][0][1], z ? zero : accL[mb][0], 0, 0, 0);
+                accM[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][1][0], z ? zero : accM[mb][1], 0, 0, 0);
+                accL[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][1][1], z ? zero : accL[mb][1], 0, 0, 0);
+                accL[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][0][0], accL[mb][0], 0, 0, 0);
+                accL[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][1][0], accL[mb][1], 0, 0, 0);
+                if (mb == 7) {                               // this slot's next tap (of this or the next item), two taps ahead
+                    if (tap + 3 < 9) load_b(nt, ch, tap + 3, bs);
+                    else load_b(nt2, ch2, tap + 3 - 9, bs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        load_b(0, 0, 0, 0); load_b(0, 0, 1, 1); load_b(0, 0, 2, 2);
+        __syncthreads();                                     // S0: item 0 is staged
+        // tile -> n-tile -> chunk: the same item order as decode(); nested so that the accumulators are defined by the
+        // first chunk's tap 0 (zero C operand), updated by the other chunks and consumed by the reduce below
+        int k = 0;
+        for (int tl = 0; tl < mine; ++tl)
+            for (int nt = 0; nt < ntiles; ++nt) {
+                {
+                    const int nt2 = nch > 1 ? nt : (nt + 1 < ntiles ? nt + 1 : 0), ch2 = nch > 1 ? 1 : 0;
+                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, 0, nt2, ch2, std::true_type{});
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    }
+                    ++k;
+                    __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
+                }
+                for (int ch = 1; ch < nch; ++ch) {
+                    const int nt2 = ch + 1 < nch ? nt : (nt + 1 < ntiles ? nt + 1 : 0), ch2 = ch + 1 < nch ? ch + 1 : 0;
+                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
+                    ++k;
+                    __syncthreads();                         // S1
+                }
+                const int tcol = nh * 32 + (lane & 15), trow = (lane >> 4) * 4;
+                if (kg == 1) {
+#pragma unroll
+                    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg)
+                                Tile[(mb * 16 + trow + rg) * V2LDT + tcol + nb * 16] = accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV;
+                }
+                __syncthreads();                             // S2
+                if (kg == 0) {
+                    float bias[2];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const int gn = nt * T2N + tcol + nb * 16;
+                        bias[nb] = (a.bias && gn < a.N) ? a.bias[gn] : 0.f;
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                float* tp = Tile + (mb * 16 + trow + rg) * V2LDT + tcol + nb * 16;
+                                *tp = (*tp + (accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV)) + bias[nb];
+                            }
+                }
+                __syncthreads();                             // S3: the finished tile is in LDS
+            }
+        return;
+    }
+
+    // ============================================== memory waves ===================================================
+    // kernel arguments the loop needs, as locals (the argument block is 600+ bytes: left alone, the compiler re-reads
+    // fields through s_load inside the loop); element offsets are 32-bit (host: images * pixels * channels < 2^31)
+    if (MODE == SRC2_GN_SS_SILU) __builtin_amdgcn_s_setprio(3);       // GroupNorm + SiLU on load: the staging VALU work is the long pole
+    const int lt = tid - 256;
+    const int c4 = lt & 15, r0 = lt >> 4;                    // staging: float4 c4 of window pixels r0 + 16 p
+    const int tpi = a.tpi, tiles_x = a.tiles_x, Hout = a.Hout, Wout = a.Wout, Win = a.Win, ldo = a.ldo, N = a.N;
+    const int nsrc = a.nsrc, C0 = a.src[0].C, C1 = a.src[1].C, ld0 = a.src[0].ld, ld1 = a.src[1].ld;
+    const float* const sp0 = a.src[0].p;
+    const float* const sp1 = a.src[1].p;
+    float* const outp = a.out;
+    float* const stats_out = a.stats_out;
+    const int so_gw = a.so_gw, dbg = a.dbg;
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
+    const float* const gn_stats = a.src[0].stats;
+    const int gn_P = a.src[0].P;
+    const float gn_cnt = a.src[0].cnt;
+    int hyx[NP];                                             // window row | column << 8 of this thread's 12 pixels
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { const int r = r0 + 16 * p; const int hy = r / V2SW; hyx[p] = hy | ((r - hy * V2SW) << 8); }
+    float4 areg[NP];
+    float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), psc = pb, psh = pb;
+    constexpr int MAXPV = WS_MAXP / 8;
+    float2 pv[MAXPV];                                        // GroupNorm partials lane & 7, + 8, ... of group lane >> 3
+    float4 fa = pg, fb = pb;                                 // GroupNorm + scale/shift folded per channel: y = v * fa + fb
+    int gsel = 0;
+    unsigned okmask = 0;
+    bool cok = true;
+    // issue the global loads of item (mt, ch): its window and, GroupNorm mode, the image's statistics partials
+    auto load_item = [&](int mt, int ch) {
+        const int img = mt / tpi, ti = mt - img * tpi;
+        const int tyi = ti / tiles_x;
+        const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
+        const bool first = (ch < nch0) || (nsrc == 1);
+        const int cl = (first ? ch : ch - nch0) * KC + c4 * 4;
+        const int Cc = first ? C0 : C1;
+        const int ld = first ? ld0 : ld1;
+        const float* base = first ? sp0 : sp1;
+        const int clc = min(cl, Cc - 4);
+        cok = cl < Cc;
+        okmask = 0;
+        const int ibase = img * HWi;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int y = ty0 - 1 + (hyx[p] & 255), x = tx0 - 1 + (hyx[p] >> 8);
+            const bool ok = (r0 + 16 * p < V2R) && ((unsigned)y < (unsigned)Hout) && ((unsigned)x < (unsigned)Wout);
+            const int srcpix = (KIND == CONV_UP2) ? (y >> 1) * Win + (x >> 1) : y * Win + x;
+            okmask |= ok ? (1u << p) : 0u;
+            areg[p] = *reinterpret_cast<const float4*>(base + (ibase + (ok ? srcpix : 0)) * ld + clc);
+        }
+        if constexpr (MODE == SRC2_GN_SS_SILU) {
+            const Src& s = a.src[0];
+            pg = *reinterpret_cast<const float4*>(s.gamma + clc);
+            pb = *reinterpret_cast<const float4*>(s.beta + clc);
+            if (s.tb) {
+                psc = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + clc);
+                psh = *reinterpret_cast<const float4*>(s.tb + (size_t)t_now * s.tb_ld + s.C + clc);
+            }
+            gsel = clc >> gw_shift;
+            const float2* pp = reinterpret_cast<const float2*>(gn_stats) + ((size_t)img * 8 + (lane >> 3)) * gn_P + (lane & 7);
+#pragma unroll
+            for (int i = 0; i < MAXPV; ++i) pv[i] = (lane & 7) + 8 * i < gn_P ? pp[8 * i] : make_float2(0.f, 0.f);
+        }
+    };
+    // GroupNorm (mean, rstd) of this thread's channels from the partials in pv: every memory wave merges for itself,
+    // without LDS-pipeline shuffles (DPP row sums, v_readlane of the 8 group totals, a select chain; merge_stats' formula)
+    auto finish_stats = [&]() {
+        if constexpr (MODE == SRC2_GN_SS_SILU) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXPV; ++i) s += pv[i].x;          // absent partials were loaded as zeros
+            s = seg_total(s, 8);                                  // group totals at lanes 7 (mod 8)
+            const float invP = 1.0f / (float)gn_P;
+            const float m = group8_total(s, lane >> 3) * invP;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXPV; ++i) {
+                const float d = pv[i].x - m;
+                q += ((lane & 7) + 8 * i < gn_P) ? pv[i].y + gn_cnt * d * d : 0.f;
+            }
+            q = seg_total(q, 8);
+            const float gm = group8_total(s, gsel) * invP;
+            const float gr = 1.0f / sqrtf(group8_total(q, gsel) / (gn_cnt * (float)gn_P) + 1e-5f);
+            // ((v - gm) gr g + b)(sc + 1) + sh  =  v fa + fb   (one fma per element in the staging loop)
+            const float sx = psc.x + 1.0f, sy = psc.y + 1.0f, sz = psc.z + 1.0f, sw = psc.w + 1.0f;
+            fa.x = gr * pg.x * sx; fa.y = gr * pg.y * sy; fa.z = gr * pg.z * sz; fa.w = gr * pg.w * sw;
+            fb.x = (pb.x - gm * gr * pg.x) * sx + psh.x; fb.y = (pb.y - gm * gr * pg.y) * sy + psh.y;
+            fb.z = (pb.z - gm * gr * pg.z) * sz + psh.z; fb.w = (pb.w - gm * gr * pg.w) * sw + psh.w;
+        }
+    };
+    auto store_item = [&](int buf) {
+        unsigned char* S0 = &smem[buf][0];
+        unsigned char* S1 = S0 + V2PLANE;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + 16 * p;
+            float4 v = areg[p];
+            if constexpr (MODE == SRC2_GN_SS_SILU) {
+                v.x = silu_f(__builtin_fmaf(v.x, fa.x, fb.x));
+                v.y = silu_f(__builtin_fmaf(v.y, fa.y, fb.y));
+                v.z = silu_f(__builtin_fmaf(v.z, fa.z, fb.z));
+                v.w = silu_f(__builtin_fmaf(v.w, fa.w, fb.w));
+            }
+            const bool ok = ((okmask >> p) & 1u) && cok;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            if (r < V2R) {
+                *reinterpret_cast<half4v*>(S0 + r * V2PITCH + c4 * 8) = hi;
+                *reinterpret_cast<half4v*>(S1 + r * V2PITCH + c4 * 8) = lo;
+            }
+        }
+    };
+    // the finished tile (mt, nt): wave lw stores tile pixels 32 lw .. 32 lw + 31 (two pixel rows) and their GroupNorm partial
+    auto write_tile = [&](int mt, int nt) {
+        const int img = mt / tpi, ti = mt - img * tpi;
+        const int tyi = ti / tiles_x;
+        const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
+        const int oc4 = lane & 15, q = lane >> 4;
+        const int col = nt * T2N + oc4 * 4;
+        const bool nok = col < N;                            // N is a multiple of 4 (host)
+        // tile pixel r = 32 lw + q + 4 j: row 2 lw + (j >> 2), column q + 4 (j & 3)
+        float* o0 = outp + ((img * Hout + ty0 + 2 * lw) * Wout + tx0 + q) * ldo + col;
+        const float* t0 = Tile + (32 * lw + q) * V2LDT + oc4 * 4;
+        float4 v[8];                                         // all eight LDS reads in flight before the first store
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(t0 + 4 * j * V2LDT);
+        if (nok && dbg != 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(o0 + ((j >> 2) * Wout + 4 * (j & 3)) * ldo) = v[j];
+        }
+        if (!stats_out) return;
+        // shifted sums about the group's first element of the wave's first pixel
+        const int gwt = so_gw;                               // 8 or 16 channels: 2 or 4 lanes (oc4) per group
+        const float K = Tile[32 * lw * V2LDT + ((oc4 * 4) & ~(gwt - 1))];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d0 = v[j].x - K, d1 = v[j].y - K, d2 = v[j].z - K, d3 = v[j].w - K;
+            s1 += (d0 + d1) + (d2 + d3);
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        s1 = dpp_add<0x111, 0xf>(s1); s2 = dpp_add<0x111, 0xf>(s2);                     // pairs of oc4 -> odd lanes
+        if (gwt >= 16) { s1 = dpp_add<0x112, 0xf>(s1); s2 = dpp_add<0x112, 0xf>(s2); }  // quads -> lanes 3 (mod 4)
+        s1 = xsum32(xsum16(s1)); s2 = xsum32(xsum16(s2));                                // the wave's 4 pixel phases
+        const int lpg = gwt >> 2;                            // lanes per group
+        if (lane < 16 && (oc4 & (lpg - 1)) == lpg - 1 && nok) {
+            const int g = col >> (31 - __builtin_clz(gwt));
+            const float ine = 1.0f / (float)(32 * gwt);      // a power of two: the products below are exact divisions
+            float* o = stats_out + (((size_t)img * 8 + g) * (tpi * WS_SPT) + ti * WS_SPT + lw) * 2;
+            const float mean_d = s1 * ine;
+            o[0] = K + mean_d;
+            o[1] = fmaxf(s2 - s1 * mean_d, 0.f);
+        }
+    };
+
+    // Software pipeline, two items deep: phase k (the matrix waves multiply item k) stages item k+1 from the registers
+    // loaded during phase k-1, THEN issues item k+2's loads into the same registers, THEN writes the previous tile.
+    // vmcnt retires in order: with the tile's stores issued after the loads, no wait for a load ever covers a store.
+    int mt, nt, ch, mtn, ntn, chn;
+    decode(0, mt, nt, ch);
+    load_item(mt, ch);
+    finish_stats();
+    store_item(0);
+    if (nitems > 1) { decode(1, mtn, ntn, chn); load_item(mtn, chn); }
+    __syncthreads();                                         // S0
+    int pmt = -1, pnt = 0;                                   // finished tile waiting in LDS
+    for (int k = 0; k < nitems; ++k) {
+        if (k + 1 < nitems && dbg != 5) { finish_stats(); store_item((k + 1) & 1); }
+        if (k + 2 < nitems && dbg != 2 && dbg != 5) { decode(k + 2, mtn, ntn, chn); load_item(mtn, chn); }
+        if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt); pmt = -1; }
+        __syncthreads();                                     // S1
+        if (ch == nch - 1) {
+            __syncthreads();                                 // S2
+            __syncthreads();                                 // S3
+            pmt = mt; pnt = nt;
+        }
+        if (k + 1 < nitems) decode(k + 1, mt, nt, ch);
+    }
+    if (pmt >= 0) write_tile(pmt, pnt);
+}
+
+}  // namespace cindm

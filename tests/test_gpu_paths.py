@@ -74,7 +74,7 @@ def test_unet1d_paths_chain_and_ragged(gold_dir, device, opts):
     assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
 
 
-@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}], ids=["mfma_f32", "la_site0"])
+@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}], ids=["mfma_f32", "la_site0", "conv_ws_0"])
 def test_unet2d_paths_golden(gold_dir, device, opts):
     from test_gpu_parity_2d import build_unet2d
     g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
@@ -84,6 +84,34 @@ def test_unet2d_paths_golden(gold_dir, device, opts):
     x = torch.from_numpy(g["x"]).to(device)
     for t in (0, 500, 999):
         assert rel(m(x, torch.full((2,), t, device=device)), g[f"eps_t{t}"]) < TOL_FWD, (opts, t)
+
+
+@pytest.mark.parametrize("conv_ws", [1, 2, 3], ids=["all", "plain_only", "groupnorm_only"])
+def test_unet2d_conv_ws_repeatable(device, conv_ws):
+    """The persistent wave-specialised 3x3 kernel (conv2d_ws_kernel) is a producer / consumer pipeline inside one
+    workgroup: 40 repeats of one forward must be bit-identical, block by block (a stale window pixel in its staging
+    showed up as 3 wrong output pixels in about one run of five while it was being written), and agree with the
+    per-tile kernel (conv_ws = 0) to rounding.  conv_ws = 2 / 3 route only the plain-source / only the
+    GroupNorm-on-load convolutions through it, so both sides of the statistics hand-over are exercised."""
+    from test_gpu_parity_2d import build_unet2d
+    m, _ = build_unet2d(device)
+    x = torch.randn((2, 21, 64, 64), generator=torch.Generator().manual_seed(1)).to(device)
+    t = torch.full((2,), 500, device=device)
+    names = ["downs.0.1", "downs.1.3", "mid_block1", "mid_block2", "ups.0.0", "ups.0.1", "ups.1.1", "final_res_block"]
+    m.set_option("conv_ws", 0)
+    m(x, t)
+    ref = {n: m.tap(n, 2).clone() for n in names}
+    m.set_option("conv_ws", conv_ws)
+    first = None
+    for it in range(40):
+        m(x, t)
+        cur = {n: m.tap(n, 2).clone() for n in names}
+        if first is None:
+            first = cur
+            for n in names:
+                assert rel(cur[n], ref[n].cpu().numpy()) < 1e-5, (conv_ws, n)
+        for n in names:
+            assert torch.equal(cur[n], first[n]), (conv_ws, n, it)
 
 
 # ------------------------------------------------------------------ branches of round 2's fixtures
