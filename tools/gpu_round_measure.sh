@@ -24,7 +24,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc5_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc5_write -- python3 /root/repo/tools/prof2d.py 64 2 5 > /dev/null 2>&1
 cd /root/repo
 python3 tools/rocprof_summary.py $(find /tmp/k5 -name "*.db" | head -1) gpurun_out/meas/kstats_cfg5.txt > /dev/null
-python3 tools/pmc_traffic.py /tmp/pmc5_fetch /tmp/pmc5_write > gpurun_out/meas/pmc_traffic_cfg5.json
+python3 tools/pmc_traffic.py /tmp/pmc5_fetch /tmp/pmc5_write 7 > gpurun_out/meas/pmc_traffic_cfg5.json
+cp gpurun_out/meas/pmc_traffic_cfg5.json profiles/r02_pmc_traffic_cfg5.json      # bench.py reads the committed name
 python bench.py --workload cfg5 > gpurun_out/meas/bench_cfg5.json 2> gpurun_out/meas/bench_cfg5.err
 cat gpurun_out/meas/bench_cfg5.json
 fi
