@@ -340,17 +340,24 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     // Software pipeline, two items deep: phase k (the matrix waves multiply item k) stages item k+1 from the registers
     // loaded during phase k-1, THEN issues item k+2's loads into the same registers, THEN writes the previous tile.
     // vmcnt retires in order: with the tile's stores issued after the loads, no wait for a load ever covers a store.
+    // An item whose planes (pixel tile, chunk) are the ones its buffer already holds -- the second n-tile of a
+    // two-chunk layer: items c0, c1, c0, c1 alternate buffers 0, 1, 0, 1 -- is neither loaded nor staged again.
     int mt, nt, ch, mtn, ntn, chn;
     decode(0, mt, nt, ch);
     load_item(mt, ch);
     finish_stats();
     store_item(0);
+    bool staged_skip = false;                                // the item waiting for its staging needs none
     if (nitems > 1) { decode(1, mtn, ntn, chn); load_item(mtn, chn); }
     __syncthreads();                                         // S0
     int pmt = -1, pnt = 0;                                   // finished tile waiting in LDS
     for (int k = 0; k < nitems; ++k) {
-        if (k + 1 < nitems && dbg != 5) { finish_stats(); store_item((k + 1) & 1); }
-        if (k + 2 < nitems && dbg != 2 && dbg != 5) { decode(k + 2, mtn, ntn, chn); load_item(mtn, chn); }
+        if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1); }
+        if (k + 2 < nitems && dbg != 5) {
+            decode(k + 2, mtn, ntn, chn);
+            staged_skip = (mtn == mt && chn == ch);                // its buffer, (k + 2) & 1, holds item k's planes: these
+            if (!staged_skip && dbg != 2) load_item(mtn, chn);
+        }
         if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt); pmt = -1; }
         __syncthreads();                                     // S1
         if (ch == nch - 1) {
