@@ -43,7 +43,7 @@ namespace cindm {
 constexpr int V2Y = 8, V2X = 16, V2M = V2Y * V2X;          // output pixel tile
 constexpr int V2SW = 18, V2R = 10 * V2SW;                   // staged window 10 x 18 pixels
 constexpr int V2PITCH = 144, V2PLANE = V2R * V2PITCH;       // bytes per staged pixel and plane (64 halfs + 16 B pad)
-constexpr int V2LDT = 68;                                   // output tile pitch (floats)
+constexpr int V2LDT = 132;                                  // output tile [64 channels][128 pixels + 4]: pitch in floats
 constexpr int WS_GRID = 256;                                // one persistent workgroup per CU
 constexpr int WS_SPT = 4;                                   // GroupNorm partials per tile (one per memory wave, 32 pixels)
 constexpr int WS_MAXP = 128;                                // most GroupNorm partials per (image, group) the consumer side holds
@@ -52,7 +52,7 @@ template <int KIND, int MODE>
 __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     constexpr int KC = 64, NP = 12;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * V2PLANE];   // [buffer][plane hi/lo][V2R][V2PITCH]
-    __shared__ __attribute__((aligned(16))) float Tile[V2M * V2LDT];
+    __shared__ __attribute__((aligned(16))) float Tile[T2N * V2LDT];   // channel-major: an accumulator's 4 rows are 16 contiguous bytes
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,33 +145,41 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     ++k;
                     __syncthreads();                         // S1
                 }
-                const int tcol = nh * 32 + (lane & 15), trow = (lane >> 4) * 4;
+                // the accumulators' 4 row registers are 4 consecutive pixels of one channel: one ds_write_b128 per (pixel
+                // block, column block) into the channel-major tile (the pixel-major tile of the first version cost 64
+                // 4-byte LDS writes + 32 + 32 read-modify-writes per lane: 1.75 us per tile)
+                float* const trow = Tile + (nh * 32 + (lane & 15)) * V2LDT + (lane >> 4) * 4;
                 if (kg == 1) {
 #pragma unroll
                     for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                            for (int rg = 0; rg < 4; ++rg)
-                                Tile[(mb * 16 + trow + rg) * V2LDT + tcol + nb * 16] = accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV;
+                        for (int nb = 0; nb < 2; ++nb) {
+                            float4 v;
+                            v.x = accM[mb][nb][0] + accL[mb][nb][0] * H3_INV; v.y = accM[mb][nb][1] + accL[mb][nb][1] * H3_INV;
+                            v.z = accM[mb][nb][2] + accL[mb][nb][2] * H3_INV; v.w = accM[mb][nb][3] + accL[mb][nb][3] * H3_INV;
+                            *reinterpret_cast<float4*>(trow + nb * 16 * V2LDT + mb * 16) = v;
+                        }
                 }
                 __syncthreads();                             // S2
                 if (kg == 0) {
                     float bias[2];
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
-                        const int gn = nt * T2N + tcol + nb * 16;
+                        const int gn = nt * T2N + nh * 32 + (lane & 15) + nb * 16;
                         bias[nb] = (a.bias && gn < a.N) ? a.bias[gn] : 0.f;
                     }
 #pragma unroll
                     for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) {
-                                float* tp = Tile + (mb * 16 + trow + rg) * V2LDT + tcol + nb * 16;
-                                *tp = (*tp + (accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV)) + bias[nb];
-                            }
+                        for (int nb = 0; nb < 2; ++nb) {
+                            float4* tp = reinterpret_cast<float4*>(trow + nb * 16 * V2LDT + mb * 16);
+                            float4 v = *tp;
+                            v.x = (v.x + (accM[mb][nb][0] + accL[mb][nb][0] * H3_INV)) + bias[nb];
+                            v.y = (v.y + (accM[mb][nb][1] + accL[mb][nb][1] * H3_INV)) + bias[nb];
+                            v.z = (v.z + (accM[mb][nb][2] + accL[mb][nb][2] * H3_INV)) + bias[nb];
+                            v.w = (v.w + (accM[mb][nb][3] + accL[mb][nb][3] * H3_INV)) + bias[nb];
+                            *tp = v;
+                        }
                 }
                 __syncthreads();                             // S3: the finished tile is in LDS
             }
@@ -302,20 +310,34 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         const int oc4 = lane & 15, q = lane >> 4;
         const int col = nt * T2N + oc4 * 4;
         const bool nok = col < N;                            // N is a multiple of 4 (host)
-        // tile pixel r = 32 lw + q + 4 j: row 2 lw + (j >> 2), column q + 4 (j & 3)
-        float* o0 = outp + ((img * Hout + ty0 + 2 * lw) * Wout + tx0 + q) * ldo + col;
-        const float* t0 = Tile + (32 * lw + q) * V2LDT + oc4 * 4;
-        float4 v[8];                                         // all eight LDS reads in flight before the first store
+        // this wave's 32 pixels = 8 blocks of 4 (block b: tile row 2 lw + (b >> 2), columns 4 (b & 3) ..); lane = (channel
+        // quad oc4, blocks q and q + 4): four 16-byte LDS reads give 4 channels x 4 pixels, whose transpose is a renaming
+        float* o0 = outp + ((img * Hout + ty0 + 2 * lw) * Wout + tx0) * ldo + col;
+        const float* t0 = Tile + (oc4 * 4) * V2LDT + 32 * lw + 4 * q;
+        float4 f[2][4];                                      // all eight LDS reads in flight before the first store
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(t0 + 4 * j * V2LDT);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) f[jj][ci] = *reinterpret_cast<const float4*>(t0 + ci * V2LDT + 16 * jj);
+        float4 v[8];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            v[4 * jj + 0] = make_float4(f[jj][0].x, f[jj][1].x, f[jj][2].x, f[jj][3].x);
+            v[4 * jj + 1] = make_float4(f[jj][0].y, f[jj][1].y, f[jj][2].y, f[jj][3].y);
+            v[4 * jj + 2] = make_float4(f[jj][0].z, f[jj][1].z, f[jj][2].z, f[jj][3].z);
+            v[4 * jj + 3] = make_float4(f[jj][0].w, f[jj][1].w, f[jj][2].w, f[jj][3].w);
+        }
         if (nok && dbg != 4) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(o0 + ((j >> 2) * Wout + 4 * (j & 3)) * ldo) = v[j];
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)               // block b = q + 4 jj: row jj, column 4 q + pi
+                    *reinterpret_cast<float4*>(o0 + (jj * Wout + 4 * q + pi) * ldo) = v[4 * jj + pi];
         }
         if (!stats_out) return;
         // shifted sums about the group's first element of the wave's first pixel
         const int gwt = so_gw;                               // 8 or 16 channels: 2 or 4 lanes (oc4) per group
-        const float K = Tile[32 * lw * V2LDT + ((oc4 * 4) & ~(gwt - 1))];
+        const float K = Tile[((oc4 * 4) & ~(gwt - 1)) * V2LDT + 32 * lw];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
