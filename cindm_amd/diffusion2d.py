@@ -263,7 +263,7 @@ class GaussianDiffusion(nn.Module):
     # ------------------------------------------------------------------ loops
     @torch.no_grad()
     def p_sample_loop(self, shape, design_fn=None, design_guidance="standard", return_all_timesteps=None, *,
-                      noise=None, seed=0, sample_offset=0, use_graph=True, t_stop=0, device=None):
+                      noise=None, seed=0, sample_offset=0, use_graph=True, t_stop=0, device=None, fused=True):
         """:893-907.  Returns [B, nb, C, H, W].  ``noise``: a NoiseTape2D (parity runs); otherwise x_T and the
         per-step draws come from the library's counter-based generator keyed by (seed, sample_offset + design)."""
         B, nb, Cc, H, W = shape
@@ -291,6 +291,30 @@ class GaussianDiffusion(nn.Module):
                 _ffi.check(L.cindm_ddpm2d_sample(h, self.model._h, _ffi.ptr(x), B, nb, int(self.use_average_share),
                                                  _ffi.ptr(ns), _ffi.ptr(nbnd), seed, sample_offset, T - 1, int(t_stop),
                                                  _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+            return from_device_layout(x, Cc, H, W).reshape(B, nb, Cc, H, W)
+        from .forceunet import ForceObjective
+        if isinstance(design_fn, ForceObjective) and design_guidance == "standard-alpha" and fused:
+            # the library's own objective: surrogate forward + input gradient, the reverse step and the guidance shift are
+            # ONE captured graph per timestep (cindm_ddpm2d_sample_force), as PointObjective is in the 1-D path
+            fo = design_fn
+            if (fo.B, fo.nb) != (B, nb) or Cc != 3 * fo.frames + 3:
+                raise ValueError("ForceObjective was built for another batch / boundary / frame count")
+            fo.model.sync_weights()
+            h, ws = self._prepare(B * nb, device)
+            nfb = L.cindm_airfoil_design_workspace_bytes(fo.model._h, B, nb)
+            wsf = torch.empty(nfb, dtype=torch.uint8, device=device)
+            g = torch.empty_like(x)
+            eta = (self.coeff_ratio * self.betas.flip(0)).to(device, torch.float32).contiguous()
+            ns = nbnd = None
+            if noise is not None:
+                ns = _state_cl(noise.step_state.to(device, torch.float32))
+                nbnd = _boundary_cl(noise.step_boundary.to(device, torch.float32))
+            with torch.cuda.device(device):
+                _ffi.check(L.cindm_ddpm2d_sample_force(h, self.model._h, fo.model._h, _ffi.ptr(x), B, nb, int(self.use_average_share),
+                                                       _ffi.ptr(ns), _ffi.ptr(nbnd), seed, sample_offset, T - 1, int(t_stop),
+                                                       fo.frames, fo.p_min, fo.p_max, fo.lambda_force, fo.lambda_overlap, fo.factor,
+                                                       _ffi.ptr(eta), _ffi.ptr(g), _ffi.ptr(ws), ws.numel(), _ffi.ptr(wsf),
+                                                       wsf.numel(), _ffi.current_stream(device), int(use_graph)))
             return from_device_layout(x, Cc, H, W).reshape(B, nb, Cc, H, W)
         img = from_device_layout(x, Cc, H, W)
         for t in reversed(range(int(t_stop), T)):

@@ -382,6 +382,19 @@ size_t cindm_airfoil_design_workspace_bytes(const cindm_forceunet* h, int64_t B,
 int  cindm_airfoil_design_grad(cindm_forceunet* h, const float* x, int64_t B, int32_t nb, int32_t frames, int32_t CP,
                                float p_min, float p_max, float lambda_force, float lambda_overlap, int32_t downsampling_factor,
                                float* grad, void* ws, size_t ws_bytes, void* stream);
+/* Design-guided 2-D sampling with the airfoil objective inside the captured step (inference/inverse_design_2d.py:236-244
+ * with design_guidance = "standard-alpha"; p_sample's guided tail model/diffusion_2d.py:806-845): per reverse step
+ * g = cindm_airfoil_design_grad(x_t); x_{t-1} = p_sample(x_t) (as cindm_ddpm2d_sample); x_{t-1} -= eta[t] * g, with eta a
+ * device table of `timesteps` floats (coeff_ratio * betas.flip(0)).  grad: a device buffer shaped like x; ws as
+ * cindm_ddpm2d_sample, ws_force as cindm_airfoil_design_grad.  One hipGraph per call, replayed once per timestep. */
+int  cindm_ddpm2d_sample_force(cindm_ddpm1d* sched, cindm_unet2d* u, cindm_forceunet* f, float* x, int64_t B, int32_t nb,
+                               int32_t use_average_share, const float* noise_state_steps,
+                               const float* noise_boundary_steps, uint64_t seed, int64_t sample_offset,
+                               int32_t t_start, int32_t t_end, int32_t frames, float p_min, float p_max,
+                               float lambda_force, float lambda_overlap, int32_t down_factor, const float* eta,
+                               float* grad, void* ws, size_t ws_bytes, void* ws_force, size_t ws_force_bytes,
+                               void* stream, int32_t use_graph);
+
 
 #ifdef __cplusplus
 }

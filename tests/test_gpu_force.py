@@ -88,3 +88,30 @@ def test_guided_step_with_force_objective(device, force):
     fn = cindm_amd.ForceObjective(m, B, nb, 6, p_min=-37.7, p_max=57.6)
     out, _ = d.p_sample((B, nb, 21, 64, 64), x.to(device), 400, design_fn=fn, design_guidance="standard-alpha", noise=nz.to(device))
     assert rel(out, ref) < TOL
+
+
+def test_guided_chain_fused_equals_loop(device, force):
+    """``sample(design_fn=ForceObjective, design_guidance="standard-alpha")`` runs surrogate gradient + reverse step +
+    guidance shift as one captured graph per timestep (cindm_ddpm2d_sample_force); it must reproduce the per-step loop
+    (p_sample + the same objective called from Python) on the same explicit noise, with and without graph replay."""
+    from test_gpu_parity_2d import _tape
+    m, _ = force
+    sd2 = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
+    u = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21)
+    u.load_state_dict(sd2, strict=True)
+    d = cindm_amd.GaussianDiffusion(u, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000, loss_type="l2",
+                                    coeff_ratio=0.05).to(device)
+    B, nb = 2, 2
+    fn = cindm_amd.ForceObjective(m, B, nb, 6, p_min=-37.7, p_max=57.6)
+    tape = _tape(31, B, nb, 21, 64, 64, 1000)
+    shape = (B, nb, 21, 64, 64)
+    kw = dict(design_fn=fn, design_guidance="standard-alpha", noise=tape, t_stop=995, device=device)
+    loop = d.p_sample_loop(shape, fused=False, **kw)
+    fused = d.p_sample_loop(shape, fused=True, **kw)
+    eager = d.p_sample_loop(shape, fused=True, use_graph=False, **kw)
+    assert torch.isfinite(fused).all()
+    assert rel(fused, loop.cpu().numpy()) < 1e-6
+    assert torch.equal(fused, eager)
+    # the guidance is not a no-op at this coefficient
+    plain = d.p_sample_loop(shape, noise=tape, t_stop=995, device=device)
+    assert not torch.equal(fused, plain)
