@@ -128,7 +128,7 @@ SIGNATURES = {
     "cindm_forceunet_workspace_bytes": (_sz, [_vp, _i64, _i32]),
     "cindm_forceunet_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "cindm_forceunet_grad": (C.c_int, [_vp, _vp, C.c_float, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "cindm_airfoil_design_workspace_bytes": (_sz, [_vp, _i64, _i32]),
+    "cindm_airfoil_design_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32]),
     "cindm_airfoil_design_grad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, _i32,
                                             _vp, _vp, _sz, _vp]),
     "cindm_ddpm2d_sample_force": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _i32, _i32,

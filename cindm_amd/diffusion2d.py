@@ -301,7 +301,7 @@ class GaussianDiffusion(nn.Module):
                 raise ValueError("ForceObjective was built for another batch / boundary / frame count")
             fo.model.sync_weights()
             h, ws = self._prepare(B * nb, device)
-            nfb = L.cindm_airfoil_design_workspace_bytes(fo.model._h, B, nb)
+            nfb = L.cindm_airfoil_design_workspace_bytes(fo.model._h, B, nb, fo.frames_per_pass)
             wsf = torch.empty(nfb, dtype=torch.uint8, device=device)
             g = torch.empty_like(x)
             eta = (self.coeff_ratio * self.betas.flip(0)).to(device, torch.float32).contiguous()

@@ -121,8 +121,12 @@ class ForceObjective:
     ``g = grad_force + lambda_overlap * grad_overlap`` for a state ``x [B * nb, 3 * frames + 3, 64, 64]``."""
 
     def __init__(self, force_model, batch_size, num_boundaries, frames, p_min, p_max, lambda_force=1.0, lambda_overlap=1.0,
-                 downsampling_factor=4):
+                 downsampling_factor=4, frames_per_pass=None):
         self.model, self.B, self.nb, self.frames = force_model, int(batch_size), int(num_boundaries), int(frames)
+        # all frames of a design as ONE surrogate batch by default (frames * B * nb images per pass; workspace scales with it)
+        self.frames_per_pass = int(frames_per_pass or frames)
+        if self.frames % self.frames_per_pass:
+            raise ValueError("frames_per_pass must divide frames")
         self.p_min, self.p_max = float(p_min), float(p_max)
         self.lambda_force, self.lambda_overlap, self.factor = float(lambda_force), float(lambda_overlap), int(downsampling_factor)
         self._ws = None
@@ -140,7 +144,7 @@ class ForceObjective:
         cp = (c + 3) // 4 * 4
         xd = to_device_layout(x.detach().float(), cp)
         g = torch.empty_like(xd)
-        nbytes = L.cindm_airfoil_design_workspace_bytes(m._h, self.B, self.nb)
+        nbytes = L.cindm_airfoil_design_workspace_bytes(m._h, self.B, self.nb, self.frames_per_pass)
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):

@@ -378,7 +378,9 @@ int  cindm_forceunet_grad(cindm_forceunet* h, const float* x, float lambda_force
 /* grad[B*nb, H*W, CP] = design_fn(x) = grad_force + lambda_overlap * grad_overlap (inverse_design_2d.py:208-214), the
  * tensor GaussianDiffusion.p_sample subtracts under "standard" / "standard-alpha" guidance (model/diffusion_2d.py:813-817).
  * frames = (real channels - 3) / 3; p_min / p_max: the pressure normalisation of the data set (:85-87). */
-size_t cindm_airfoil_design_workspace_bytes(const cindm_forceunet* h, int64_t B, int32_t nb);
+/* frames_per_pass: how many of the `frames` surrogate passes of one gradient run as one batch (a divisor of frames;
+ * cindm_airfoil_design_grad uses the largest one whose workspace fits what it is given) */
+size_t cindm_airfoil_design_workspace_bytes(const cindm_forceunet* h, int64_t B, int32_t nb, int32_t frames_per_pass);
 int  cindm_airfoil_design_grad(cindm_forceunet* h, const float* x, int64_t B, int32_t nb, int32_t frames, int32_t CP,
                                float p_min, float p_max, float lambda_force, float lambda_overlap, int32_t downsampling_factor,
                                float* grad, void* ws, size_t ws_bytes, void* stream);
