@@ -170,6 +170,7 @@ static const OptDef kUnet1dOpts[] = {
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
+    {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
     {"dbg", 0, "CINDM_DBG"}, {"dbg3", 0, "CINDM_DBG3"}, {"dbg4", 0, "CINDM_DBG4"},   // timing ablations (wrong results)
@@ -1141,6 +1142,7 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
 }
 
 static int emit_forward(Emitter& E, const float* x, float* eps) {
+    const bool taps = E.h->O("taps") != 0;      // tap-only block outputs of the level kernels (tests); off on the sampling path
     cindm_unet1d* h = E.h;
     const auto& d = h->d;
     const int nres = d.n_mults;
@@ -1168,7 +1170,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 Level0Args l;
                 std::memset(&l, 0, sizeof(l));
                 l.pf = pfl;
-                l.x = cur.p; l.F = cur.C; l.h1 = h1.p; l.h2 = h2.p; l.skip = sk.p; l.down = dn.p;
+                l.x = cur.p; l.F = cur.C; l.h1 = taps ? h1.p : nullptr; l.h2 = taps ? h2.p : nullptr; l.skip = sk.p; l.down = dn.p;
                 const char* cv[4] = {"downs.0.0.blocks.0", "downs.0.0.blocks.1", "downs.0.1.blocks.0", "downs.0.1.blocks.1"};
                 for (int i = 0; i < 4; ++i) {
                     const std::string cp = cv[i];
@@ -1188,7 +1190,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 }
                 E.prof_end();
             }
-            E.tap("downs.0.0", h1); E.tap("downs.0.1", h2); E.tap("downs.0.2", sk); E.tap("downs.0.3", dn);
+            if (taps) { E.tap("downs.0.0", h1); E.tap("downs.0.1", h2); }
+            E.tap("downs.0.2", sk); E.tap("downs.0.3", dn);
             skips.push_back(sk);
             cur = dn;
             continue;
@@ -1208,7 +1211,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 Level1Args l;
                 std::memset(&l, 0, sizeof(l));
                 l.pf = pfl;
-                l.x = cur.p; l.h1 = h1.p; l.h2 = h2.p; l.skip = sk.p; l.down = dn.p;
+                l.x = cur.p; l.h1 = taps ? h1.p : nullptr; l.h2 = taps ? h2.p : nullptr; l.skip = sk.p; l.down = dn.p;
                 const char* cv[4] = {"downs.1.0.blocks.0", "downs.1.0.blocks.1", "downs.1.1.blocks.0", "downs.1.1.blocks.1"};
                 for (int i = 0; i < 4; ++i) {
                     const std::string cp = cv[i];
@@ -1231,7 +1234,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 }
                 E.prof_end();
             }
-            E.tap("downs.1.0", h1); E.tap("downs.1.1", h2); E.tap("downs.1.2", sk); E.tap("downs.1.3", dn);
+            if (taps) { E.tap("downs.1.0", h1); E.tap("downs.1.1", h2); }
+            E.tap("downs.1.2", sk); E.tap("downs.1.3", dn);
             skips.push_back(sk);
             cur = dn;
             continue;
@@ -1266,7 +1270,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 UpsLastArgs l;
                 std::memset(&l, 0, sizeof(l));
                 l.pf = pfl;
-                l.x = cur.p; l.skip = skip.p; l.h1 = h1.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p; l.ypre = ypre.p; l.eps = eps; l.F = d.transition_dim;
+                l.x = cur.p; l.skip = skip.p; l.eps = eps; l.F = d.transition_dim;
+                if (taps) { l.h1 = h1.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p; l.ypre = ypre.p; }     // tap-only outputs of the last level
                 const std::string cv[5] = {p + ".0.blocks.0", p + ".0.blocks.1", p + ".1.blocks.0", p + ".1.blocks.1", "final_conv.0"};
                 for (int i = 0; i < 5; ++i) {
                     l.Wc[i] = E.W(h->packed.at(cv[i] + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cv[i] + ".block.0"));
@@ -1285,7 +1290,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                     KLAUNCH(E, ups_last_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
                 E.prof_end();
             }
-            E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre);
+            if (taps) { E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre); }
             return 0;
         }
         cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
@@ -1304,7 +1309,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 UpsTailArgs l;
                 std::memset(&l, 0, sizeof(l));
                 l.pf = pfl;
-                l.x = cur.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p;
+                l.x = cur.p; l.h2 = taps ? h2.p : nullptr; l.h3 = taps ? h3.p : nullptr; l.up = up.p;
                 const std::string cv[2] = {p + ".1.blocks.0", p + ".1.blocks.1"};
                 for (int i = 0; i < 2; ++i) {
                     l.Wc[i] = E.W(h->packed.at(cv[i] + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cv[i] + ".block.0"));
@@ -1321,7 +1326,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                     KLAUNCH(E, ups_tail128_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
                 E.prof_end();
             }
-            E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up);
+            if (taps) { E.tap(p + ".1", h2); E.tap(p + ".2", h3); }
+            E.tap(p + ".3", up);
             cur = up;
             continue;
         }
@@ -1634,7 +1640,8 @@ extern "C" int cindm_unet1d_tap(cindm_unet1d* h, const char* name, int64_t rows,
     REQUIRE(h && name && ws && dst, "null argument");
     REQUIRE(rows == h->taps_rows, "tap: rows differ from the last forward");
     auto it = h->taps.find(name);
-    if (it == h->taps.end()) return fail(std::string("unknown tap: ") + name);
+    if (it == h->taps.end())
+        return fail(std::string("unknown tap: ") + name + (h->O("taps") ? "" : " (block outputs inside the level kernels are stored only with set_option(\"taps\", 1))"));
     const auto& tp = it->second;
     const int64_t n = rows * tp.L * tp.C;
     REQUIRE(tp.ld == tp.C, "tap: strided tensor");

@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     f32x4 h1[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) h1[nt] = v[nt] + r1[nt];
-    lvl_store<NT>(h1, a.h1 + (size_t)b * L * C, c0, L, lane);
+    if (a.h1) lvl_store<NT>(h1, a.h1 + (size_t)b * L * C, c0, L, lane);
     lvl_to_planes<NT, PPB>(h1, P[1][0], P[1][1], c0, 2, L, lane);
     __syncthreads();
     // ---- block 1 (identity residual) ----
@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     f32x4 h2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) h2[nt] = v[nt] + h1[nt];
-    lvl_store<NT>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
+    if (a.h2) lvl_store<NT>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
         *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl]) = make_float4(h2[nt][0], h2[nt][1], h2[nt][2], h2[nt][3]);
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) h1[mt][nt] = v[mt][nt] + r1[mt][nt];
-    store(h1, a.h1, L);
+    if (a.h1) store(h1, a.h1, L);
     to_planes(h1, P[1][0], P[1][1]);
     __syncthreads();
     if (a.dbg == 2) return;
@@ -2000,7 +2000,7 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) h2[mt][nt] = v[mt][nt] + h1[mt][nt];
-    store(h2, a.h2, L);
+    if (a.h2) store(h2, a.h2, L);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -2260,7 +2260,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
         lvlm_gn_mish(vb[mt][0], pvb4(3, mt), pvb4(4, mt), pvb4(5, mt), L, lane);
         h1b[mt][0] = vb[mt][0] + rb[mt][0];
-        if (lr < L) *reinterpret_cast<float4*>(a.h1 + ((size_t)b * L + lr) * CB + clb(mt)) = make_float4(h1b[mt][0][0], h1b[mt][0][1], h1b[mt][0][2], h1b[mt][0][3]);
+        if (a.h1 && lr < L) *reinterpret_cast<float4*>(a.h1 + ((size_t)b * L + lr) * CB + clb(mt)) = make_float4(h1b[mt][0][0], h1b[mt][0][1], h1b[mt][0][2], h1b[mt][0][3]);
     }
     q_planes(h1b, Q[1][0], Q[1][1]);
     __syncthreads();
@@ -2278,7 +2278,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     lvlm_prefetch<1, 1, 4, 8>(ring, wbase(a.Wo, 1, 4), lane);           // to_out fragments: in flight through the attention
     lvl_gn_mish<1>(v1[0], pv4(3), pv4(4), pv4(5), L, lane);
     h2[0] = v1[0][0] + r1[0][0];
-    lvl_store<1>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
+    if (a.h2) lvl_store<1>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
     *reinterpret_cast<float4*>(&H[lr * HP + cl]) = make_float4(h2[0][0], h2[0][1], h2[0][2], h2[0][3]);
     __syncthreads();
     // ---- attention site (C = 64, one 16-position tile) ----
@@ -2360,7 +2360,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     h3[0] = v1[0][0];
     add4(h3[0], pv4(11));
     h3[0] += h2[0];
-    lvl_store<1>(h3, a.h3 + (size_t)b * L * C, c0, L, lane);
+    if (a.h3) lvl_store<1>(h3, a.h3 + (size_t)b * L * C, c0, L, lane);
     lvl_to_planes<1, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
     // ---- Upsample1d: ConvTranspose1d(k = 4, stride 2, pad 1), L -> 2L positions (two tiles) ----
@@ -2368,7 +2368,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     lvlm_conv<1, 2, 4, 2, PPB, 8, 1>(ring, wbase(a.Wu, 4, 2), P[0][0], P[0][1], 0, 0, 0, ROWS2 - 1, lane, u);
     lvlm_prefetch<1, 5, 2, 8>(ring, wbase(a.Wc[4], 5, 2), lane);
     add4(u[0][0], pv4(12)); add4(u[0][1], pv4(12));
-    lvl_store<2>(u[0], a.up + (size_t)b * L2 * C, c0, L2, lane);
+    if (a.up) lvl_store<2>(u[0], a.up + (size_t)b * L2 * C, c0, L2, lane);
     lvl_to_planes<2, PPB>(u[0], P[1][0], P[1][1], c0, 2, L2, lane);
     __syncthreads();
     // ---- final Conv1dBlock(64 -> 64, k5) and Conv1d(64 -> F, 1) ----
@@ -2376,7 +2376,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     lvlm_conv<1, 2, 5, 2, PPB, 8>(ring, wbase(a.Wc[4], 5, 2), P[1][0], P[1][1], 16, 1, 0, ROWS2 - 1, lane, y);
     if (w == 0) lvlm_prefetch<1, 1, 2, 8>(ring, reinterpret_cast<const float4*>(a.Wf), lane);
     add4(y[0][0], pv4(6)); add4(y[0][1], pv4(6));
-    lvl_store<2>(y[0], a.ypre + (size_t)b * L2 * C, c0, L2, lane);
+    if (a.ypre) lvl_store<2>(y[0], a.ypre + (size_t)b * L2 * C, c0, L2, lane);
     lvl_gn_mish<2>(y[0], zero4, pv4(7), pv4(8), L2, lane);
     lvl_to_planes<2, PPB>(y[0], P[0][0], P[0][1], c0, 2, L2, lane);
     __syncthreads();
@@ -2515,7 +2515,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
         h2[mt] = v[mt] + r[mt];
         *reinterpret_cast<float4*>(&H[lr * HP + cl(mt)]) = make_float4(h2[mt][0], h2[mt][1], h2[mt][2], h2[mt][3]);
     }
-    store(h2, a.h2, L);
+    if (a.h2) store(h2, a.h2, L);
     __syncthreads();
     // ---- attention site (C = 128) ----
     {
@@ -2609,7 +2609,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) { add4(h3[mt], pv4(8, mt)); h3[mt] += h2[mt]; }
-    store(h3, a.h3, L);
+    if (a.h3) store(h3, a.h3, L);
     planes(h3, P[0][0], P[0][1], L);
     __syncthreads();
     // ---- Upsample1d: ConvTranspose1d(k = 4, stride 2, pad 1), L -> 2L <= 16 positions (one tile) ----

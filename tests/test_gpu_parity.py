@@ -82,10 +82,19 @@ def test_unet_blocks_golden(gold_dir, device, unet8):
     g = np.load(os.path.join(gold_dir, "unet1d_fwd.npz"))
     m, _ = unet8
     x = torch.from_numpy(g["x"][:2]).to(device)
-    m(x, torch.full((2,), 500, device=device))
-    for k in ("downs.0.0", "downs.0.1", "downs.0.2", "downs.0.3", "downs.1.0", "downs.2.1", "downs.3.2", "mid_block1",
-              "mid_attn", "mid_block2", "ups.0.0", "ups.0.3", "ups.1.1", "ups.2.2", "ups.2.3"):
-        assert rel(m.tap(k, 2), g["tap." + k]) < TOL_FWD, k
+    m.set_option("taps", 1)          # block outputs inside the level kernels reach HBM only on request
+    try:
+        out = m(x, torch.full((2,), 500, device=device))
+        for k in ("downs.0.0", "downs.0.1", "downs.0.2", "downs.0.3", "downs.1.0", "downs.2.1", "downs.3.2", "mid_block1",
+                  "mid_attn", "mid_block2", "ups.0.0", "ups.0.3", "ups.1.1", "ups.2.2", "ups.2.3"):
+            assert rel(m.tap(k, 2), g["tap." + k]) < TOL_FWD, k
+    finally:
+        m.set_option("taps", 0)
+    # the sampling configuration (no tap stores) computes the same prediction bit for bit and still serves the skips
+    assert torch.equal(m(x, torch.full((2,), 500, device=device)), out)
+    assert rel(m.tap("downs.0.2", 2), g["tap.downs.0.2"]) < TOL_FWD
+    with pytest.raises(cindm_amd.CindmError):
+        m.tap("downs.0.0", 2)
 
 
 @pytest.mark.parametrize("hz,F,att,key,xkey", [(24, 4, True, "eps_f4_t321", "x_f4"), (24, 16, True, "eps_f16_t321", "x_f16"),
