@@ -23,8 +23,9 @@
 //  * GroupNorm statistics travel as per-(tile, memory wave) partials (32 pixels each; no cross-wave reduction in the
 //    store path) and the consumer merges them itself -- the gn_merge_kernel launches are gone.  Inside this kernel the
 //    merge uses DPP row sums + v_readlane + a select chain (group8_total), NOT ds_bpermute shuffles: with __shfl in the
-//    memory waves, one run in ~5 staged a stale window pixel (3 wrong output pixels per incident, tools/dbg_ws2.py
-//    reproduces it with conv_ws = 1 and merge_stats8); without LDS-pipeline instructions in that path, 0 of 450 runs;
+//    memory waves, one run in ~5 staged a stale window pixel (3 wrong output pixels per incident; 40 repeats of one
+//    forward in tests/test_gpu_paths.py::test_unet2d_conv_ws_repeatable is the regression test); without LDS-pipeline
+//    instructions in that path, 0 of 450 runs;
 //  * XCD x (workgroup % 8) owns a contiguous eighth of the tile list, its 32 workgroups walk it side by side, so halos
 //    and both n-tiles' input hit that XCD's L2.
 // LDS: 2 plane buffers x 51 840 B + 34 816 B output tile = 138.5 KB.

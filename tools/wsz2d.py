@@ -1,3 +1,4 @@
+"""2-D workspace size with and without aliasing of block-internal temporaries: python tools/wsz2d.py"""
 import sys, torch
 sys.path.insert(0, "/root/repo"); import cindm_amd
 from cindm_amd.synthetic import synthetic_init_
