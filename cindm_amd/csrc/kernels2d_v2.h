@@ -205,9 +205,26 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const float* const gn_stats = a.src[0].stats;
     const int gn_P = a.src[0].P;
     const float gn_cnt = a.src[0].cnt;
-    int hyx[NP];                                             // window row | column << 8 of this thread's 12 pixels
+    // Per thread and window pixel p, once: the source byte offset relative to the tile's origin pixel, per unit of row
+    // pitch (dpix4 = 4 * pixel delta), and which pixels fall off each image border.  Per item the address is then ONE mad
+    // per pixel and the validity mask a handful of scalar selects (the first version recomputed y, x, the bounds test, the
+    // pixel index and a 64-bit address per pixel and item: ~150 of the memory waves' ~650 VALU instructions per item,
+    // every one of which takes an issue slot from the matrix wave on its SIMD).  Loads are raw-buffer loads: an offset
+    // that falls outside the tensor (the row above the first image) reads zeros instead of faulting; in-range but
+    // off-image pixels read a neighbour and are zeroed when staged.
+    int dpix4[NP];
+    unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_valid = 0;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) { const int r = r0 + 16 * p; const int hy = r / V2SW; hyx[p] = hy | ((r - hy * V2SW) << 8); }
+    for (int p = 0; p < NP; ++p) {
+        const int r = r0 + 16 * p;
+        const int hy = r / V2SW, hx = r - hy * V2SW;
+        dpix4[p] = 4 * ((KIND == CONV_UP2) ? ((hy - 1) >> 1) * Win + ((hx - 1) >> 1) : (hy - 1) * Win + (hx - 1));
+        m_valid |= (r < V2R) ? (1u << p) : 0u;
+        m_top |= (hy == 0) ? (1u << p) : 0u;  m_bot |= (hy == V2Y + 1) ? (1u << p) : 0u;
+        m_left |= (hx == 0) ? (1u << p) : 0u; m_right |= (hx == V2X + 1) ? (1u << p) : 0u;
+    }
+    const unsigned src_bytes0 = (unsigned)a.NI * (unsigned)HWi * (unsigned)ld0 * 4u;
+    const unsigned src_bytes1 = (unsigned)a.NI * (unsigned)HWi * (unsigned)ld1 * 4u;
     float4 areg[NP];
     float4 pg = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f), psc = pb, psh = pb;
     constexpr int MAXPV = WS_MAXP / 8;
@@ -228,15 +245,15 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         const float* base = first ? sp0 : sp1;
         const int clc = min(cl, Cc - 4);
         cok = cl < Cc;
-        okmask = 0;
-        const int ibase = img * HWi;
+        okmask = m_valid & ~((ty0 == 0 ? m_top : 0u) | (ty0 + V2Y == Hout ? m_bot : 0u) | (tx0 == 0 ? m_left : 0u) |
+                             (tx0 + V2X == Wout ? m_right : 0u));
+        const int origin = (KIND == CONV_UP2) ? img * HWi + (ty0 >> 1) * Win + (tx0 >> 1) : img * HWi + ty0 * Win + tx0;
+        const int t4 = (origin * ld + clc) * 4;               // byte offset of the tile origin's float4 of this thread
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, first ? src_bytes0 : src_bytes1, 0x00020000);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int y = ty0 - 1 + (hyx[p] & 255), x = tx0 - 1 + (hyx[p] >> 8);
-            const bool ok = (r0 + 16 * p < V2R) && ((unsigned)y < (unsigned)Hout) && ((unsigned)x < (unsigned)Wout);
-            const int srcpix = (KIND == CONV_UP2) ? (y >> 1) * Win + (x >> 1) : y * Win + x;
-            okmask |= ok ? (1u << p) : 0u;
-            areg[p] = *reinterpret_cast<const float4*>(base + (ibase + (ok ? srcpix : 0)) * ld + clc);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, dpix4[p] * ld + t4, 0, 0);
+            areg[p] = __builtin_bit_cast(float4, v);
         }
         if constexpr (MODE == SRC2_GN_SS_SILU) {
             const Src& s = a.src[0];
