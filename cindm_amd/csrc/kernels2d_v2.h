@@ -208,8 +208,9 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     // Per thread and window pixel p, once: the source byte offset relative to the tile's origin pixel, per unit of row
     // pitch (dpix4 = 4 * pixel delta), and which pixels fall off each image border.  Per item the address is then ONE mad
     // per pixel and the validity mask a handful of scalar selects (the first version recomputed y, x, the bounds test, the
-    // pixel index and a 64-bit address per pixel and item: ~150 of the memory waves' ~650 VALU instructions per item,
-    // every one of which takes an issue slot from the matrix wave on its SIMD).  Loads are raw-buffer loads: an offset
+    // pixel index and a 64-bit address per pixel and item: ~150 of the memory waves' ~650 VALU instructions per item;
+    // measured: the step time did not change, so it is not the instruction COUNT of a lone wave per SIMD that bounds
+    // the memory waves).  Loads are raw-buffer loads: an offset
     // that falls outside the tensor (the row above the first image) reads zeros instead of faulting; in-range but
     // off-image pixels read a neighbour and are zeroed when staged.
     int dpix4[NP];
