@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -280,3 +281,14 @@ def test_get_item_1d_matches_reference_formula():
     # sample 1, step 5, body 2, feature 3
     assert float(out[1, 5, 2 * 4 + 3]) == float(x[1 * 4 + 2, 5, 3] / 200.0)
     assert torch.equal(to_simulator_units(out, 4), (x / 200.0) * 200.0)
+
+
+def test_bench_refuses_world_size_mismatch():
+    """`bench.py --gpus N` under a torchrun environment of another size must exit non-zero before touching a GPU
+    (the driver launches N ranks and reads n_gpus from the line; a silent single-rank run would misreport)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
