@@ -1098,6 +1098,133 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
     }
 }
 
+// conv1x1_tail_h3_kernel<KT>: the ResnetBlock tails that carry a real GEMM -- out = res_conv(cat(x0, x1)) + bias +
+// SiLU(GN(y1)) (+ LayerNorm partials), KT = 128 or 192 input channels -- on the split-fp16 products.  On the fp32 MFMA
+// (conv1x1_wide_kernel) these launches were co-bound by the matrix pipe (8.6 GFLOP = 55 us at the fp32 peak for 536 MB
+// of traffic); with 3 fp16 MFMAs per product the pipe needs a fifth of that and the launch is a memory stream.  Same
+// 64-pixel workgroup, same transposed product (A = weights: wave w owns output channels 16 w .. of each 64-channel
+// tile; B = pixels), same accumulator layout (a lane holds 4 consecutive channels of pixel (lane & 15) + 16 pb) and the
+// same epilogue as conv1x1_wide_kernel<.., EPI>; the input tile is split into hi / scaled-lo fp16 planes while it is
+// staged ([plane][pixel][KT halfs + 8]), B fragments are one ds_read_b128 per plane and 32-channel k-step.
+// Weights: [n-tile][k-step][plane][thread = wave * 64 + lane][8 halfs] = W[n = tile*64 + wave*16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e].
+template <int KT>
+__global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArgs a) {
+    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
+    static_assert((64 * F4) % 256 == 0, "whole passes");
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
+    __shared__ float tabE[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lq = lane & 15, lg = lane >> 4;
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const int HWo = a.Hout * a.Wout;
+    const int img = (int)(row0 / HWo);
+    const Src& s0 = a.src[0];
+    const int ntile = a.Npad / T2N;
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + tid;
+    half8 wA[KS][2], wB[KS][2];
+    auto load_w = [&](int it, half8 (&wv)[KS][2]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[(((size_t)it * KS + ks) * 2 + pl) * 256]);
+    };
+    load_w(0, wA);
+    if (a.e_y && w == 1) {
+        float m, r;
+        merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
+        if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
+    }
+    // staging: all global loads first, then split + store
+    float4 sv[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int i = tid + 256 * p;
+        const int r = i / F4, c4 = i - r * F4;
+        const int cl = c4 * 4;
+        const bool first = cl < s0.C || a.nsrc == 1;
+        const Src& s = first ? a.src[0] : a.src[1];
+        const int cs = first ? cl : cl - s0.C;
+        sv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cs < s.C && (int64_t)(row0 + r) < a.rows_total) sv[p] = *reinterpret_cast<const float4*>(s.p + (row0 + r) * s.ld + cs);
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int i = tid + 256 * p;
+        const int r = i / F4, c4 = i - r * F4;
+        const float4 v = sv[p];
+        half4v hi, lo;
+        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+        lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+        *reinterpret_cast<half4v*>(&Xs[0][r * PITCH + c4 * 8]) = hi;
+        *reinterpret_cast<half4v*>(&Xs[1][r * PITCH + c4 * 8]) = lo;
+    }
+    __syncthreads();
+    const unsigned char* xh0 = &Xs[0][lq * PITCH + lg * 16];
+    const unsigned char* xl0 = &Xs[1][lq * PITCH + lg * 16];
+    auto tile = [&](int it, const half8 (&wv)[KS][2]) {
+        const int col = it * T2N + w * 16 + lg * 4;           // this lane's 4 consecutive output channels
+        f32x4 accM[4], accL[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) { accM[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const half8 xh = *reinterpret_cast<const half8*>(xh0 + pb * 16 * PITCH + ks * 64);
+                const half8 xl = *reinterpret_cast<const half8*>(xl0 + pb * 16 * PITCH + ks * 64);
+                accM[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xh, accM[pb], 0, 0, 0);
+                accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
+                accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
+            }
+        if (col >= a.N) return;                               // N is a multiple of 4 (host)
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col);
+        float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
+        float em = 0.f, er = 1.f;
+        if (a.e_y) {
+            eg = *reinterpret_cast<const float4*>(a.e_gamma + col); eb = *reinterpret_cast<const float4*>(a.e_beta + col);
+            const int g = col >> (31 - __builtin_clz(a.e_gw));
+            em = tabE[2 * g]; er = tabE[2 * g + 1];
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const size_t prow = row0 + pb * 16 + lq;
+            float4 v = make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
+                                   (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
+            if (a.e_y) {
+                const float4 y = *reinterpret_cast<const float4*>(a.e_y + prow * a.e_ld + col);
+                v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
+                v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
+            }
+            if (a.res) {
+                const float4 r4 = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + col);
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            }
+            *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
+            if (a.ln_out) {
+                // LayerNorm partial of this pixel over the wave's 16 channels: 4 in this lane, 4 lanes (lg) per pixel
+                float sm = (v.x + v.y) + (v.z + v.w);
+                sm = xsum32(xsum16(sm));
+                const float mean = sm * (1.0f / 16.0f);
+                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                m2 = xsum32(xsum16(m2));
+                if (lg == 0) {
+                    float* o = a.ln_out + (prow * (a.Npad / 16) + it * 4 + w) * 2;
+                    o[0] = mean; o[1] = m2;
+                }
+            }
+        }
+    };
+    for (int it = 0; it < ntile; it += 2) {
+        if (it + 1 < ntile) load_w(it + 1, wB);
+        tile(it, wA);
+        if (it + 2 < ntile) load_w(it + 2, wA);
+        if (it + 1 < ntile) tile(it + 1, wB);
+    }
+}
+
 // Merge the per-tile GroupNorm partials of an image: [NI][8][tpi][2] -> [NI][8][2] = (mean, M2) over the whole
 // (image, group); every tile holds 64*gw elements.  Chan's formula, fixed order.
 __global__ void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ merged, int n_stats, int tpi, int gw) {

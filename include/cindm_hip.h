@@ -301,7 +301,8 @@ int  cindm_unet2d_set_sinusoid_table(cindm_unet2d* h, const float* table, int64_
  * :205-208) evaluated for every timestep into a device table. */
 /* Kernel-path selection, as cindm_unet1d_set_option.  Keys: "mfma_f32", "la_site", "conv_ws" (1 = persistent
  * wave-specialised 3x3 kernel, 0 = per-tile kernel, 2 / 3 = only the plain-source / GroupNorm-on-load convolutions on
- * it), "ws_alias" (block-internal temporaries share workspace), "auto_range", "dbg2"/"dbg3". */
+ * it), "tail_h3" (ResnetBlock tails with a res_conv GEMM on the split-fp16 products), "ws_alias" (block-internal
+ * temporaries share workspace), "auto_range", "dbg2"/"dbg3". */
 int  cindm_unet2d_set_option(cindm_unet2d* h, const char* key, int32_t value);
 int  cindm_unet2d_get_option(const cindm_unet2d* h, const char* key, int32_t* value);
 int  cindm_unet2d_finalize(cindm_unet2d* h, void* stream);

@@ -75,8 +75,8 @@ def test_unet1d_paths_chain_and_ragged(gold_dir, device, opts):
     assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
 
 
-@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}],
-                         ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0"])
+@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}, {"tail_h3": 0}],
+                         ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0", "tail_h3_0"])
 def test_unet2d_paths_golden(gold_dir, device, opts):
     from test_gpu_parity_2d import build_unet2d
     g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
