@@ -116,6 +116,41 @@ def test_unet2d_conv_ws_repeatable(device, conv_ws):
             assert torch.equal(cur[n], first[n]), (conv_ws, n, it)
 
 
+def test_unet2d_forward_128_images_repeatable_and_batch_independent(device):
+    """The bench shape of config 5 (128 images per evaluation): every workgroup slot of the GPU is reused several times per
+    launch, which is where two intra-kernel hand-over bugs of round 2 showed (sporadically wrong pixels in workgroups
+    after the first residency wave).  Five forwards must be bit-identical, block by block, and images 60..67 must equal
+    an 8-image forward of the same inputs."""
+    from test_gpu_parity_2d import build_unet2d
+    m, _ = build_unet2d(device)
+    x = torch.randn((128, 21, 64, 64), generator=torch.Generator().manual_seed(3)).to(device)
+    t = torch.full((128,), 500, device=device)
+    names = ["downs.0.1", "downs.1.3", "mid_block1", "mid_attn", "mid_block2", "ups.0.1", "ups.1.1", "final_res_block"]
+    y0 = m(x, t)
+    first = {n: m.tap(n, 128).clone() for n in names}
+    assert bool(torch.isfinite(y0).all())
+    for it in range(4):
+        y = m(x, t)
+        for n in names:
+            assert torch.equal(m.tap(n, 128), first[n]), (n, it)
+        assert torch.equal(y, y0), it
+    y8 = m(x[60:68].contiguous(), t[:8])
+    assert torch.equal(y0[60:68], y8)
+
+
+def test_unet1d_forward_256_rows_repeatable(device, unet8):
+    """The same guard for the 1-D path at the bench batch: five forwards of 256 rows are bit-identical (pair exchanges,
+    head-split attention and the level kernels all hand data between workgroups inside a launch)."""
+    m, _ = unet8
+    x = torch.randn((256, 24, 8), generator=torch.Generator().manual_seed(11)).to(device)
+    t = torch.full((256,), 333, device=device)
+    y0 = m(x, t)
+    assert bool(torch.isfinite(y0).all())
+    for it in range(4):
+        assert torch.equal(m(x, t), y0), it
+    assert torch.equal(m(x[100:104].contiguous(), t[:4]), y0[100:104])
+
+
 # ------------------------------------------------------------------ branches of round 2's fixtures
 @pytest.fixture(scope="module")
 def unet8(device):
