@@ -1225,6 +1225,26 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
     }
 }
 
+// y = LayerNorm_channels(x) * g from the row partials [rows][P][2] (the PreNorm of the bottleneck attention,
+// model/diffusion_2d.py:82-97 / :256): one thread per float4.  A separate 20 us pass so that the qkv projection can run
+// as a plain-source GEMM on conv1x1_tail_h3_kernel (the LayerNorm-on-load variant of that kernel was not reliable).
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, int P, float cnt,
+                                                       const float* __restrict__ g, float* __restrict__ y, int C, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int f4 = C >> 2;
+    const int64_t row = i / f4;
+    const int c4 = (int)(i - row * f4);
+    float mean, rstd;
+    merge_stats(stats + row * P * 2, P, cnt, 1e-5f, mean, rstd);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 pg = *reinterpret_cast<const float4*>(g + c4 * 4);
+    float4 o;
+    o.x = (v.x - mean) * rstd * pg.x; o.y = (v.y - mean) * rstd * pg.y;
+    o.z = (v.z - mean) * rstd * pg.z; o.w = (v.w - mean) * rstd * pg.w;
+    reinterpret_cast<float4*>(y)[i] = o;
+}
+
 // Merge the per-tile GroupNorm partials of an image: [NI][8][tpi][2] -> [NI][8][2] = (mean, M2) over the whole
 // (image, group); every tile holds 64*gw elements.  Chan's formula, fixed order.
 __global__ void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ merged, int n_stats, int tpi, int gw) {
