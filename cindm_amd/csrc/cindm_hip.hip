@@ -49,6 +49,8 @@ struct Packed { size_t off = 0; size_t sz = 0; int T = 0, CinP = 0, Npad = 0, N 
 struct RtbDesc { std::string p; int cin, cout; int tb_off; };
 
 struct cindm_unet1d {
+    const cindm::ComposeArgs* fuse_upd = nullptr;   // set by run_step around one forward: ups_last_kernel also runs this update
+    bool fused_done = false;                          // ... and reports here that it did
     cindm_unet1d_desc d;
     std::vector<Param> params;
     std::unordered_map<std::string, int> index;
@@ -170,6 +172,7 @@ static const OptDef kUnet1dOpts[] = {
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
+    {"fuse_update", 1, "CINDM_FUSE_UPDATE"},   // plain single-model steps: the reverse-step update inside ups_last_kernel (no update launch)
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
@@ -1272,6 +1275,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.pf = pfl;
                 l.x = cur.p; l.skip = skip.p; l.eps = eps; l.F = d.transition_dim;
                 if (taps) { l.h1 = h1.p; l.h2 = h2.p; l.h3 = h3.p; l.up = up.p; l.ypre = ypre.p; }     // tap-only outputs of the last level
+                if (h->fuse_upd && !E.prof) { l.fuse_upd = 1; l.upd = *h->fuse_upd; h->fused_done = true; }
                 const std::string cv[5] = {p + ".0.blocks.0", p + ".0.blocks.1", p + ".1.blocks.0", p + ".1.blocks.1", "final_conv.0"};
                 for (int i = 0; i < 5; ++i) {
                     l.Wc[i] = E.W(h->packed.at(cv[i] + ".block.0#lvl")); l.bc[i] = E.B(h->packed.at(cv[i] + ".block.0"));
@@ -1852,13 +1856,23 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
         hipLaunchKernelGGL(compose_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
         unet_in = a.pair_in;
     }
-    if (cindm_unet1d_forward(pair, unet_in, t, t_dev, (float*)(w + s.off_pair_eps), s.pair_rows, w + s.off_ws_pair,
-                             ws_bytes - s.off_ws_pair, stream) != 0) return -1;
+    // A plain single-model step (configs 1 and 2: the U-Net reads the state, its output row IS the row's prediction, the
+    // update is element-wise and in place): ups_last_kernel runs the update on the rows it has just predicted, so the step
+    // has no compose_update_kernel launch.  Everything else (composition over windows / pairs, a second U-Net, guidance,
+    // DDIM, callers that want mean / x0 / eps back) keeps the separate kernel.
+    const bool can_fuse = c->mode == CINDM_COMPOSE_PLAIN && s.direct && !s.single_rows && !guided && !io.ddim_tab && io.x_out == io.x &&
+                          !io.mean_out && !io.x0_out && !io.eps_out && !io.inp_cond && pair->O("fuse_update") && (a.F & 3) == 0;
+    pair->fused_done = false;
+    pair->fuse_upd = can_fuse ? &a : nullptr;
+    const int frc = cindm_unet1d_forward(pair, unet_in, t, t_dev, (float*)(w + s.off_pair_eps), s.pair_rows, w + s.off_ws_pair,
+                                         ws_bytes - s.off_ws_pair, stream);
+    pair->fuse_upd = nullptr;
+    if (frc != 0) return -1;
     if (s.single_rows &&
         cindm_unet1d_forward(uncond, a.single_in, t, t_dev, (float*)(w + s.off_single_eps), s.single_rows,
                              w + s.off_ws_single, ws_bytes - s.off_ws_single, stream) != 0) return -1;
     const int64_t ne = B * (int64_t)Ltot * a.F;
-    hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);
+    if (!pair->fused_done) hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);
     if (io.dec_t) {
         // the counter kernel also advances the U-Nets' exchange epochs for the step that follows
         hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, io.ddim_tab ? io.ddim_tnext : (const int*)nullptr,

@@ -2135,6 +2135,62 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
 //   -> Upsample1d (ConvTranspose1d k4 s2 p1, L -> 2L) -> final Conv1dBlock(64 -> 64, k5) -> Conv1d(64 -> F, 1)
 // (model/diffusion_1d.py:576-583, :635-646, :100-106, :605-608).  Same machinery as the down-level kernels; 8 launches
 // become one.  In the 128-channel block a wave owns two 16-channel tiles (= two GroupNorm groups), afterwards one.
+// Composition / DDPM update arguments (the kernels are further down; defined here because ups_last_kernel can run the
+// update of a plain single-model step in its own epilogue: UpsLastArgs::upd)
+struct ComposeArgs {
+    int mode, W, cs, T, nb, cond_steps, objective, clip;
+    float uncond_coef;
+    int64_t B;
+    int Ltot;            // rows of the state x per sample (excludes cond rows)
+    int F;               // 4 * nb
+    const float* x;      // [B, Ltot, F]
+    const float* cond;   // [B, cond_steps, F] or null
+    float* pair_in;      // [(kk*P+p)*B + b, T, 8]
+    float* single_in;    // MULTIBODY: [i*B + b, T, 4]
+    const float* pair_eps;
+    const float* single_eps;
+    // schedule tables (device, [timesteps])
+    const float* sqrt_recip; const float* sqrt_recipm1; const float* sqrt_ac; const float* sqrt_1mac;
+    const float* coef1; const float* coef2; const float* logvar;
+    const int* t_ptr; int t_imm;
+    // outputs
+    float* mean_out; float* x0_out; float* eps_out;   // predict
+    float* x_out;                                      // step: x_{t-1} (may alias x)
+    const float* noise; int64_t noise_t_stride;        // explicit noise (+ t * stride), or null
+    uint64_t seed; int64_t sample_off; int add_noise;
+    const unsigned long long* dyn;      // sample loops: (seed, sample_off) in device memory, so that a captured step is reusable across calls
+    const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
+    int* t_dec; unsigned* done;     // unused by the kernel: the host launches step_counter_kernel after the update
+    // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
+    // device step index; noise tapes are then indexed by the step index instead of t
+    const float* ddim_tab; const int* ddim_tnext; int* step_idx;
+    // built-in design objective (the paper's point objective, inference/inverse_design_diffusion_1d.py:211-229) with
+    // "standard" / "standard-alpha" (-recurrence-N) guidance: pred = mean - [eta_t] * grad_x objective(x)
+    int dz_mode;                 // 0 off, 1 "L2", 2 "L2square"
+    int dz_alpha;                // 1: scale the gradient by eta_t = beta_t / sqrt(alphas_cumprod_prev_t) (standard-alpha)
+    int dz_last_n; float dz_coef, dz_tc, dz_tx, dz_ty;
+    int relax;                   // this launch is a relaxation iteration (:1365-1367): x <- a_t pred + b_t z'
+    const float* recur_noise;    // explicit z' of this iteration (+ t * recur_t_stride), or null (counter-based, tag below)
+    int64_t recur_t_stride; uint32_t recur_tag;
+    const float* iso; int iso_steps;     // initial_state_overwrite [B, iso_steps, F] (:1352-1361) or null
+    const float* betas; const float* ac; const float* acp;     // schedule tables for eta_t and the relaxation
+};
+// the update of state element i = (b * Ltot + row) * F + f (compose_update_kernel's body)
+__device__ void compose_update_element(const ComposeArgs& a, int64_t i);
+__device__ __forceinline__ void counter_normal4(uint64_t seed, uint64_t sample, uint32_t step, uint32_t elem4, float (&z)[4]);
+// x_{t-1} of one element of a PLAIN single-model step from the model output o (compose_update_element's mode 0 followed
+// by its unguided DDPM tail, operation for operation: the fused and the separate update are bit-identical)
+__device__ __forceinline__ float plain_step_value(const ComposeArgs& a, int t, float xv, float o, float z) {
+    float x0;
+    if (a.objective == 0) x0 = __fsub_rn(__fmul_rn(a.sqrt_recip[t], xv), __fmul_rn(a.sqrt_recipm1[t], o));
+    else if (a.objective == 1) x0 = o;
+    else x0 = __fsub_rn(__fmul_rn(a.sqrt_ac[t], xv), __fmul_rn(a.sqrt_1mac[t], o));
+    if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    float v = __fadd_rn(__fmul_rn(a.coef1[t], x0), __fmul_rn(a.coef2[t], xv));
+    if (a.add_noise && t > 0) v += expf(0.5f * a.logvar[t]) * z;
+    return v;
+}
+
 struct UpsLastArgs {
     const float* x; const float* skip;                   // [Bp, L, 128] each (torch.cat((x, h.pop()), dim=1))
     float* h1; float* h2; float* h3; float* up; float* ypre; float* eps; int F;      // h1 [Bp, L, 128]; h2, h3 [Bp, L, 64]; up, ypre [Bp, 2L, 64]
@@ -2147,6 +2203,7 @@ struct UpsLastArgs {
     const int* t_ptr; int t_imm;
     int L;
     Pf pf;                                               // L2 warm-up for the next launch (the next step's first kernel)
+    int fuse_upd; ComposeArgs upd;                       // plain single-model step: x_{t-1} from this kernel's eps rows, in place
 };
 
 __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
@@ -2381,15 +2438,47 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     lvl_to_planes<2, PPB>(y[0], P[0][0], P[0][1], c0, 2, L2, lane);
     __syncthreads();
     if (w == 0) {
+        // Plain single-model step (UpsLastArgs::upd): the lanes that hold the prediction of 4 state elements also apply the
+        // reverse-step update to them, in place -- no compose_update_kernel launch.  The state values and the noise of those
+        // elements are fetched / generated BEFORE the final projection, so the update adds a few FMAs to this kernel's tail.
+        float4 xq[2] = {}, zq[2] = {};
+        const ComposeArgs& u = a.upd;
+        const int tu = a.fuse_upd ? (u.t_ptr ? *u.t_ptr : u.t_imm) : 0;
+        if (a.fuse_upd) {
+            const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
+            const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = nt * 16 + lr;
+                if (n < L2 && lq * 4 < a.F) {
+                    const size_t i0 = ((size_t)b * L2 + n) * a.F + lq * 4;
+                    xq[nt] = *reinterpret_cast<const float4*>(u.x + i0);
+                    if (u.add_noise && tu > 0) {
+                        if (u.noise) zq[nt] = *reinterpret_cast<const float4*>(u.noise + (size_t)tu * u.noise_t_stride + i0);
+                        else {
+                            float z4[4];
+                            counter_normal4(dseed, (uint64_t)(dsoff + b), (uint32_t)tu, (uint32_t)((n * a.F + lq * 4) >> 2), z4);
+                            zq[nt] = make_float4(z4[0], z4[1], z4[2], z4[3]);
+                        }
+                    }
+                }
+            }
+        }
         f32x4 e[1][2];
         lvlm_conv<1, 2, 1, 2, PPB, 8>(ring, reinterpret_cast<const float4*>(a.Wf), P[0][0], P[0][1], 16, 1, 2, ROWS2 - 1, lane, e);
         const float4 bf = *reinterpret_cast<const float4*>(&PV[13][lq * 4]);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = nt * 16 + lr;
-            if (n < L2 && lq * 4 < a.F)
-                *reinterpret_cast<float4*>(a.eps + ((size_t)b * L2 + n) * a.F + lq * 4) =
-                    make_float4(e[0][nt][0] + bf.x, e[0][nt][1] + bf.y, e[0][nt][2] + bf.z, e[0][nt][3] + bf.w);
+            if (n < L2 && lq * 4 < a.F) {
+                const size_t i0 = ((size_t)b * L2 + n) * a.F + lq * 4;
+                const float4 o = make_float4(e[0][nt][0] + bf.x, e[0][nt][1] + bf.y, e[0][nt][2] + bf.z, e[0][nt][3] + bf.w);
+                *reinterpret_cast<float4*>(a.eps + i0) = o;
+                if (a.fuse_upd)
+                    *reinterpret_cast<float4*>(u.x_out + i0) =
+                        make_float4(plain_step_value(u, tu, xq[nt].x, o.x, zq[nt].x), plain_step_value(u, tu, xq[nt].y, o.y, zq[nt].y),
+                                    plain_step_value(u, tu, xq[nt].z, o.z, zq[nt].z), plain_step_value(u, tu, xq[nt].w, o.w, zq[nt].w));
+            }
         }
     }
     l2_prefetch_done(a.pf, pfr);
@@ -2682,44 +2771,7 @@ __global__ void fill_normal_kernel(float* out, int64_t B, int64_t per, uint64_t 
 
 // ---------------------------------------------------------------------------------------------
 // Composition: gather U-Net input rows, and scatter-aggregate + DDPM posterior update.
-struct ComposeArgs {
-    int mode, W, cs, T, nb, cond_steps, objective, clip;
-    float uncond_coef;
-    int64_t B;
-    int Ltot;            // rows of the state x per sample (excludes cond rows)
-    int F;               // 4 * nb
-    const float* x;      // [B, Ltot, F]
-    const float* cond;   // [B, cond_steps, F] or null
-    float* pair_in;      // [(kk*P+p)*B + b, T, 8]
-    float* single_in;    // MULTIBODY: [i*B + b, T, 4]
-    const float* pair_eps;
-    const float* single_eps;
-    // schedule tables (device, [timesteps])
-    const float* sqrt_recip; const float* sqrt_recipm1; const float* sqrt_ac; const float* sqrt_1mac;
-    const float* coef1; const float* coef2; const float* logvar;
-    const int* t_ptr; int t_imm;
-    // outputs
-    float* mean_out; float* x0_out; float* eps_out;   // predict
-    float* x_out;                                      // step: x_{t-1} (may alias x)
-    const float* noise; int64_t noise_t_stride;        // explicit noise (+ t * stride), or null
-    uint64_t seed; int64_t sample_off; int add_noise;
-    const unsigned long long* dyn;      // sample loops: (seed, sample_off) in device memory, so that a captured step is reusable across calls
-    const float* inp_cond; int inp_steps; const float* inp_noise; int64_t inp_noise_t_stride;
-    int* t_dec; unsigned* done;     // unused by the kernel: the host launches step_counter_kernel after the update
-    // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
-    // device step index; noise tapes are then indexed by the step index instead of t
-    const float* ddim_tab; const int* ddim_tnext; int* step_idx;
-    // built-in design objective (the paper's point objective, inference/inverse_design_diffusion_1d.py:211-229) with
-    // "standard" / "standard-alpha" (-recurrence-N) guidance: pred = mean - [eta_t] * grad_x objective(x)
-    int dz_mode;                 // 0 off, 1 "L2", 2 "L2square"
-    int dz_alpha;                // 1: scale the gradient by eta_t = beta_t / sqrt(alphas_cumprod_prev_t) (standard-alpha)
-    int dz_last_n; float dz_coef, dz_tc, dz_tx, dz_ty;
-    int relax;                   // this launch is a relaxation iteration (:1365-1367): x <- a_t pred + b_t z'
-    const float* recur_noise;    // explicit z' of this iteration (+ t * recur_t_stride), or null (counter-based, tag below)
-    int64_t recur_t_stride; uint32_t recur_tag;
-    const float* iso; int iso_steps;     // initial_state_overwrite [B, iso_steps, F] (:1352-1361) or null
-    const float* betas; const float* ac; const float* acp;     // schedule tables for eta_t and the relaxation
-};
+// (struct ComposeArgs is defined above UpsLastArgs: ups_last_kernel can carry the update of a plain single-model step)
 
 __device__ __forceinline__ int pair_index(int i, int j, int nb) {   // i < j, order (0,1),(0,2),..,(1,2),..
     return i * nb - (i * (i + 1)) / 2 + (j - i - 1);
@@ -2768,9 +2820,8 @@ __global__ void compose_gather_kernel(const ComposeArgs a) {
 }
 
 // One thread per state element (b, l, f) of the FULL sequence (cond rows skipped on output).
-__global__ void compose_update_kernel(const ComposeArgs a) {
+__device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
     const int Lfull = a.Ltot + a.cond_steps;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
     const int sidx = a.ddim_tab ? *a.step_idx : 0;
     const uint64_t dseed = a.dyn ? (uint64_t)a.dyn[0] : a.seed;
@@ -2942,6 +2993,10 @@ __global__ void compose_update_kernel(const ComposeArgs a) {
         a.x_out[i] = v;
     }
     }
+}
+
+__global__ void compose_update_kernel(const ComposeArgs a) {
+    compose_update_element(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Advances the device-side step counter after the update kernel of a step (its own graph node: every reader of t in this

@@ -82,7 +82,8 @@ int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
  * Keys: "mfma_f32" (1 = exact fp32 MFMA kernels instead of the split-fp16 ones), "local_gn", "attn_site",
  * "wide_qkv", "level0", "level1", "ups_last", "ups_tail", "h3_resample", "site_pack", "dconv", "dconv_pair",
  * "attn_head", "l2_prefetch", "auto_range" (1 = a checkpoint whose conv / projection weights leave the split-fp16 window
- * 2^-12 <= max|w| <= 2^15 runs on the fp32 kernels; "range_fallback" then reads 1), "taps" (1 = block outputs that live
+ * 2^-12 <= max|w| <= 2^15 runs on the fp32 kernels; "range_fallback" then reads 1), "fuse_update" (plain single-model
+ * steps apply the DDPM update inside the last U-Net kernel), "taps" (1 = block outputs that live
  * only inside a level kernel are also stored for cindm_unet1d_tap; off on the sampling path),
  * "dbg"/"dbg3"/"dbg4" (timing ablations, wrong results).  No reference counterpart (PyTorch picks its own kernels). */
 int  cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value);

@@ -138,6 +138,28 @@ def test_unet2d_forward_128_images_repeatable_and_batch_independent(device):
     assert torch.equal(y0[60:68], y8)
 
 
+@pytest.mark.parametrize("objective", ["pred_noise", "pred_x0", "pred_v"])
+def test_fused_update_equals_update_kernel(device, unet8, objective):
+    """Plain single-model steps run their reverse-step update inside ups_last_kernel (option fuse_update); it must be
+    bit-identical to the separate compose_update_kernel -- counter-based noise and an explicit tape, every objective."""
+    m, _ = unet8
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000,
+                                      objective=objective).to(device)
+    tape = _tape(5, (19, 24, 8), 1000)
+    res = {}
+    try:
+        for v in (0, 1):
+            m.set_option("fuse_update", v)
+            res[v] = (d.sample(batch_size=19, n_composed=0, compose_n_bodies=2, seed=17, sample_offset=3, t_stop=985),
+                      d.sample(batch_size=19, n_composed=0, compose_n_bodies=2, noise=tape, t_stop=985),
+                      d.sample(batch_size=19, n_composed=0, compose_n_bodies=2, seed=17, sample_offset=3, t_stop=985, use_graph=False))
+    finally:
+        m.set_option("fuse_update", 1)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[1][0], res[1][2])
+
+
 def test_unet1d_forward_256_rows_repeatable(device, unet8):
     """The same guard for the 1-D path at the bench batch: five forwards of 256 rows are bit-identical (pair exchanges,
     head-split attention and the level kernels all hand data between workgroups inside a launch)."""
