@@ -160,6 +160,23 @@ def test_fused_update_equals_update_kernel(device, unet8, objective):
     assert torch.equal(res[1][0], res[1][2])
 
 
+def test_chains_repeatable_at_bench_shape(device, unet8):
+    """Whole chains at the shapes bench.py runs -- config 2 (256 designs, 1000 steps) and config 5 (64 designs x 2 boundaries,
+    25 steps) -- twice with the same seed: bit-identical (graph replay of kernels that hand data between workgroups)."""
+    from test_gpu_parity_2d import build_unet2d
+    m, _ = unet8
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    a = d.sample(batch_size=256, n_composed=0, compose_n_bodies=2, seed=5)
+    b = d.sample(batch_size=256, n_composed=0, compose_n_bodies=2, seed=5)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    m2, _ = build_unet2d(device)
+    d2 = cindm_amd.GaussianDiffusion(m2, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                     loss_type="l2").to(device)
+    a2 = d2.sample(batch_size=64, num_boundaries=2, seed=5, t_stop=975)
+    b2 = d2.sample(batch_size=64, num_boundaries=2, seed=5, t_stop=975)
+    assert bool(torch.isfinite(a2).all()) and torch.equal(a2, b2)
+
+
 def test_unet1d_forward_256_rows_repeatable(device, unet8):
     """The same guard for the 1-D path at the bench batch: five forwards of 256 rows are bit-identical (pair exchanges,
     head-split attention and the level kernels all hand data between workgroups inside a launch)."""
