@@ -6,8 +6,9 @@
 // "transposed" layers: convolution backward-data = the same convolution kernel on flipped / transposed weights
 // (packed once at finalize), plus the derivative kernels of GroupNorm+SiLU, LayerNorm, linear attention, softmax
 // attention, pixel-unshuffle and the mean-pool / Linear head.  Layout: channel-last fp32 [image][pixel][C], as the rest
-// of the 2-D path.  Convolutions run on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32): this module is written for
-// correctness first (gradient parity 2e-5 against torch autograd of the CPU restatement); it is not yet on the split-fp16 pipe.
+// of the 2-D path.  The kernels here run on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32); the host side routes the FORWARD
+// 3x3 convolutions of the 64 / 32 / 16-pixel levels through conv2d_ws_kernel (kernels2d_v2.h, split-fp16 products), the
+// input-gradient pass stays here (gradient parity 2e-5 against torch autograd of the CPU restatement).
 #pragma once
 #include "kernels.h"
 
