@@ -99,69 +99,121 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// GroupNorm(8 groups) statistics per (image, group): two passes (mean, then M2) -> (mean, rstd)
+// GroupNorm(8 groups) + SiLU and its derivative.  All four kernels move float4 (4 channels of one pixel: a group is at
+// least 8 channels wide, so a float4 never straddles groups) with the channel quad fixed per thread: rows are read whole
+// and coalesced.  (The first version ran one workgroup per (image, group) over a 32-byte-per-pixel strided slice with
+// 4-byte accesses: 12 % of every cache line it touched.)  Reductions are fixed-order (no atomics): results repeat bit
+// for bit.  Requires (C / 4) to divide 256 (C <= 1024, a power of two).
+//
+// statistics per (image, group): two passes (mean, then M2) -> (mean, rstd); one workgroup per image
+__device__ __forceinline__ void fu_group_reduce(float v, float (&red)[256], float (&out)[8], int tid, int tpg) {
+    red[tid] = v;
+    __syncthreads();
+    if (tid < 8) {                                          // group g = the threads whose (tid % f4) / (f4 / 8) == g
+        float s = 0.f;
+        const int f4 = tpg * 8;
+        for (int rep = 0; rep < 256 / f4; ++rep)
+            for (int k = 0; k < tpg; ++k) s += red[rep * f4 + tid * tpg + k];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C) {
     __shared__ float red[256];
-    const int g = blockIdx.x, img = blockIdx.y, gw = C / 8, n = HW * gw, tid = threadIdx.x;
-    const float* base = x + (size_t)img * HW * C + g * gw;
+    __shared__ float tot[8];
+    const int img = blockIdx.x, tid = threadIdx.x, f4 = C >> 2, tpg = f4 >> 3, ppp = 256 / f4;      // pixels per pass
+    const int c4 = tid % f4, p0 = tid / f4;
+    const float4* base = reinterpret_cast<const float4*>(x + (size_t)img * HW * C) + c4;
+    const float n = (float)HW * (float)(C / 8);
     float s = 0.f;
-    for (int i = tid; i < n; i += 256) s += base[(size_t)(i / gw) * C + (i % gw)];
-    red[tid] = s; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    const float mean = red[0] / (float)n;
+    for (int p = p0; p < HW; p += ppp) { const float4 v = base[(size_t)p * f4]; s += (v.x + v.y) + (v.z + v.w); }
+    fu_group_reduce(s, red, tot, tid, tpg);
+    const int g = c4 / tpg;
+    const float mean = tot[g] / n;
     __syncthreads();
     float m2 = 0.f;
-    for (int i = tid; i < n; i += 256) { const float d = base[(size_t)(i / gw) * C + (i % gw)] - mean; m2 += d * d; }
-    red[tid] = m2; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) { stats[((size_t)img * 8 + g) * 2] = mean; stats[((size_t)img * 8 + g) * 2 + 1] = 1.0f / sqrtf(red[0] / (float)n + 1e-5f); }
+    for (int p = p0; p < HW; p += ppp) {
+        const float4 v = base[(size_t)p * f4];
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    fu_group_reduce(m2, red, tot, tid, tpg);
+    if (tid < f4 && (c4 % tpg) == 0) {                      // tid < f4: pixel slot 0; one writer per group
+        stats[((size_t)img * 8 + g) * 2] = mean;
+        stats[((size_t)img * 8 + g) * 2 + 1] = 1.0f / sqrtf(tot[g] / n + 1e-5f);
+    }
 }
 
-// y = SiLU(GN(x)) [+ res]
+// y = SiLU(GN(x)) [+ res]; one float4 per thread
 __global__ void fu_gn_silu_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gam,
                                   const float* __restrict__ bet, const float* __restrict__ res, float* __restrict__ y,
                                   int64_t total, int HW, int C) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // float4 index; total = elements / 4
     if (i >= total) return;
-    const int c = (int)(i % C), img = (int)(i / ((int64_t)HW * C)), g = c / (C / 8);
+    const int f4 = C >> 2;
+    const int c4 = (int)(i % f4), img = (int)(i / ((int64_t)HW * f4)), g = c4 / (f4 >> 3);
     const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
-    const float u = (x[i] - m) * r * gam[c] + bet[c];
-    const float v = u * fu_sigmoid(u);
-    y[i] = res ? v + res[i] : v;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 ga = *reinterpret_cast<const float4*>(gam + c4 * 4), be = *reinterpret_cast<const float4*>(bet + c4 * 4);
+    float4 o;
+    { const float u = (v.x - m) * r * ga.x + be.x; o.x = u * fu_sigmoid(u); }
+    { const float u = (v.y - m) * r * ga.y + be.y; o.y = u * fu_sigmoid(u); }
+    { const float u = (v.z - m) * r * ga.z + be.z; o.z = u * fu_sigmoid(u); }
+    { const float u = (v.w - m) * r * ga.w + be.w; o.w = u * fu_sigmoid(u); }
+    if (res) { const float4 q = reinterpret_cast<const float4*>(res)[i]; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+    reinterpret_cast<float4*>(y)[i] = o;
 }
 
 // backward of y = SiLU(GN(x)): pass 1 reduces S1 = sum dz, S2 = sum dz * z per (image, group) (dz = dy * silu'(u) * gamma,
 // z = (x - mean) * rstd); pass 2 applies dx = rstd * (dz - S1 / n - z * S2 / n).
+__device__ __forceinline__ void fu_gn_dz(float xv, float dyv, float m, float r, float ga, float be, float& z, float& dz) {
+    z = (xv - m) * r;
+    const float u = z * ga + be, sg = fu_sigmoid(u);
+    dz = dyv * (sg * (1.0f + u * (1.0f - sg))) * ga;
+}
 __global__ __launch_bounds__(256) void fu_gn_silu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      const float* __restrict__ stats, const float* __restrict__ gam,
                                                                      const float* __restrict__ bet, float* __restrict__ sums, int HW, int C) {
-    __shared__ float r1[256], r2[256];
-    const int g = blockIdx.x, img = blockIdx.y, gw = C / 8, n = HW * gw, tid = threadIdx.x;
-    const size_t base = (size_t)img * HW * C + g * gw;
+    __shared__ float red[256];
+    __shared__ float t1[8], t2[8];
+    const int img = blockIdx.x, tid = threadIdx.x, f4 = C >> 2, tpg = f4 >> 3, ppp = 256 / f4;
+    const int c4 = tid % f4, p0 = tid / f4, g = c4 / tpg;
+    const size_t ib = (size_t)img * HW * f4 + c4;
     const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
+    const float4 ga = *reinterpret_cast<const float4*>(gam + c4 * 4), be = *reinterpret_cast<const float4*>(bet + c4 * 4);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const int c = g * gw + (i % gw);
-        const size_t idx = base + (size_t)(i / gw) * C + (i % gw);
-        const float z = (x[idx] - m) * r, u = z * gam[c] + bet[c], sg = fu_sigmoid(u);
-        const float dz = dy[idx] * (sg * (1.0f + u * (1.0f - sg))) * gam[c];
-        s1 += dz; s2 += dz * z;
+    for (int p = p0; p < HW; p += ppp) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[ib + (size_t)p * f4], dv = reinterpret_cast<const float4*>(dy)[ib + (size_t)p * f4];
+        float z, dz;
+        fu_gn_dz(xv.x, dv.x, m, r, ga.x, be.x, z, dz); s1 += dz; s2 += dz * z;
+        fu_gn_dz(xv.y, dv.y, m, r, ga.y, be.y, z, dz); s1 += dz; s2 += dz * z;
+        fu_gn_dz(xv.z, dv.z, m, r, ga.z, be.z, z, dz); s1 += dz; s2 += dz * z;
+        fu_gn_dz(xv.w, dv.w, m, r, ga.w, be.w, z, dz); s1 += dz; s2 += dz * z;
     }
-    r1[tid] = s1; r2[tid] = s2; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; } __syncthreads(); }
-    if (tid == 0) { sums[((size_t)img * 8 + g) * 2] = r1[0] / (float)n; sums[((size_t)img * 8 + g) * 2 + 1] = r2[0] / (float)n; }
+    fu_group_reduce(s1, red, t1, tid, tpg);
+    fu_group_reduce(s2, red, t2, tid, tpg);
+    const float n = (float)HW * (float)(C / 8);
+    if (tid < 8) { sums[((size_t)img * 8 + tid) * 2] = t1[tid] / n; sums[((size_t)img * 8 + tid) * 2 + 1] = t2[tid] / n; }
 }
 __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                             const float* __restrict__ sums, const float* __restrict__ gam, const float* __restrict__ bet,
                                             float* __restrict__ dx, float beta, int64_t total, int HW, int C) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // float4 index; total = elements / 4
     if (i >= total) return;
-    const int c = (int)(i % C), img = (int)(i / ((int64_t)HW * C)), g = c / (C / 8);
+    const int f4 = C >> 2;
+    const int c4 = (int)(i % f4), img = (int)(i / ((int64_t)HW * f4)), g = c4 / (f4 >> 3);
     const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
-    const float z = (x[i] - m) * r, u = z * gam[c] + bet[c], sg = fu_sigmoid(u);
-    const float dz = dy[i] * (sg * (1.0f + u * (1.0f - sg))) * gam[c];
-    const float v = r * (dz - sums[((size_t)img * 8 + g) * 2] - z * sums[((size_t)img * 8 + g) * 2 + 1]);
-    dx[i] = beta != 0.f ? beta * dx[i] + v : v;
+    const float a1 = sums[((size_t)img * 8 + g) * 2], a2 = sums[((size_t)img * 8 + g) * 2 + 1];
+    const float4 xv = reinterpret_cast<const float4*>(x)[i], dv = reinterpret_cast<const float4*>(dy)[i];
+    const float4 ga = *reinterpret_cast<const float4*>(gam + c4 * 4), be = *reinterpret_cast<const float4*>(bet + c4 * 4);
+    float z, dz;
+    float4 v;
+    fu_gn_dz(xv.x, dv.x, m, r, ga.x, be.x, z, dz); v.x = r * (dz - a1 - z * a2);
+    fu_gn_dz(xv.y, dv.y, m, r, ga.y, be.y, z, dz); v.y = r * (dz - a1 - z * a2);
+    fu_gn_dz(xv.z, dv.z, m, r, ga.z, be.z, z, dz); v.z = r * (dz - a1 - z * a2);
+    fu_gn_dz(xv.w, dv.w, m, r, ga.w, be.w, z, dz); v.w = r * (dz - a1 - z * a2);
+    if (beta != 0.f) { const float4 o = reinterpret_cast<float4*>(dx)[i]; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
+    reinterpret_cast<float4*>(dx)[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -239,33 +291,31 @@ __global__ __launch_bounds__(256) void fu_la_kstat_kernel(const float* __restric
         kstat[((size_t)img * 128 + h * 32 + d) * 2] = mx; kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1] = s;
     }
 }
-// qs[n][h*32+d] = softmax_d(q) * scale ; ks[n][h*32+d] = exp(k - max_n) / sum_n: one thread per (pixel, head)
+// qs[n][h*32+d] = softmax_d(q) * scale ; ks[n][h*32+d] = exp(k - max_n) / sum_n.  One lane per float4 (4 channels of one
+// pixel): a wave covers two pixels with fully coalesced 16-byte accesses, the softmax over a head's 32 channels is a
+// reduction over 8 adjacent lanes (the first version ran one thread per (pixel, head): 64 cache lines per load).
+__device__ __forceinline__ float fu_red8_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return fmaxf(v, __shfl_xor(v, 4)); }
+__device__ __forceinline__ float fu_red8_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v + __shfl_xor(v, 4); }
 __global__ __launch_bounds__(256) void fu_la_prep_kernel(const float* __restrict__ qkv, const float* __restrict__ kstat,
                                                          float* __restrict__ qs, float* __restrict__ ks, int n, int64_t total) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // total = pixels * 32 float4 lanes (always whole waves)
     if (t >= total) return;
-    const int h = (int)(t & 3);
-    const int64_t pix = t >> 2;
+    const int c4 = (int)(t & 31);
+    const int64_t pix = t >> 5;
     const int img = (int)(pix / n);
-    const float* qp = qkv + pix * 384 + h * 32;
-    float q[32], mx = -INFINITY, sm = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; j += 4) { const float4 v = *reinterpret_cast<const float4*>(qp + j); q[j] = v.x; q[j + 1] = v.y; q[j + 2] = v.z; q[j + 3] = v.w; }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) mx = fmaxf(mx, q[j]);
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { q[j] = __expf(q[j] - mx); sm += q[j]; }
+    const float4 q = *reinterpret_cast<const float4*>(qkv + pix * 384 + c4 * 4);
+    const float mx = fu_red8_max(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+    float4 e = make_float4(__expf(q.x - mx), __expf(q.y - mx), __expf(q.z - mx), __expf(q.w - mx));
+    const float sm = fu_red8_sum((e.x + e.y) + (e.z + e.w));
     const float sc = 0.17677669529663687f / sm;
-    const float* st = kstat + ((size_t)img * 128 + h * 32) * 2;
-#pragma unroll
-    for (int j = 0; j < 32; j += 4) {
-        *reinterpret_cast<float4*>(qs + pix * 128 + h * 32 + j) = make_float4(q[j] * sc, q[j + 1] * sc, q[j + 2] * sc, q[j + 3] * sc);
-        const float4 kv = *reinterpret_cast<const float4*>(qp + 128 + j);
-        float4 o;
-        o.x = __expf(kv.x - st[2 * j]) / st[2 * j + 1]; o.y = __expf(kv.y - st[2 * j + 2]) / st[2 * j + 3];
-        o.z = __expf(kv.z - st[2 * j + 4]) / st[2 * j + 5]; o.w = __expf(kv.w - st[2 * j + 6]) / st[2 * j + 7];
-        *reinterpret_cast<float4*>(ks + pix * 128 + h * 32 + j) = o;
-    }
+    *reinterpret_cast<float4*>(qs + pix * 128 + c4 * 4) = make_float4(e.x * sc, e.y * sc, e.z * sc, e.w * sc);
+    const float* st = kstat + ((size_t)img * 128 + c4 * 4) * 2;
+    const float4 s01 = *reinterpret_cast<const float4*>(st), s23 = *reinterpret_cast<const float4*>(st + 4);
+    const float4 kv = *reinterpret_cast<const float4*>(qkv + pix * 384 + 128 + c4 * 4);
+    float4 o;
+    o.x = __expf(kv.x - s01.x) / s01.y; o.y = __expf(kv.y - s01.z) / s01.w;
+    o.z = __expf(kv.z - s23.x) / s23.y; o.w = __expf(kv.w - s23.z) / s23.w;
+    *reinterpret_cast<float4*>(ks + pix * 128 + c4 * 4) = o;
 }
 // M[img][h][d][e] = alpha * sum_n X[img][n][xoff + h*32 + d] * Y[img][n][yoff + h*32 + e]; workgroup = (head, image), the
 // four waves split n, fp32 MFMA 16x16x4 (A[i = d][k = pixel], B[k = pixel][j = e]), partial tiles summed through LDS.
@@ -340,29 +390,27 @@ __global__ __launch_bounds__(256) void fu_la_bwd_kdot_kernel(const float* __rest
         T[(size_t)img * 128 + h * 32 + d] = s;
     }
 }
-// dqkv[n][384]: dq = s (dqs - sum_d s dqs) with s = softmax(q) = qs / scale (dqs already scaled by nothing: the scale
-// sits in qs), dk = ks (dks - T), dv as given.  One thread per (pixel, head); dqs / dks / dv are [img][n][128].
+// dqkv[n][384]: dq = s (dqs - sum_d s dqs) with s = softmax(q) = qs / scale (the scale sits in qs), dk = ks (dks - T), dv as
+// given; dqs / dks / dv are [img][n][128].  One lane per float4, the per-head dot product over 8 adjacent lanes.
 __global__ __launch_bounds__(256) void fu_la_bwd_apply_kernel(const float* __restrict__ qs, const float* __restrict__ ks, const float* __restrict__ dqs,
                                                               const float* __restrict__ dks, const float* __restrict__ dv, const float* __restrict__ T,
                                                               float* __restrict__ dqkv, int n, int64_t total) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // total = pixels * 32 float4 lanes
     if (t >= total) return;
-    const int h = (int)(t & 3);
-    const int64_t pix = t >> 2;
+    const int c4 = (int)(t & 31);
+    const int64_t pix = t >> 5;
     const int img = (int)(pix / n);
-    const size_t o = pix * 128 + h * 32;
-    float dot = 0.f;
-#pragma unroll
-    for (int d = 0; d < 32; ++d) dot += qs[o + d] * dqs[o + d];              // = scale * sum_d s_d dqs_d
-#pragma unroll
-    for (int d = 0; d < 32; ++d) {
-        // q_s = scale * s  =>  dq_d = scale * s_d * (dqs_d - sum_j s_j dqs_j) = qs_d * (dqs_d - dot / scale)
-        dqkv[pix * 384 + h * 32 + d] = qs[o + d] * (dqs[o + d] - dot * 5.656854249492381f);
-        dqkv[pix * 384 + 128 + h * 32 + d] = ks[o + d] * (dks[o + d] - T[(size_t)img * 128 + h * 32 + d]);
-        dqkv[pix * 384 + 256 + h * 32 + d] = dv[o + d];
-    }
+    const size_t o = pix * 128 + c4 * 4;
+    const float4 a = *reinterpret_cast<const float4*>(qs + o), b = *reinterpret_cast<const float4*>(dqs + o);
+    const float dot = fu_red8_sum((a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w)) * 5.656854249492381f;   // = sum_d s_d dqs_d
+    // q_s = scale * s  =>  dq_d = scale * s_d * (dqs_d - sum_j s_j dqs_j) = qs_d * (dqs_d - dot)
+    *reinterpret_cast<float4*>(dqkv + pix * 384 + c4 * 4) = make_float4(a.x * (b.x - dot), a.y * (b.y - dot), a.z * (b.z - dot), a.w * (b.w - dot));
+    const float4 k4 = *reinterpret_cast<const float4*>(ks + o), dk4 = *reinterpret_cast<const float4*>(dks + o);
+    const float4 t4 = *reinterpret_cast<const float4*>(T + (size_t)img * 128 + c4 * 4);
+    *reinterpret_cast<float4*>(dqkv + pix * 384 + 128 + c4 * 4) =
+        make_float4(k4.x * (dk4.x - t4.x), k4.y * (dk4.y - t4.y), k4.z * (dk4.z - t4.z), k4.w * (dk4.w - t4.w));
+    *reinterpret_cast<float4*>(dqkv + pix * 384 + 256 + c4 * 4) = *reinterpret_cast<const float4*>(dv + o);
 }
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Softmax attention of the bottleneck (model/diffusion_2d.py:266-278), n <= 64 tokens: one workgroup of n threads per
 // (image, head).  fwd: out[i][h*32+d] = sum_j softmax_j(q_i.k_j * scale) v_j[d].  bwd: dqkv from dout (recomputes P).
