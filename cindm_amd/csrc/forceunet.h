@@ -6,9 +6,11 @@
 // "transposed" layers: convolution backward-data = the same convolution kernel on flipped / transposed weights
 // (packed once at finalize), plus the derivative kernels of GroupNorm+SiLU, LayerNorm, linear attention, softmax
 // attention, pixel-unshuffle and the mean-pool / Linear head.  Layout: channel-last fp32 [image][pixel][C], as the rest
-// of the 2-D path.  The kernels here run on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32); the host side routes the FORWARD
-// 3x3 convolutions of the 64 / 32 / 16-pixel levels through conv2d_ws_kernel (kernels2d_v2.h, split-fp16 products), the
-// input-gradient pass stays here (gradient parity 2e-5 against torch autograd of the CPU restatement).
+// of the 2-D path.  The kernels here run on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32); the host side routes the 3x3
+// convolutions of the 64 / 32 / 16-pixel levels through conv2d_ws_kernel (kernels2d_v2.h, split-fp16 products): the forward
+// ones as they are, the input-gradient ones scaled by the power of two their source gradient's maximum asks for (MODE
+// SRC2_SCALED; the maximum is left by fu_gn_silu_bwd_apply_kernel).  Gradient parity 2e-5 against torch autograd of the
+// CPU restatement either way.
 #pragma once
 #include "kernels.h"
 
@@ -118,10 +120,12 @@ __device__ __forceinline__ void fu_group_reduce(float v, float (&red)[256], floa
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C) {
+__global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C,
+                                                           unsigned* __restrict__ amax_reset) {
     __shared__ float red[256];
     __shared__ float tot[8];
     const int img = blockIdx.x, tid = threadIdx.x, f4 = C >> 2, tpg = f4 >> 3, ppp = 256 / f4;      // pixels per pass
+    if (amax_reset && img == 0 && tid == 0) *amax_reset = 0u;   // the backward pass of this block accumulates max |dx| here
     const int c4 = tid % f4, p0 = tid / f4;
     const float4* base = reinterpret_cast<const float4*>(x + (size_t)img * HW * C) + c4;
     const float n = (float)HW * (float)(C / 8);
@@ -197,9 +201,9 @@ __global__ __launch_bounds__(256) void fu_gn_silu_bwd_reduce_kernel(const float*
 }
 __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                             const float* __restrict__ sums, const float* __restrict__ gam, const float* __restrict__ bet,
-                                            float* __restrict__ dx, float beta, int64_t total, int HW, int C) {
+                                            float* __restrict__ dx, float beta, int64_t total, int HW, int C, unsigned* __restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // float4 index; total = elements / 4
-    if (i >= total) return;
+    if (i >= total) return;                                             // (total is a multiple of 64: whole waves leave)
     const int f4 = C >> 2;
     const int c4 = (int)(i % f4), img = (int)(i / ((int64_t)HW * f4)), g = c4 / (f4 >> 3);
     const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
@@ -214,6 +218,16 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
     fu_gn_dz(xv.w, dv.w, m, r, ga.w, be.w, z, dz); v.w = r * (dz - a1 - z * a2);
     if (beta != 0.f) { const float4 o = reinterpret_cast<float4*>(dx)[i]; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
     reinterpret_cast<float4*>(dx)[i] = v;
+    if (amax) {
+        // max |dx| over the tensor, as a bit pattern (monotone for non-negative floats; a maximum does not depend on the
+        // order: the result repeats bit for bit).  One atomic per wave, and only while the wave still raises the value.
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (!(m <= 3.0e38f)) m = 3.0e38f;                                 // inf / nan: saturate (the products are garbage either way)
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const unsigned mb = __builtin_bit_cast(unsigned, m);
+        if ((threadIdx.x & 63) == 0 && mb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(amax, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

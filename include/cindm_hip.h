@@ -371,7 +371,10 @@ void cindm_forceunet_destroy(cindm_forceunet* h);
 int  cindm_forceunet_num_params(const cindm_forceunet* h);
 int  cindm_forceunet_param_info(const cindm_forceunet* h, int idx, char* name, int name_cap, int64_t shape[4], int* ndim);
 int  cindm_forceunet_set_param(cindm_forceunet* h, const char* key, const float* src, int64_t numel, int on_device);
-int  cindm_forceunet_finalize(cindm_forceunet* h, void* stream);      /* folds weight standardisation, packs forward and backward-data fragments */
+/* folds weight standardisation, packs forward and backward-data fragments.  Environment, read here: CINDM_FORCE_H3=0 keeps
+ * the forward 3x3 convolutions, CINDM_FORCE_H3_BWD=0 the input-gradient ones, on the exact fp32 MFMA kernel instead of the
+ * split-fp16 one (diagnostics; both paths meet the 2e-5 parity bound). */
+int  cindm_forceunet_finalize(cindm_forceunet* h, void* stream);
 size_t cindm_forceunet_workspace_bytes(const cindm_forceunet* h, int64_t images, int32_t with_grad);
 /* out[images, 2] = ForceUnet.forward(x)   (:460-486) */
 int  cindm_forceunet_forward(cindm_forceunet* h, const float* x, float* out, int64_t images, void* ws, size_t ws_bytes, void* stream);

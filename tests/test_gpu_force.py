@@ -115,3 +115,26 @@ def test_guided_chain_fused_equals_loop(device, force):
     # the guidance is not a no-op at this coefficient
     plain = d.p_sample_loop(shape, noise=tape, t_stop=995, device=device)
     assert not torch.equal(fused, plain)
+
+
+@pytest.mark.parametrize("env", ["CINDM_FORCE_H3", "CINDM_FORCE_H3_BWD"])
+def test_forceunet_fp32_convolution_paths(device, force, env, monkeypatch):
+    """The exact fp32-MFMA convolutions behind CINDM_FORCE_H3=0 (forward) / CINDM_FORCE_H3_BWD=0 (input gradient) -- read
+    when a handle is finalized -- against the oracle's autograd, and the default split-fp16 path against them."""
+    m, sd = force
+    monkeypatch.setenv(env, "0")
+    m32 = cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+    m32.load_state_dict(sd, strict=True)
+    m32 = m32.to(device)
+    monkeypatch.delenv(env)
+    x = torch.randn((3, 4, 64, 64), generator=torch.Generator().manual_seed(11))
+    out32, dx32 = m32.input_grad(x.to(device), lambda_force=2.0)
+    out, dx = m.input_grad(x.to(device), lambda_force=2.0)
+    xo = x.clone().requires_grad_(True)
+    y = O.force_unet_forward(sd, xo)
+    ref = torch.autograd.grad((2.0 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
+    assert rel(out32, y.detach()) < TOL and rel(dx32, ref) < TOL
+    assert rel(out, out32.cpu().numpy()) < TOL and rel(dx, dx32.cpu().numpy()) < TOL
+    # the scale of each input-gradient convolution comes from an atomic maximum: order-independent, so the pass repeats bit for bit
+    _, dx2 = m.input_grad(x.to(device), lambda_force=2.0)
+    assert torch.equal(dx2, dx)
