@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
         __syncthreads();
+        const int nk = min(CK / 4, (a.Cin - c0 + 3) >> 2);
 #pragma unroll 1
         for (int tap = 0; tap < KS * KS; ++tap) {
             const int dy = tap / KS, dx = tap - dy * KS;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
             const float* wp = a.W + ((((size_t)tap * kcs + c0 / 4) * nq_total + ntq) * 64 + lane) * NB;
 #pragma unroll
             for (int kk = 0; kk < CK / 4; ++kk) {
+                if (kk >= nk) break;                         // the stem: 4 of the 16 staged channels exist (the rest multiply packed zeros)
                 const float av = ap[kk * 4];
                 const float* wk = wp + (size_t)kk * nq_total * 64 * NB;
                 if constexpr (NB == 4) {
@@ -231,49 +233,83 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm over channels (per pixel) times g: one wave per pixel.  fwd: y = (x - m) * r * g [+ res];
+// LayerNorm over channels (per pixel) times g.  fwd: y = (x - m) * r * g [+ res];
 // bwd: dz = dy * g, dx = beta * dx + r * (dz - mean(dz) - z * mean(dz * z)).
+// A row is held by LPR = min(64, C / 4) adjacent lanes, one float4 each (two at C = 512), 64 / LPR rows per wave: every access
+// is a 16-byte lane in a contiguous run, the row reductions are xor-shuffles inside the LPR lanes.  (The first version
+// gave a whole wave to each row with 4-byte accesses: at C = 64 a wave moved 256 bytes per instruction and most of its
+// time went to the five cross-wave reductions.)  C: a power of two in 64 .. 1024.
+__device__ __forceinline__ float fu_row_sum(float v, int lpr) {
+    for (int o = lpr >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __global__ __launch_bounds__(256) void fu_ln_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ res,
                                                     float* __restrict__ y, int64_t rows, int C) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* xr = x + row * C;
+    const int f4 = C >> 2, lpr = min(64, f4), nv = f4 / lpr, rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63, sub = lane / lpr, l = lane - sub * lpr;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub;
+    if (row >= rows) return;                                 // rows is a multiple of 64 / LPR * 4 (host: whole images)
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C) + l;
+    float4 v[4];
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xr[c];
-    s = rowgroup_sum<64>(s);
-    const float m = s / C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) { v[k] = xr[k * 64]; s += (v[k].x + v[k].y) + (v[k].z + v[k].w); }
+    const float m = fu_row_sum(s, lpr) / C;
     float q = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; q += d * d; }
-    q = rowgroup_sum<64>(q);
-    const float r = 1.0f / sqrtf(q / C + 1e-5f);
-    for (int c = lane; c < C; c += 64) {
-        const float v = (xr[c] - m) * r * g[c];
-        y[row * C + c] = res ? v + res[row * C + c] : v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) {
+        const float d0 = v[k].x - m, d1 = v[k].y - m, d2 = v[k].z - m, d3 = v[k].w - m;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float r = 1.0f / sqrtf(fu_row_sum(q, lpr) / C + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) {
+        const float4 gg = reinterpret_cast<const float4*>(g)[l + k * 64];
+        float4 o = make_float4((v[k].x - m) * r * gg.x, (v[k].y - m) * r * gg.y, (v[k].z - m) * r * gg.z, (v[k].w - m) * r * gg.w);
+        if (res) { const float4 e = (reinterpret_cast<const float4*>(res + row * C) + l)[k * 64]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+        (reinterpret_cast<float4*>(y + row * C) + l)[k * 64] = o;
     }
 }
 __global__ __launch_bounds__(256) void fu_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ dy,
                                                         float* __restrict__ dx, float beta, int64_t rows, int C) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int f4 = C >> 2, lpr = min(64, f4), nv = f4 / lpr, rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63, sub = lane / lpr, l = lane - sub * lpr;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub;
     if (row >= rows) return;
-    const float* xr = x + row * C;
-    const float* dr = dy + row * C;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C) + l;
+    const float4* dr = reinterpret_cast<const float4*>(dy + row * C) + l;
+    float4 v[4], dz[4];
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xr[c];
-    s = rowgroup_sum<64>(s);
-    const float m = s / C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) {
+        v[k] = xr[k * 64];
+        const float4 d = dr[k * 64], gg = reinterpret_cast<const float4*>(g)[l + k * 64];
+        dz[k] = make_float4(d.x * gg.x, d.y * gg.y, d.z * gg.z, d.w * gg.w);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float m = fu_row_sum(s, lpr) / C;
     float q = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = xr[c] - m; q += d * d; }
-    q = rowgroup_sum<64>(q);
-    const float r = 1.0f / sqrtf(q / C + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) {
+        v[k].x -= m; v[k].y -= m; v[k].z -= m; v[k].w -= m;
+        q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+    const float r = 1.0f / sqrtf(fu_row_sum(q, lpr) / C + 1e-5f);
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < C; c += 64) { const float dz = dr[c] * g[c], z = (xr[c] - m) * r; s1 += dz; s2 += dz * z; }
-    s1 = rowgroup_sum<64>(s1) / C; s2 = rowgroup_sum<64>(s2) / C;
-    for (int c = lane; c < C; c += 64) {
-        const float dz = dr[c] * g[c], z = (xr[c] - m) * r;
-        const float v = r * (dz - s1 - z * s2);
-        dx[row * C + c] = beta != 0.f ? beta * dx[row * C + c] + v : v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) {
+        v[k].x *= r; v[k].y *= r; v[k].z *= r; v[k].w *= r;                        // z
+        s1 += (dz[k].x + dz[k].y) + (dz[k].z + dz[k].w);
+        s2 += (dz[k].x * v[k].x + dz[k].y * v[k].y) + (dz[k].z * v[k].z + dz[k].w * v[k].w);
+    }
+    s1 = fu_row_sum(s1, lpr) / C; s2 = fu_row_sum(s2, lpr) / C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nv) {
+        float4 o = make_float4(r * (dz[k].x - s1 - v[k].x * s2), r * (dz[k].y - s1 - v[k].y * s2),
+                               r * (dz[k].z - s1 - v[k].z * s2), r * (dz[k].w - s1 - v[k].w * s2));
+        float4* op = reinterpret_cast<float4*>(dx + row * C) + l + k * 64;
+        if (beta != 0.f) { const float4 e = *op; o.x += beta * e.x; o.y += beta * e.y; o.z += beta * e.z; o.w += beta * e.w; }
+        *op = o;
     }
 }
 
@@ -364,30 +400,45 @@ __global__ __launch_bounds__(256) void fu_la_outer_kernel(const float* __restric
     for (int i = tid; i < 1024; i += 256)
         M[((size_t)img * 4 + h) * 1024 + i] = alpha * ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
 }
-// Z[img][n][zoff + h*32 + e] = alpha * sum_d X[img][n][xoff + h*32 + d] * (TRANS ? M[e][d] : M[d][e]); one wave per 16 pixels
-// of one head: A[i = pixel][k = d], B[k = d][j = e]
+// Z[img][n][zoff + h*32 + e] = alpha * sum_d X[img][n][xoff + h*32 + d] * (TRANS ? M[e][d] : M[d][e]); wave = head, a workgroup
+// walks nblk blocks of 16 pixels with the head's matrix held in registers as MFMA fragments (loaded once, strided or not).
+// The product is computed transposed -- D[i = e][j = pixel] = sum_d M(d, e) X[pixel][d], the matrix as the A operand -- so
+// that a lane ends up with four consecutive e of ONE pixel: X is read and Z written as float4 (the first version read X
+// and wrote Z 4 bytes at a time, 16 pixel rows per instruction, and re-read the matrix for every 16 pixels).  The k index
+// of MFMA step (half, kk) is d = 16 half + 4 (lane >> 4) + kk: exactly the float4 a lane loads.
 template <bool TRANS>
 __global__ __launch_bounds__(256) void fu_la_rowmat_kernel(const float* __restrict__ X, int ldx, int xoff, const float* __restrict__ M,
-                                                           float* __restrict__ Z, int ldz, int zoff, float alpha, int n) {
-    const int img = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w;      // wave = head
-    const int p0 = blockIdx.x * 16;
+                                                           float* __restrict__ Z, int ldz, int zoff, float alpha, int n, int nblk) {
+    const int img = blockIdx.y, lane = threadIdx.x & 63, h = threadIdx.x >> 6;      // wave = head
+    const int lp = lane & 15, q = lane >> 4;
     const float* mp = M + ((size_t)img * 4 + h) * 1024;
-    const float* xp = X + ((size_t)img * n + p0 + (lane & 15)) * ldx + xoff + h * 32 + (lane >> 4);
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float mf[2][4][2];                                       // [half][kk][e block]: M(d = 16 half + 4 q + kk, e = lp + 16 block)
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        const float av = xp[kk * 4];
-        const int d = kk * 4 + (lane >> 4), e = lane & 15;
-        const float b0 = TRANS ? mp[e * 32 + d] : mp[d * 32 + e];
-        const float b1 = TRANS ? mp[(e + 16) * 32 + d] : mp[d * 32 + e + 16];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int d = hf * 16 + q * 4 + kk;
+            mf[hf][kk][0] = TRANS ? mp[lp * 32 + d] : mp[d * 32 + lp];
+            mf[hf][kk][1] = TRANS ? mp[(lp + 16) * 32 + d] : mp[d * 32 + lp + 16];
+        }
+    for (int b = 0; b < nblk; ++b) {
+        const size_t pix = (size_t)img * n + ((size_t)blockIdx.x * nblk + b) * 16 + lp;
+        const float* xp = X + pix * ldx + xoff + h * 32 + q * 4;
+        const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 16);
+        const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(mf[hf][kk][0], av[hf][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(mf[hf][kk][1], av[hf][kk], acc[1], 0, 0, 0);
+            }
+        float* zp = Z + pix * ldz + zoff + h * 32 + q * 4;   // D[i = e][j = pixel]: lane = (pixel lp, e = 16 block + 4 q + reg)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+            *reinterpret_cast<float4*>(zp + jb * 16) = make_float4(alpha * acc[jb][0], alpha * acc[jb][1], alpha * acc[jb][2], alpha * acc[jb][3]);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-            Z[((size_t)img * n + p0 + (lane >> 4) * 4 + rg) * ldz + zoff + h * 32 + j * 16 + (lane & 15)] = alpha * acc[j][rg];
 }
 // T[img][h*32+d] = sum_n ks[n,d] * dks[n,d] (dks already carries the 1/n of v' = v / n)
 __global__ __launch_bounds__(256) void fu_la_bwd_kdot_kernel(const float* __restrict__ ks, const float* __restrict__ dks, float* __restrict__ T, int n) {
