@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
             const float* wp = a.W + ((((size_t)tap * kcs + c0 / 4) * nq_total + ntq) * 64 + lane) * NB;
 #pragma unroll
             for (int kk = 0; kk < CK / 4; ++kk) {
-                if (kk >= nk) break;                         // the stem: 4 of the 16 staged channels exist (the rest multiply packed zeros)
+                if (KS == 7 && NB == 4 && kk >= nk) break;   // the stem forward: 4 of the 16 staged channels exist (the rest multiply packed zeros)
                 const float av = ap[kk * 4];
                 const float* wk = wp + (size_t)kk * nq_total * 64 * NB;
                 if constexpr (NB == 4) {
@@ -205,7 +205,7 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
                                             const float* __restrict__ sums, const float* __restrict__ gam, const float* __restrict__ bet,
                                             float* __restrict__ dx, float beta, int64_t total, int HW, int C, unsigned* __restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // float4 index; total = elements / 4
-    if (i >= total) return;                                             // (total is a multiple of 64: whole waves leave)
+    if (i >= total) return;                                             // (total is a multiple of 256: whole workgroups leave)
     const int f4 = C >> 2;
     const int c4 = (int)(i % f4), img = (int)(i / ((int64_t)HW * f4)), g = c4 / (f4 >> 3);
     const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
@@ -222,13 +222,18 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
     reinterpret_cast<float4*>(dx)[i] = v;
     if (amax) {
         // max |dx| over the tensor, as a bit pattern (monotone for non-negative floats; a maximum does not depend on the
-        // order: the result repeats bit for bit).  One atomic per wave, and only while the wave still raises the value.
+        // order: the result repeats bit for bit).  One atomic per workgroup, and only while it still raises the value.
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (!(m <= 3.0e38f)) m = 3.0e38f;                                 // inf / nan: saturate (the products are garbage either way)
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        const unsigned mb = __builtin_bit_cast(unsigned, m);
-        if ((threadIdx.x & 63) == 0 && mb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_max(amax, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __shared__ float wm[4];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+            if (mb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_fetch_max(amax, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -21,7 +21,8 @@ namespace cindm {
 
 enum SrcMode2d { SRC2_PLAIN = 0, SRC2_GN_SS_SILU = 4, SRC2_LN = 2,
                  SRC2_SCALED = 5 };   // conv2d_ws_kernel only: plain source times a power of two taken from a device maximum (below)
-enum ConvKind { CONV_3X3 = 0, CONV_1X1 = 1, CONV_UP2 = 2, CONV_UNSHUF = 3, CONV_STEM7 = 4, CONV_1X1_WIDE = 5 };
+enum ConvKind { CONV_3X3 = 0, CONV_1X1 = 1, CONV_UP2 = 2, CONV_UNSHUF = 3, CONV_STEM7 = 4, CONV_1X1_WIDE = 5,
+                CONV_3X3_PAIR = 6 };   // conv2d_ws_kernel only: 8-pixel-wide images, two side by side per 8 x 16 tile
 // Packed2::h3: 3x3 weights packed as split fp16 for conv2d_h3_kernel
 
 constexpr int T2Y = 4, T2X = 16, T2M = T2Y * T2X;    // output pixel tile 4 x 16

@@ -51,8 +51,13 @@ constexpr int WS_MAXP = 128;                                // most GroupNorm pa
 
 template <int KIND, int MODE>
 __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
-    constexpr int KC = 64, NP = 12;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * V2PLANE];   // [buffer][plane hi/lo][V2R][V2PITCH]
+    // KIND CONV_3X3_PAIR (ForceUnet's 8 x 8 level): the images are 8 pixels wide and a tile is rows ty0 .. ty0 + 7 of images
+    // 2j | 2j + 1 side by side (a.NI counts PAIRS).  Each half keeps its own zero columns: the window is 10 x 20 pixels,
+    // [pad A0..A7 pad | pad B0..B7 pad], and the right half's fragment / staging addresses are shifted by two pixels.
+    constexpr bool PAIR = KIND == CONV_3X3_PAIR;
+    constexpr int SW = PAIR ? 20 : V2SW, R = 10 * SW, PLANE = R * V2PITCH;
+    constexpr int KC = 64, NP = (R + 15) / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * PLANE];   // [buffer][plane hi/lo][R][V2PITCH]
     __shared__ __attribute__((aligned(16))) float Tile[T2N * V2LDT];   // channel-major: an accumulator's 4 rows are 16 contiguous bytes
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,17 +92,17 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) breg[slot_][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
         };
-        const int foff = (lane & 15) * V2PITCH + kg * 64 + (lane >> 4) * 16;
+        const int foff = ((lane & 15) + (PAIR && (lane & 15) >= 8 ? 2 : 0)) * V2PITCH + kg * 64 + (lane >> 4) * 16;
         // 72 steps (tap, pixel block); fragments of step s + 2 are read while step s multiplies
         auto compute = [&](const unsigned char* P0, int nt, int ch, int nt2, int ch2, auto FIRST_) {
             constexpr bool FIRST = decltype(FIRST_)::value;
-            const unsigned char* P1 = P0 + V2PLANE;
+            const unsigned char* P1 = P0 + PLANE;
             half8 fh[3], fl[3];
             auto read_frag = [&](int s, int slot_) {
                 const int tap = s >> 3, mb = s & 7;
                 const int dy = tap / 3, dx = tap - dy * 3;
-                fh[slot_] = *reinterpret_cast<const half8*>(P0 + ((mb + dy) * V2SW + dx) * V2PITCH);
-                fl[slot_] = *reinterpret_cast<const half8*>(P1 + ((mb + dy) * V2SW + dx) * V2PITCH);
+                fh[slot_] = *reinterpret_cast<const half8*>(P0 + ((mb + dy) * SW + dx) * V2PITCH);
+                fl[slot_] = *reinterpret_cast<const half8*>(P1 + ((mb + dy) * SW + dx) * V2PITCH);
             };
             read_frag(0, 0); read_frag(1, 1);
 #pragma unroll
@@ -218,14 +223,16 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int r = r0 + 16 * p;
-        const int hy = r / V2SW, hx = r - hy * V2SW;
-        dpix4[p] = 4 * ((KIND == CONV_UP2) ? ((hy - 1) >> 1) * Win + ((hx - 1) >> 1) : (hy - 1) * Win + (hx - 1));
-        m_valid |= (r < V2R) ? (1u << p) : 0u;
+        const int hy = r / SW, hx0 = r - hy * SW;
+        const bool second = PAIR && hx0 >= 10;               // the pair's right image
+        const int hx = second ? hx0 - 10 : hx0;
+        dpix4[p] = 4 * ((KIND == CONV_UP2) ? ((hy - 1) >> 1) * Win + ((hx - 1) >> 1) : (hy - 1) * Win + (hx - 1) + (second ? HWi : 0));
+        m_valid |= (r < R) ? (1u << p) : 0u;
         m_top |= (hy == 0) ? (1u << p) : 0u;  m_bot |= (hy == V2Y + 1) ? (1u << p) : 0u;
-        m_left |= (hx == 0) ? (1u << p) : 0u; m_right |= (hx == V2X + 1) ? (1u << p) : 0u;
+        m_left |= (hx == 0) ? (1u << p) : 0u; m_right |= (hx == (PAIR ? 9 : V2X + 1)) ? (1u << p) : 0u;
     }
-    const unsigned src_bytes0 = (unsigned)a.NI * (unsigned)HWi * (unsigned)ld0 * 4u;
-    const unsigned src_bytes1 = (unsigned)a.NI * (unsigned)HWi * (unsigned)ld1 * 4u;
+    const unsigned src_bytes0 = (unsigned)a.NI * (PAIR ? 2u : 1u) * (unsigned)HWi * (unsigned)ld0 * 4u;
+    const unsigned src_bytes1 = (unsigned)a.NI * (PAIR ? 2u : 1u) * (unsigned)HWi * (unsigned)ld1 * 4u;
     // MODE SRC2_SCALED (ForceUnet's input-gradient pass): the source is a gradient tensor whose magnitudes sit far below
     // fp16's normal range; src[0].stats points at ONE word, the bit pattern of max |source| (atomicMax by the producer).
     // The source is staged times the power of two that puts that maximum in [2^13, 2^14) and the tile is written times
@@ -261,9 +268,9 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         const float* base = first ? sp0 : sp1;
         const int clc = min(cl, Cc - 4);
         cok = cl < Cc;
-        okmask = m_valid & ~((ty0 == 0 ? m_top : 0u) | (ty0 + V2Y == Hout ? m_bot : 0u) | (tx0 == 0 ? m_left : 0u) |
-                             (tx0 + V2X == Wout ? m_right : 0u));
-        const int origin = (KIND == CONV_UP2) ? img * HWi + (ty0 >> 1) * Win + (tx0 >> 1) : img * HWi + ty0 * Win + tx0;
+        okmask = m_valid & ~((ty0 == 0 ? m_top : 0u) | (ty0 + V2Y == Hout ? m_bot : 0u) | (PAIR || tx0 == 0 ? m_left : 0u) |
+                             (PAIR || tx0 + V2X == Wout ? m_right : 0u));
+        const int origin = (KIND == CONV_UP2) ? img * HWi + (ty0 >> 1) * Win + (tx0 >> 1) : (PAIR ? 2 * img : img) * HWi + ty0 * Win + tx0;
         const int t4 = (origin * ld + clc) * 4;               // byte offset of the tile origin's float4 of this thread
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, first ? src_bytes0 : src_bytes1, 0x00020000);
 #pragma unroll
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     };
     auto store_item = [&](int buf) {
         unsigned char* S0 = &smem[buf][0];
-        unsigned char* S1 = S0 + V2PLANE;
+        unsigned char* S1 = S0 + PLANE;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int r = r0 + 16 * p;
@@ -331,11 +338,16 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
             lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
             lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
-            if (r < V2R) {
+            if (r < R) {
                 *reinterpret_cast<half4v*>(S0 + r * V2PITCH + c4 * 8) = hi;
                 *reinterpret_cast<half4v*>(S1 + r * V2PITCH + c4 * 8) = lo;
             }
         }
+    };
+    // pixel offset of tile row jj (of this wave's two), tile column 4 q + pi, from the wave's first pixel; PAIR: tile columns
+    // 8 .. 15 are columns 0 .. 7 of the next image
+    auto opix = [&](int jj, int q, int pi) {
+        return PAIR ? jj * Wout + ((4 * q + pi) & 7) + (q >= 2 ? Hout * Wout : 0) : jj * Wout + 4 * q + pi;
     };
     // MODE SRC2_SCALED: the addend of tile (mt, nt), issued BEFORE the next item's loads so that the wait for it does not
     // cover them (write_tile's addressing)
@@ -347,11 +359,11 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
             const int oc4 = lane & 15, q = lane >> 4;
             const int col = nt * T2N + oc4 * 4;
-            const float* r0p = resp + ((img * Hout + ty0 + 2 * lw) * Wout + tx0) * ldres + min(col, N - 4);
+            const float* r0p = resp + (((PAIR ? 2 * img : img) * Hout + ty0 + 2 * lw) * Wout + tx0) * ldres + min(col, N - 4);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int pi = 0; pi < 4; ++pi) racc[4 * jj + pi] = *reinterpret_cast<const float4*>(r0p + (jj * Wout + 4 * q + pi) * ldres);
+                for (int pi = 0; pi < 4; ++pi) racc[4 * jj + pi] = *reinterpret_cast<const float4*>(r0p + opix(jj, q, pi) * ldres);
         }
     };
     // the finished tile (mt, nt): wave lw stores tile pixels 32 lw .. 32 lw + 31 (two pixel rows) and their GroupNorm partial
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         const bool nok = col < N;                            // N is a multiple of 4 (host)
         // this wave's 32 pixels = 8 blocks of 4 (block b: tile row 2 lw + (b >> 2), columns 4 (b & 3) ..); lane = (channel
         // quad oc4, blocks q and q + 4): four 16-byte LDS reads give 4 channels x 4 pixels, whose transpose is a renaming
-        float* o0 = outp + ((img * Hout + ty0 + 2 * lw) * Wout + tx0) * ldo + col;
+        float* o0 = outp + (((PAIR ? 2 * img : img) * Hout + ty0 + 2 * lw) * Wout + tx0) * ldo + col;
         const float* t0 = Tile + (oc4 * 4) * V2LDT + 32 * lw + 4 * q;
         float4 f[2][4];                                      // all eight LDS reads in flight before the first store
 #pragma unroll
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)               // block b = q + 4 jj: row jj, column 4 q + pi
-                    *reinterpret_cast<float4*>(o0 + (jj * Wout + 4 * q + pi) * ldo) = v[4 * jj + pi];
+                    *reinterpret_cast<float4*>(o0 + opix(jj, q, pi) * ldo) = v[4 * jj + pi];
         }
         if (!stats_out) return;
         // shifted sums about the group's first element of the wave's first pixel
