@@ -135,6 +135,9 @@ def test_forceunet_fp32_convolution_paths(device, force, env, monkeypatch):
     ref = torch.autograd.grad((2.0 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
     assert rel(out32, y.detach()) < TOL and rel(dx32, ref) < TOL
     assert rel(out, out32.cpu().numpy()) < TOL and rel(dx, dx32.cpu().numpy()) < TOL
+    # an odd image count: the 8 x 8 level cannot pair images and stays on the fp32 kernel
+    out3, dx3 = m.input_grad(x[:3].to(device), lambda_force=2.0)
+    assert rel(out3, y.detach()[:3]) < TOL and rel(dx3, ref[:3]) < TOL
     # the scale of each input-gradient convolution comes from an atomic maximum: order-independent, so the pass repeats bit for bit
     _, dx2 = m.input_grad(x.to(device), lambda_force=2.0)
     assert torch.equal(dx2, dx)
