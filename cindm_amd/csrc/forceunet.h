@@ -445,41 +445,83 @@ __global__ __launch_bounds__(256) void fu_la_rowmat_kernel(const float* __restri
             *reinterpret_cast<float4*>(zp + jb * 16) = make_float4(alpha * acc[jb][0], alpha * acc[jb][1], alpha * acc[jb][2], alpha * acc[jb][3]);
     }
 }
-// T[img][h*32+d] = sum_n ks[n,d] * dks[n,d] (dks already carries the 1/n of v' = v / n)
-__global__ __launch_bounds__(256) void fu_la_bwd_kdot_kernel(const float* __restrict__ ks, const float* __restrict__ dks, float* __restrict__ T, int n) {
-    __shared__ float red[8][32];
-    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const size_t base = (size_t)img * n * 128 + h * 32 + d;
+// Backward of the attention core in two launches (the first version: three row products that wrote dqs, dks, dv
+// [pixels][128] each, a pixel reduction T = sum_n ks dks over them, and an elementwise pass that read them all back):
+//   T[img][h*32+d] = sum_n ks[n,d] dks[n,d]  with dks = v dctx^T / n  is  sum_e dctx[d][e] ctx[d][e]  (ctx = ks^T v / n):
+//   a 32-term dot product per channel, no pixel pass;
+__global__ __launch_bounds__(128) void fu_la_tdot_kernel(const float* __restrict__ ctx, const float* __restrict__ dctx, float* __restrict__ T) {
+    const int img = blockIdx.x, c = threadIdx.x;            // c = h*32 + d: row c of the [img][4*32][32] matrices
+    const float4* a = reinterpret_cast<const float4*>(ctx + ((size_t)img * 128 + c) * 32);
+    const float4* b = reinterpret_cast<const float4*>(dctx + ((size_t)img * 128 + c) * 32);
     float s = 0.f;
-    for (int i = part; i < n; i += 8) s += ks[base + (size_t)i * 128] * dks[base + (size_t)i * 128];
-    red[part][d] = s; __syncthreads();
-    if (part == 0) {
-        s = 0.f;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) s += red[p][d];
-        T[(size_t)img * 128 + h * 32 + d] = s;
-    }
+    for (int k = 0; k < 8; ++k) { const float4 x = a[k], y = b[k]; s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w); }
+    T[(size_t)img * 128 + c] = s;
 }
-// dqkv[n][384]: dq = s (dqs - sum_d s dqs) with s = softmax(q) = qs / scale (the scale sits in qs), dk = ks (dks - T), dv as
-// given; dqs / dks / dv are [img][n][128].  One lane per float4, the per-head dot product over 8 adjacent lanes.
-__global__ __launch_bounds__(256) void fu_la_bwd_apply_kernel(const float* __restrict__ qs, const float* __restrict__ ks, const float* __restrict__ dqs,
-                                                              const float* __restrict__ dks, const float* __restrict__ dv, const float* __restrict__ T,
-                                                              float* __restrict__ dqkv, int n, int64_t total) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // total = pixels * 32 float4 lanes
-    if (t >= total) return;
-    const int c4 = (int)(t & 31);
-    const int64_t pix = t >> 5;
-    const int img = (int)(pix / n);
-    const size_t o = pix * 128 + c4 * 4;
-    const float4 a = *reinterpret_cast<const float4*>(qs + o), b = *reinterpret_cast<const float4*>(dqs + o);
-    const float dot = fu_red8_sum((a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w)) * 5.656854249492381f;   // = sum_d s_d dqs_d
-    // q_s = scale * s  =>  dq_d = scale * s_d * (dqs_d - sum_j s_j dqs_j) = qs_d * (dqs_d - dot)
-    *reinterpret_cast<float4*>(dqkv + pix * 384 + c4 * 4) = make_float4(a.x * (b.x - dot), a.y * (b.y - dot), a.z * (b.z - dot), a.w * (b.w - dot));
-    const float4 k4 = *reinterpret_cast<const float4*>(ks + o), dk4 = *reinterpret_cast<const float4*>(dks + o);
-    const float4 t4 = *reinterpret_cast<const float4*>(T + (size_t)img * 128 + c4 * 4);
-    *reinterpret_cast<float4*>(dqkv + pix * 384 + 128 + c4 * 4) =
-        make_float4(k4.x * (dk4.x - t4.x), k4.y * (dk4.y - t4.y), k4.z * (dk4.z - t4.z), k4.w * (dk4.w - t4.w));
-    *reinterpret_cast<float4*>(dqkv + pix * 384 + 256 + c4 * 4) = *reinterpret_cast<const float4*>(dv + o);
+//   dqkv[n][384] in one pass over the pixels: dqs = dout ctx^T, dks = v dctx^T / n, dv = ks dctx / n as fu_la_rowmat_kernel
+//   computes them (wave = head, matrix fragments in registers, transposed product: a lane ends up with channels
+//   16 jb + 4 (lane >> 4) + {0..3} of pixel lane & 15), then in place dq = qs (dqs - sum_d s_d dqs_d) (s = softmax(q) =
+//   qs / scale; the head's dot product is a sum over the lane's 8 values and the 4 lanes of its pixel), dk = ks (dks - T).
+__global__ __launch_bounds__(256) void fu_la_bwd_fused_kernel(const float* __restrict__ qs, const float* __restrict__ ks, const float* __restrict__ qkv,
+                                                              const float* __restrict__ dout, const float* __restrict__ ctx,
+                                                              const float* __restrict__ dctx, const float* __restrict__ T,
+                                                              float* __restrict__ dqkv, float inv_n, int n, int nblk) {
+    const int img = blockIdx.y, lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const float* cp = ctx + ((size_t)img * 4 + h) * 1024;
+    const float* dp = dctx + ((size_t)img * 4 + h) * 1024;
+    float cT[2][4][2], dT[2][4][2], dN[2][4][2];             // [half][kk][column block]: ctx^T, dctx^T, dctx fragments
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = hf * 16 + q * 4 + kk;
+            cT[hf][kk][0] = cp[lp * 32 + k]; cT[hf][kk][1] = cp[(lp + 16) * 32 + k];
+            dT[hf][kk][0] = dp[lp * 32 + k]; dT[hf][kk][1] = dp[(lp + 16) * 32 + k];
+            dN[hf][kk][0] = dp[k * 32 + lp]; dN[hf][kk][1] = dp[k * 32 + lp + 16];
+        }
+    const float* tp = T + (size_t)img * 128 + h * 32 + q * 4;
+    const float4 t4[2] = {*reinterpret_cast<const float4*>(tp), *reinterpret_cast<const float4*>(tp + 16)};
+    for (int b = 0; b < nblk; ++b) {
+        const size_t pix = (size_t)img * n + ((size_t)blockIdx.x * nblk + b) * 16 + lp;
+        const size_t o = pix * 128 + h * 32 + q * 4;
+        const float4 g4[2] = {*reinterpret_cast<const float4*>(dout + o), *reinterpret_cast<const float4*>(dout + o + 16)};
+        const float4 k4[2] = {*reinterpret_cast<const float4*>(ks + o), *reinterpret_cast<const float4*>(ks + o + 16)};
+        const float4 q4[2] = {*reinterpret_cast<const float4*>(qs + o), *reinterpret_cast<const float4*>(qs + o + 16)};
+        const float* vp = qkv + pix * 384 + 256 + h * 32 + q * 4;
+        const float4 v4[2] = {*reinterpret_cast<const float4*>(vp), *reinterpret_cast<const float4*>(vp + 16)};
+        const float gv[2][4] = {{g4[0].x, g4[0].y, g4[0].z, g4[0].w}, {g4[1].x, g4[1].y, g4[1].z, g4[1].w}};
+        const float kv[2][4] = {{k4[0].x, k4[0].y, k4[0].z, k4[0].w}, {k4[1].x, k4[1].y, k4[1].z, k4[1].w}};
+        const float vv[2][4] = {{v4[0].x, v4[0].y, v4[0].z, v4[0].w}, {v4[1].x, v4[1].y, v4[1].z, v4[1].w}};
+        f32x4 aq[2], ak[2], av[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) { aq[jb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[jb] = aq[jb]; av[jb] = aq[jb]; }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    aq[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cT[hf][kk][jb], gv[hf][kk], aq[jb], 0, 0, 0);   // dqs = dout ctx^T
+                    ak[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[hf][kk][jb], vv[hf][kk], ak[jb], 0, 0, 0);   // dks n = v dctx^T
+                    av[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dN[hf][kk][jb], kv[hf][kk], av[jb], 0, 0, 0);   // dv n = ks dctx
+                }
+        float dot = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) dot += (q4[jb].x * aq[jb][0] + q4[jb].y * aq[jb][1]) + (q4[jb].z * aq[jb][2] + q4[jb].w * aq[jb][3]);
+        dot += __shfl_xor(dot, 16); dot += __shfl_xor(dot, 32);
+        dot *= 5.656854249492381f;                           // qs = scale * s  =>  dq_d = qs_d (dqs_d - sum_j s_j dqs_j)
+        float* op = dqkv + pix * 384 + h * 32 + q * 4;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            *reinterpret_cast<float4*>(op + jb * 16) = make_float4(q4[jb].x * (aq[jb][0] - dot), q4[jb].y * (aq[jb][1] - dot),
+                                                                    q4[jb].z * (aq[jb][2] - dot), q4[jb].w * (aq[jb][3] - dot));
+            *reinterpret_cast<float4*>(op + 128 + jb * 16) =
+                make_float4(k4[jb].x * (inv_n * ak[jb][0] - t4[jb].x), k4[jb].y * (inv_n * ak[jb][1] - t4[jb].y),
+                            k4[jb].z * (inv_n * ak[jb][2] - t4[jb].z), k4[jb].w * (inv_n * ak[jb][3] - t4[jb].w));
+            *reinterpret_cast<float4*>(op + 256 + jb * 16) = make_float4(inv_n * av[jb][0], inv_n * av[jb][1], inv_n * av[jb][2], inv_n * av[jb][3]);
+        }
+    }
 }
 // ---------------------------------------------------------------------------------------------------------------------
 // Softmax attention of the bottleneck (model/diffusion_2d.py:266-278), n <= 64 tokens: one workgroup of n threads per
