@@ -103,6 +103,80 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// fu_stem_bwd_kernel: input gradient of the 7x7 stem (64 -> 4 channels, 64-pixel-wide images).  As a convolution with 4
+// output channels fu_conv_kernel<7, 1> fills 4 of an MFMA's 16 columns (4.5 ms per gradient call, the slowest launch of
+// the pass).  Here the 7 horizontal taps join the 4 channels as the product's columns and only the 7 vertical taps stay in
+// the reduction:
+//     T[y][x'][b*4 + ci] = sum_a sum_co g[y + a - 3][x'][co] W[co][ci][6 - a][6 - b]      (K = 7 * 64, N = 28 of 32)
+//     dx[y][x][ci]       = sum_b T[y][x + b - 3][b*4 + ci]                                 (x + b - 3 inside the row)
+// -- 224 MFMAs per 16 pixels instead of 784, and no horizontal halo (T is only needed where g exists).  Workgroup = 4
+// rows of one image, wave = row (4 blocks of 16 pixels x 2 column blocks); g is staged 16 channels at a time with its 3 + 3
+// halo rows; T goes through LDS (aliasing the stage) for the horizontal sum.  Weights: Wp[a][co][32].
+struct FuStemBwdArgs { const float* g; const float* W; float* dx; int H, NI; float beta; };
+__global__ __launch_bounds__(256) void fu_stem_bwd_kernel(const FuStemBwdArgs a) {
+    constexpr int WD = 64, CO = 64, CK = 16, CKP = 17, ROWS = 10, TP = 33;
+    __shared__ float As[ROWS * WD * CKP];                    // 43.5 KB; the epilogue's T [4 rows][64][TP] (33.8 KB) aliases it
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lp = lane & 15, q = lane >> 4;
+    const int tiles = a.H / 4;
+    const int img = blockIdx.x / tiles, y0 = (blockIdx.x - img * tiles) * 4;
+    const float* gi = a.g + (size_t)img * a.H * WD * CO;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) { acc[mb][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mb][1] = acc[mb][0]; }
+    for (int c0 = 0; c0 < CO; c0 += CK) {
+        __syncthreads();
+        for (int i = tid; i < ROWS * WD * (CK / 4); i += 256) {
+            const int hp = i >> 2, c4 = i & 3;               // hp = staged row * 64 + x
+            const int y = y0 - 3 + (hp >> 6);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.H) v = *reinterpret_cast<const float4*>(gi + ((size_t)y * WD + (hp & 63)) * CO + c0 + c4 * 4);
+            float* d = &As[hp * CKP + c4 * 4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ta = 0; ta < 7; ++ta) {                     // g row y0 + w + ta - 3 = staged row w + ta
+            const float* ap = &As[((w + ta) * WD + lp) * CKP + q];
+            const float* wp = a.W + ((size_t)(ta * CO + c0 + q)) * 32 + lp;
+#pragma unroll
+            for (int kk = 0; kk < CK / 4; ++kk) {
+                const float b0 = wp[kk * 4 * 32], b1 = wp[kk * 4 * 32 + 16];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const float av = ap[mb * 16 * CKP + kk * 4];
+                    acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[mb][0], 0, 0, 0);
+                    acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[mb][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* Ts = As;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) Ts[(w * WD + mb * 16 + q * 4 + rg) * TP + nb * 16 + lp] = acc[mb][nb][rg];
+    __syncthreads();
+    {
+        const int r = tid >> 6, x = tid & 63;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const int xg = x + b - 3;
+            if (xg >= 0 && xg < WD) {
+                const float* tp = &Ts[(r * WD + xg) * TP + b * 4];
+                s.x += tp[0]; s.y += tp[1]; s.z += tp[2]; s.w += tp[3];
+            }
+        }
+        float4* o = reinterpret_cast<float4*>(a.dx + (((size_t)img * a.H + y0 + r) * WD + x) * 4);
+        if (a.beta != 0.f) { const float4 e = *o; s.x += a.beta * e.x; s.y += a.beta * e.y; s.z += a.beta * e.z; s.w += a.beta * e.w; }
+        *o = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // GroupNorm(8 groups) + SiLU and its derivative.  All four kernels move float4 (4 channels of one pixel: a group is at
 // least 8 channels wide, so a float4 never straddles groups) with the channel quad fixed per thread: rows are read whole
 // and coalesced.  (The first version ran one workgroup per (image, group) over a 32-byte-per-pixel strided slice with
