@@ -363,7 +363,7 @@ typedef struct {
     int32_t n_mults;          /* len(dim_mults) <= 4                        :417 */
     int32_t dim_mults[4];     /* (1, 2, 4, 8): the bottleneck must be 512 wide (final = Linear(512, 2), :458) */
     int32_t channels;         /* 4 = (pressure, boundary mask, 2 offsets)   :418 */
-    int32_t image_size;       /* 64 */
+    int32_t image_size;       /* 64 = 8 * 2^(n_mults - 1): the coarsest level is 8 x 8 (other sizes: fewer levels) */
 } cindm_forceunet_desc;
 
 int  cindm_forceunet_create(const cindm_forceunet_desc* desc, cindm_forceunet** out);

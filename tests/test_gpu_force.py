@@ -141,3 +141,24 @@ def test_forceunet_fp32_convolution_paths(device, force, env, monkeypatch):
     # the scale of each input-gradient convolution comes from an atomic maximum: order-independent, so the pass repeats bit for bit
     _, dx2 = m.input_grad(x.to(device), lambda_force=2.0)
     assert torch.equal(dx2, dx)
+
+
+def test_forceunet_rejects_a_bottleneck_larger_than_64_tokens():
+    with pytest.raises(cindm_amd.CindmError, match="coarsest level must be 8 x 8"):
+        cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4, image_size=128)
+
+
+@pytest.mark.parametrize("size,mults,n", [(32, (1, 2, 8), 4), (16, (1, 8), 6)])
+def test_forceunet_other_image_sizes(device, size, mults, n):
+    """Shapes other than the paper's 64 x 64 / (1, 2, 4, 8): 32 x 32 with three levels (split-fp16 tiles at 32 and 16 pixels,
+    paired images at 8, the stem's input gradient on the generic kernel) and 16 x 16 with two."""
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(dim_mults=mults), 5)
+    m = cindm_amd.ForceUnet(dim=64, dim_mults=mults, channels=4, image_size=size)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device)
+    x = torch.randn((n, 4, size, size), generator=torch.Generator().manual_seed(3))
+    out, dx = m.input_grad(x.to(device), lambda_force=0.7)
+    xo = x.clone().requires_grad_(True)
+    y = O.force_unet_forward(sd, xo)
+    ref = torch.autograd.grad((0.7 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
+    assert rel(out, y.detach()) < TOL and rel(dx, ref) < TOL
