@@ -215,3 +215,25 @@ def test_step2d_recurrence_golden(gold_dir, device, tag, guid, t):
     out, x0 = d.p_sample((1, 2, 21, 32, 32), torch.from_numpy(g[tag + ".x"]).to(device), t, None, design_fn=design_grad,
                          design_guidance=guid, noise=nz, recur_noise=torch.from_numpy(g[tag + ".recur"]).to(device))
     assert rel(out, g[tag + ".out"]) < TOL_STEP and rel(x0, g[tag + ".x0"]) < TOL_STEP
+
+
+@pytest.mark.parametrize("size,mults,ch,n,served", [(64, (1, 2), 15, 2, True), (32, (1, 1), 21, 3, True), (32, (2, 2), 21, 1, False), (64, (1, 2, 4), 21, 2, False),
+                                                    (64, (1, 2, 4, 8), 21, 2, False), (128, (1, 2), 21, 1, False), (16, (1, 2), 21, 1, False)])
+def test_unet2d_other_configurations(device, size, mults, ch, n, served):
+    """Configurations other than the airfoil checkpoint's (dim_mults (1, 2), 21 channels, 64 x 64): the library either
+    computes them to the same tolerance (other channel counts / widths of 64 or 128 per level) or refuses them at
+    construction or when the weights are packed (deeper / wider U-Nets, images the 4 x 16 / 8 x 16 tiles do not cover) -- never a silent wrong answer."""
+    sd = O.synth_state_dict_2d(O.unet2d_param_shapes(64, mults, ch), 9)
+    if not served:                                       # at construction, or when the weights are packed (first use)
+        with pytest.raises(cindm_amd.CindmError):
+            m = cindm_amd.Unet(dim=64, dim_mults=mults, channels=ch, image_size=size)
+            m.load_state_dict(sd, strict=True)
+            m.to(device)(torch.zeros((n, ch, size, size), device=device), 412)
+        return
+    m = cindm_amd.Unet(dim=64, dim_mults=mults, channels=ch, image_size=size)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device)
+    x = torch.randn((n, ch, size, size), generator=torch.Generator().manual_seed(21)) * 0.9
+    ref = O.unet2d_forward(sd, x, torch.full((n,), 412, dtype=torch.long))
+    out = m(x.to(device), 412)
+    assert rel(out, ref) < TOL_FWD
