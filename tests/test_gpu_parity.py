@@ -457,3 +457,22 @@ def test_builtin_objective_paper_configuration(device, unet8, diff8):
                        **{**kw, "initial_state_overwrite": iso.to(device)})
     assert out.shape == (B, Lt, F)
     assert rel(out, ref) < TOL_STEP * 2
+
+
+@pytest.mark.parametrize("hz,F,dim,mults,att", [(24, 8, 32, (1, 2, 4, 8), True), (24, 8, 64, (1, 2, 4), True), (24, 8, 64, (1, 4, 8), False),
+                                                (16, 8, 64, (1, 2), True), (24, 6, 64, (1, 2, 4, 8), True), (24, 8, 128, (1, 2, 4, 8), True),
+                                                (24, 3, 64, (1, 2, 4, 8), False)])
+def test_unet_other_widths_and_depths(device, hz, F, dim, mults, att):
+    """Constructor arguments other than the n-body checkpoints' (dim 64, dim_mults (1, 2, 4, 8), 4 / 8 / 16 features): the
+    library either computes them to the same tolerance (through its general kernels) or refuses them with an error at
+    construction / when the weights are packed -- never a silent wrong answer."""
+    sd = O.synth_state_dict(O.unet1d_param_shapes(hz, F, dim=dim, dim_mults=mults, attention=att), seed=4)
+    x = torch.randn((3, hz, F), generator=torch.Generator().manual_seed(31))
+    try:
+        m = cindm_amd.TemporalUnet1D(hz, F, False, dim=dim, dim_mults=mults, attention=att)
+        m.load_state_dict(sd, strict=True)
+        out = m.to(device)(x.to(device), torch.full((3,), 77, device=device))
+    except cindm_amd.CindmError:
+        return
+    ref = O.unet1d_forward(sd, x, torch.full((3,), 77, dtype=torch.long))
+    assert rel(out, ref) < TOL_FWD
