@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void fu_ln_bwd_kernel(const float* __restrict_
 // decomposed into (1) column statistics of k, (2) an elementwise pass that materialises qs and ks [img][n][128] (kept for
 // the backward pass), and two small fp32-MFMA GEMM shapes shared by forward and backward:
 //   fu_la_outer_kernel:  M[d][e] = alpha * sum_n X[n,d] Y[n,e]          (ctx = ks^T v / n ; dctx = qs^T dout)
-//   fu_la_rowmat_kernel: Z[n,e]  = alpha * sum_d X[n,d] M[d][e] (or M^T) (out = qs ctx ; dqs = dout ctx^T ; dks = v dctx^T ; dv = ks dctx)
+//   fu_la_rowmat_kernel: Z[n,e]  = alpha * sum_d X[n,d] M[d][e]          (out = qs ctx; the backward's three row products live in fu_la_bwd_fused_kernel)
 __global__ __launch_bounds__(256) void fu_la_kstat_kernel(const float* __restrict__ qkv, float* __restrict__ kstat, int n) {
     __shared__ float red[8][32];
     const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -479,13 +479,12 @@ __global__ __launch_bounds__(256) void fu_la_outer_kernel(const float* __restric
     for (int i = tid; i < 1024; i += 256)
         M[((size_t)img * 4 + h) * 1024 + i] = alpha * ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
 }
-// Z[img][n][zoff + h*32 + e] = alpha * sum_d X[img][n][xoff + h*32 + d] * (TRANS ? M[e][d] : M[d][e]); wave = head, a workgroup
-// walks nblk blocks of 16 pixels with the head's matrix held in registers as MFMA fragments (loaded once, strided or not).
+// Z[img][n][zoff + h*32 + e] = alpha * sum_d X[img][n][xoff + h*32 + d] * M[d][e]; wave = head, a workgroup
+// walks nblk blocks of 16 pixels with the head's matrix held in registers as MFMA fragments (loaded once).
 // The product is computed transposed -- D[i = e][j = pixel] = sum_d M(d, e) X[pixel][d], the matrix as the A operand -- so
 // that a lane ends up with four consecutive e of ONE pixel: X is read and Z written as float4 (the first version read X
 // and wrote Z 4 bytes at a time, 16 pixel rows per instruction, and re-read the matrix for every 16 pixels).  The k index
 // of MFMA step (half, kk) is d = 16 half + 4 (lane >> 4) + kk: exactly the float4 a lane loads.
-template <bool TRANS>
 __global__ __launch_bounds__(256) void fu_la_rowmat_kernel(const float* __restrict__ X, int ldx, int xoff, const float* __restrict__ M,
                                                            float* __restrict__ Z, int ldz, int zoff, float alpha, int n, int nblk) {
     const int img = blockIdx.y, lane = threadIdx.x & 63, h = threadIdx.x >> 6;      // wave = head
@@ -497,8 +496,8 @@ __global__ __launch_bounds__(256) void fu_la_rowmat_kernel(const float* __restri
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int d = hf * 16 + q * 4 + kk;
-            mf[hf][kk][0] = TRANS ? mp[lp * 32 + d] : mp[d * 32 + lp];
-            mf[hf][kk][1] = TRANS ? mp[(lp + 16) * 32 + d] : mp[d * 32 + lp + 16];
+            mf[hf][kk][0] = mp[d * 32 + lp];
+            mf[hf][kk][1] = mp[d * 32 + lp + 16];
         }
     for (int b = 0; b < nblk; ++b) {
         const size_t pix = (size_t)img * n + ((size_t)blockIdx.x * nblk + b) * 16 + lp;
