@@ -224,6 +224,17 @@ __global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restric
     }
 }
 
+// ... or, when conv2d_ws_kernel produced x, from the (mean, M2) partials its store path leaves per (tile, memory wave):
+// [img][8][P][2], P equal-count partials of cnt elements each; one wave per image (kernels2d.h merge_stats8)
+__global__ __launch_bounds__(64) void fu_gn_merge_kernel(const float* __restrict__ part, float* __restrict__ stats, int P, float cnt,
+                                                         unsigned* __restrict__ amax_reset) {
+    const int img = blockIdx.x, lane = threadIdx.x;
+    if (amax_reset && img == 0 && lane == 0) *amax_reset = 0u;
+    float m, r;
+    merge_stats8(part + (size_t)img * 8 * P * 2, P, cnt, lane, m, r);
+    if ((lane & 7) == 0) { stats[((size_t)img * 8 + (lane >> 3)) * 2] = m; stats[((size_t)img * 8 + (lane >> 3)) * 2 + 1] = r; }
+}
+
 // y = SiLU(GN(x)) [+ res]; one float4 per thread
 __global__ void fu_gn_silu_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gam,
                                   const float* __restrict__ bet, const float* __restrict__ res, float* __restrict__ y,
