@@ -27,10 +27,17 @@ struct FuConvArgs {
     const float* x; const float* W; const float* bias; float* y;
     int Cin, CinP, Cout, CoutP, H, Wd, NI;        // CinP: multiple of 16 (packed), CoutP: multiple of 16*NB
     float beta;                                   // 0: overwrite, 1: accumulate into y
+    int Csrc;                                     // UNSHUF: channels of the full-resolution tensor (Cin or Cout = 4 Csrc)
 };
 
-template <int KS, int NB>
+// UNSHUF (1x1 only) folds the pixel-unshuffle 'b c (h p1) (w p2) -> b (c p1 p2) h w' in front of the down-sampling 1x1
+// into the convolution's addressing instead of a pass of its own: with the weights' input channels packed in the order
+// k' = (p1 p2) * C + c, 4 consecutive k' are 4 consecutive channels of ONE full-resolution pixel (2y + p1, 2x + p2).
+// UNSHUF = 1: x is the full-resolution tensor [2H][2W][Csrc], staged through that map (forward).  UNSHUF = 2: the input
+// gradient's channels k' are scattered back to the full-resolution gradient y [2H][2W][Csrc] (backward).
+template <int KS, int NB, int UNSHUF = 0>
 __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
+    static_assert(UNSHUF == 0 || KS == 1, "the unshuffle fold is for the 1x1 after the rearrange");
     constexpr int HALO = KS - 1, TW = 8 + HALO, NPIX = TW * TW, CK = 16, CKP = 17;
     __shared__ float As[NPIX * CKP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -53,6 +60,10 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
             const int y = ty0 + hy - HALO / 2, x = tx0 + hx - HALO / 2;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int c = c0 + c4 * 4;
+            if constexpr (UNSHUF == 1) {
+                const int pp = c / a.Csrc, cs = c - pp * a.Csrc;             // Csrc is a multiple of 16: a float4 stays in one pixel
+                v = *reinterpret_cast<const float4*>(a.x + (((size_t)img * 2 * a.H + 2 * y + (pp >> 1)) * (2 * a.Wd) + 2 * x + (pp & 1)) * a.Csrc + cs);
+            } else
             if (y >= 0 && y < a.H && x >= 0 && x < a.Wd && c < a.Cin) {
                 const float* p = a.x + ((size_t)img * HW + (size_t)y * a.Wd + x) * a.Cin + c;
                 if (c + 3 < a.Cin) v = *reinterpret_cast<const float4*>(p);
@@ -96,6 +107,10 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
         for (int rg = 0; rg < 4; ++rg) {
             const int r = (lane >> 4) * 4 + rg, y = ty0 + 2 * w + (r >> 3), x = tx0 + (r & 7);
             float* o = a.y + ((size_t)img * HW + (size_t)y * a.Wd + x) * a.Cout + co;
+            if constexpr (UNSHUF == 2) {
+                const int pp = co / a.Csrc, cs = co - pp * a.Csrc;
+                o = a.y + (((size_t)img * 2 * a.H + 2 * y + (pp >> 1)) * (2 * a.Wd) + 2 * x + (pp & 1)) * a.Csrc + cs;
+            }
             const float val = acc[e][rg] + bs;
             *o = a.beta != 0.f ? a.beta * (*o) + val : val;
         }
@@ -692,18 +707,6 @@ __global__ __launch_bounds__(64) void fu_attn_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// pixel-unshuffle 'b c (h p1) (w p2) -> b (c p1 p2) h w' (channel-last) and its inverse (scatter of gradients)
-__global__ void fu_unshuffle_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int Wd, int C, int64_t total, int inverse, float beta) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // index into the unshuffled tensor [img][H/2*W/2][4C]
-    if (i >= total) return;
-    const int C4 = 4 * C, cc = (int)(i % C4), h2 = H / 2, w2 = Wd / 2;
-    const int64_t pix = i / C4;
-    const int img = (int)(pix / (h2 * w2)), p = (int)(pix % (h2 * w2)), yy = p / w2, xx = p % w2;
-    const int c = cc >> 2, p1 = (cc >> 1) & 1, p2 = cc & 1;
-    const size_t src = ((size_t)img * H * Wd + (size_t)(2 * yy + p1) * Wd + 2 * xx + p2) * C + c;
-    if (!inverse) y[i] = x[src];
-    else y[src] = beta != 0.f ? beta * y[src] + x[i] : x[i];              // x: gradient in unshuffled layout, y: gradient of the source
-}
 __global__ void fu_add_kernel(const float* __restrict__ a, float* __restrict__ y, float beta, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < total) y[i] = beta != 0.f ? beta * y[i] + a[i] : a[i];
