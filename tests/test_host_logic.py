@@ -111,6 +111,21 @@ def test_constructor_validation():
     assert L.cindm_last_error()
 
 
+def test_constructor_validation_2d_and_force():
+    """Shapes the 2-D kernels do not serve are refused when the handle is created (host code, no GPU needed)."""
+    for kw in (dict(dim_mults=(1, 2, 4)), dict(dim_mults=(1, 2, 4, 8)), dict(image_size=128), dict(image_size=16)):
+        args = dict(dim=64, dim_mults=(1, 2), channels=21, image_size=64)
+        args.update(kw)
+        with pytest.raises(_ffi.CindmError):
+            cindm_amd.Unet(**args)
+    for kw in (dict(image_size=128), dict(image_size=32), dict(dim_mults=(1, 2, 4)), dict(dim_mults=(1, 3, 4, 8)), dict(dim=32)):
+        args = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=4, image_size=64)
+        args.update(kw)
+        with pytest.raises(_ffi.CindmError):
+            cindm_amd.ForceUnet(**args)
+    cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 8), channels=4, image_size=32)      # three levels: 32 -> 16 -> 8
+
+
 def test_diffusion_buffers_and_schedule(gold_dir):
     g = np.load(os.path.join(gold_dir, "schedule.npz"))
     m = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
