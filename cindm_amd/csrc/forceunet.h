@@ -425,25 +425,41 @@ __global__ __launch_bounds__(256) void fu_ln_bwd_kernel(const float* __restrict_
 // the backward pass), and two small fp32-MFMA GEMM shapes shared by forward and backward:
 //   fu_la_outer_kernel:  M[d][e] = alpha * sum_n X[n,d] Y[n,e]          (ctx = ks^T v / n ; dctx = qs^T dout)
 //   fu_la_rowmat_kernel: Z[n,e]  = alpha * sum_d X[n,d] M[d][e]          (out = qs ctx; the backward's three row products live in fu_la_bwd_fused_kernel)
+// column statistics of k over the pixels: kstat[img][c] = (max_n k[n,c], sum_n exp(k[n,c] - max)), c = h*32 + d.  One
+// workgroup per image, ONE pass (running maximum with the sum rescaled when it moves), a thread per float4 of the 128 k
+// channels and row phase: every row is read as 512 contiguous bytes.  (The first version ran a workgroup per (image, head)
+// -- 128-byte row pieces -- and read k twice: maximum, then sum.)
 __global__ __launch_bounds__(256) void fu_la_kstat_kernel(const float* __restrict__ qkv, float* __restrict__ kstat, int n) {
-    __shared__ float red[8][32];
-    const int img = blockIdx.y, h = blockIdx.x, d = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const float* kp = qkv + (size_t)img * n * 384 + 128 + h * 32 + d;
-    float mx = -INFINITY;
-    for (int i = part; i < n; i += 8) mx = fmaxf(mx, kp[(size_t)i * 384]);
-    red[part][d] = mx; __syncthreads();
-    mx = red[0][d];
+    __shared__ float4 rm[8][32], rs[8][32];
+    const int img = blockIdx.x, c4 = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const float* kp = qkv + (size_t)img * n * 384 + 128 + c4 * 4;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = part; i < n; i += 8) {
+        const float4 v4 = *reinterpret_cast<const float4*>(kp + (size_t)i * 384);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-    for (int p = 1; p < 8; ++p) mx = fmaxf(mx, red[p][d]);
+        for (int e = 0; e < 4; ++e) {
+            const float mn = fmaxf(m[e], v[e]);
+            s[e] = s[e] * __expf(m[e] - mn) + __expf(v[e] - mn);        // exp(-inf) = 0 on the first row
+            m[e] = mn;
+        }
+    }
+    rm[part][c4] = make_float4(m[0], m[1], m[2], m[3]); rs[part][c4] = make_float4(s[0], s[1], s[2], s[3]);
     __syncthreads();
-    float s = 0.f;
-    for (int i = part; i < n; i += 8) s += __expf(kp[(size_t)i * 384] - mx);
-    red[part][d] = s; __syncthreads();
     if (part == 0) {
-        s = 0.f;
+        float M[4] = {m[0], m[1], m[2], m[3]};
 #pragma unroll
-        for (int p = 0; p < 8; ++p) s += red[p][d];
-        kstat[((size_t)img * 128 + h * 32 + d) * 2] = mx; kstat[((size_t)img * 128 + h * 32 + d) * 2 + 1] = s;
+        for (int p = 1; p < 8; ++p) { const float4 o = rm[p][c4]; M[0] = fmaxf(M[0], o.x); M[1] = fmaxf(M[1], o.y); M[2] = fmaxf(M[2], o.z); M[3] = fmaxf(M[3], o.w); }
+        float S[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {                        // fixed order: the result repeats bit for bit
+            const float4 om = rm[p][c4], os = rs[p][c4];
+            S[0] += os.x * __expf(om.x - M[0]); S[1] += os.y * __expf(om.y - M[1]);
+            S[2] += os.z * __expf(om.z - M[2]); S[3] += os.w * __expf(om.w - M[3]);
+        }
+        float* o = kstat + ((size_t)img * 128 + c4 * 4) * 2;
+        *reinterpret_cast<float4*>(o) = make_float4(M[0], S[0], M[1], S[1]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(M[2], S[2], M[3], S[3]);
     }
 }
 // qs[n][h*32+d] = softmax_d(q) * scale ; ks[n][h*32+d] = exp(k - max_n) / sum_n.  One lane per float4 (4 channels of one
