@@ -64,8 +64,12 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = w >> 2, lw = w & 3;
     // ---- this workgroup's items -----------------------------------------------------------------------------------
-    const int ntiles = a.Npad / T2N, nch = a.CinP / KC, ipt = ntiles * nch;      // items per pixel tile
-    const int MT = a.NI * a.tpi;
+    // The unit of work a workgroup owns is a pixel tile with all its n-tiles (the staged planes serve them all) -- except
+    // in PAIR kind, where the unit is (pixel tile, n-tile): 384 tiles of 8 n-tiles x 8 chunks on 256 workgroups left a
+    // third of them with twice the work; 3072 units spread evenly (with 4-8 chunks per tile no plane is reused anyway).
+    constexpr bool NSPLIT = PAIR;
+    const int ntiles = a.Npad / T2N, nch = a.CinP / KC, ipt = NSPLIT ? nch : ntiles * nch;      // items per unit
+    const int MT = a.NI * a.tpi * (NSPLIT ? ntiles : 1);
     const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, wpx = gridDim.x >> 3;
     const int lo = (int)(((long long)xcd * MT) >> 3), hi = (int)(((long long)(xcd + 1) * MT) >> 3);
     const int mine = hi - lo > wj ? (hi - lo - wj + wpx - 1) / wpx : 0;
@@ -75,9 +79,10 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const int nch0 = (a.src[0].C + KC - 1) / KC;
     auto decode = [&](int k, int& mt, int& nt, int& ch) {
         const int tl = k / ipt, rem = k - tl * ipt;
-        nt = rem / nch; ch = rem - nt * nch;
-        mt = lo + wj + tl * wpx;
+        if constexpr (NSPLIT) { const int u = lo + wj + tl * wpx; mt = u / ntiles; nt = u - mt * ntiles; ch = rem; }
+        else { nt = rem / nch; ch = rem - nt * nch; mt = lo + wj + tl * wpx; }
     };
+    auto nt_of = [&](int tl) { return (lo + wj + tl * wpx) % ntiles; };      // NSPLIT: the n-tile of this workgroup's unit tl
 
     if (role == 0) {
         // =========================================== matrix waves ==================================================
@@ -126,15 +131,17 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        load_b(0, 0, 0, 0); load_b(0, 0, 1, 1); load_b(0, 0, 2, 2);
+        { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
         __syncthreads();                                     // S0: item 0 is staged
         // tile -> n-tile -> chunk: the same item order as decode(); nested so that the accumulators are defined by the
         // first chunk's tap 0 (zero C operand), updated by the other chunks and consumed by the reduce below
         int k = 0;
         for (int tl = 0; tl < mine; ++tl)
-            for (int nt = 0; nt < ntiles; ++nt) {
+            for (int nt = NSPLIT ? nt_of(tl) : 0, nt_end = NSPLIT ? nt + 1 : ntiles; nt < nt_end; ++nt) {
+                // the n-tile of the item after this (unit, n-tile)'s last chunk: the weight ring runs across items
+                const int nt_after = NSPLIT ? (tl + 1 < mine ? nt_of(tl + 1) : 0) : (nt + 1 < ntiles ? nt + 1 : 0);
                 {
-                    const int nt2 = nch > 1 ? nt : (nt + 1 < ntiles ? nt + 1 : 0), ch2 = nch > 1 ? 1 : 0;
+                    const int nt2 = nch > 1 ? nt : nt_after, ch2 = nch > 1 ? 1 : 0;
                     if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, 0, nt2, ch2, std::true_type{});
                     else {
 #pragma unroll
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
                 }
                 for (int ch = 1; ch < nch; ++ch) {
-                    const int nt2 = ch + 1 < nch ? nt : (nt + 1 < ntiles ? nt + 1 : 0), ch2 = ch + 1 < nch ? ch + 1 : 0;
+                    const int nt2 = ch + 1 < nch ? nt : nt_after, ch2 = ch + 1 < nch ? ch + 1 : 0;
                     if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
                     ++k;
                     __syncthreads();                         // S1
