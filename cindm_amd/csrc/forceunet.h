@@ -723,6 +723,22 @@ __global__ __launch_bounds__(64) void fu_attn_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// max |x| of a tensor as a bit pattern (for conv2d_ws_kernel<.., SRC2_SCALED> when the gradient's producer did not leave
+// one): grid-stride float4 pass, one atomic maximum per workgroup; *amax is zeroed by the host before the launch
+__global__ __launch_bounds__(256) void fu_absmax_kernel(const float* __restrict__ x, int64_t total4, unsigned* __restrict__ amax) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (!(m <= 3.0e38f)) m = 3.0e38f;
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_max(amax, __builtin_bit_cast(unsigned, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void fu_add_kernel(const float* __restrict__ a, float* __restrict__ y, float beta, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < total) y[i] = beta != 0.f ? beta * y[i] + a[i] : a[i];
