@@ -162,3 +162,23 @@ def test_forceunet_other_image_sizes(device, size, mults, n):
     y = O.force_unet_forward(sd, xo)
     ref = torch.autograd.grad((0.7 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
     assert rel(out, y.detach()) < TOL and rel(dx, ref) < TOL
+
+
+def test_forceunet_full_batch_repeatable_and_batch_independent(device, force):
+    """768 images -- one design-gradient pass of config 5 (64 designs x 2 boundaries x 6 frames), every persistent workgroup
+    of the 3x3 kernel walking many tiles: the pass repeats bit for bit, and an image's output and input gradient do not
+    depend on what else is in the batch (to tolerance: the input-gradient convolutions scale by the batch's maximum)."""
+    m, sd = force
+    x = torch.randn((768, 4, 64, 64), generator=torch.Generator().manual_seed(17))
+    xd = x.to(device)
+    out, dx = m.input_grad(xd, lambda_force=1.3)
+    out2, dx2 = m.input_grad(xd, lambda_force=1.3)
+    assert torch.isfinite(out).all() and torch.isfinite(dx).all()
+    assert torch.equal(out, out2) and torch.equal(dx, dx2)
+    idx = [0, 255, 256, 511, 766, 767]
+    outs, dxs = m.input_grad(xd[idx], lambda_force=1.3)
+    assert rel(out[idx], outs.cpu().numpy()) < TOL and rel(dx[idx], dxs.cpu().numpy()) < TOL
+    xo = x[[255, 767]].clone().requires_grad_(True)
+    y = O.force_unet_forward(sd, xo)
+    ref = torch.autograd.grad((1.3 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
+    assert rel(out[[255, 767]], y.detach()) < TOL and rel(dx[[255, 767]], ref) < TOL
