@@ -182,3 +182,22 @@ def test_forceunet_full_batch_repeatable_and_batch_independent(device, force):
     y = O.force_unet_forward(sd, xo)
     ref = torch.autograd.grad((1.3 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
     assert rel(out[[255, 767]], y.detach()) < TOL and rel(dx[[255, 767]], ref) < TOL
+
+
+def test_design_gradient_config5_shape_is_design_independent(device, force):
+    """The objective at config 5's shape (64 designs x 2 boundaries x 6 frames = one 768-image surrogate pass): designs
+    do not interact, so designs 0, 31 and 63 of the full call equal a 3-design call on the same states; and frame batching
+    (frames_per_pass 6 vs 1) is only a batching choice."""
+    m, _ = force
+    B, nb, frames = 64, 2, 6
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn((B * nb, 3 * frames + 3, 64, 64), generator=gen) * 0.5
+    x[:, -3] = (torch.rand((B * nb, 64, 64), generator=gen) > 0.7).float() * 0.7 + 0.05 * torch.randn((B * nb, 64, 64), generator=gen)
+    kw = dict(p_min=-37.7, p_max=57.6, lambda_force=1.0, lambda_overlap=1.0)
+    full = cindm_amd.ForceObjective(m, B, nb, frames, **kw)(x.to(device))
+    assert torch.isfinite(full).all()
+    rows = [d * nb + b for d in (0, 31, 63) for b in range(nb)]
+    sub = cindm_amd.ForceObjective(m, 3, nb, frames, **kw)(x[rows].to(device))
+    assert rel(full[rows], sub.cpu().numpy()) < TOL
+    one = cindm_amd.ForceObjective(m, 3, nb, frames, frames_per_pass=1, **kw)(x[rows].to(device))
+    assert rel(sub, one.cpu().numpy()) < TOL
