@@ -6,7 +6,9 @@ batch of 256 nbody-2 designs through TemporalUnet1D(dim=64, horizon=24) (BASELIN
 synthetic generator-defined weights (cindm_amd.synthetic), x_T and per-step noise from the in-kernel counter-based generator.
 Inputs (weights, state) are resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W            (--workload cfg5: the 2-D airfoil configuration)
+    python bench.py --gpus N --steps K --warmup W            (--workload cfg5: the 2-D airfoil configuration, see DESIGN.md;
+                                                              --workload cfg5g --steps 1 --warmup 1: the same under the force
+                                                              objective, ~55 s per chain)
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank samples its own 256 designs
 (weak scaling, no communication inside the loop) and the final designs are all-gathered over RCCL.
 Prints ONE JSON line on rank 0.
@@ -222,9 +224,17 @@ def main_cfg5(args):
     B, nb = (args.batch or 64), 2
     total = B * world
     stream = torch.cuda.Stream(device=dev)
+    # --workload cfg5g: the same chain under the airfoil design objective (inference/inverse_design_2d.py:208-214): every
+    # reverse step also runs the ForceUnet surrogate forward + input gradient over 6 frames x B x nb images and shifts the
+    # state by eta_t * gradient ("standard-alpha"), all inside the captured step
+    guided = args.workload == "cfg5g"
+    design_kw = {}
+    if guided:
+        force = synthetic_init_(cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4), seed=7).to(dev)
+        design_kw = dict(design_fn=cindm_amd.ForceObjective(force, B, nb, 6, p_min=-37.7, p_max=57.6), design_guidance="standard-alpha")
 
     def one_chain(i):
-        local = diffusion.sample(batch_size=B, num_boundaries=nb, seed=1234 + i, sample_offset=rank * B)
+        local = diffusion.sample(batch_size=B, num_boundaries=nb, seed=1234 + i, sample_offset=rank * B, **design_kw)
         return cdist.all_gather_designs(local, total) if distributed else local
 
     def fence():
@@ -293,14 +303,18 @@ def main_cfg5(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"airfoil 2-D: Unet dim=64 mults (1,2) channels=21 on 64x64, {nb}-boundary composition, "
-                                   f"batch {B} designs/GPU ({B * nb} images per reverse step), {TIMESTEPS} DDPM steps (BASELINE configs[4])",
+                                   f"batch {B} designs/GPU ({B * nb} images per reverse step), {TIMESTEPS} DDPM steps (BASELINE configs[4])"
+                                   + (f"; force-guided (standard-alpha): ForceUnet dim=64 mults (1,2,4,8) forward + input gradient on "
+                                      f"{6 * B * nb} images per step inside the captured step" if guided else ""),
                        "designs_per_step": total, "unet_evals_per_design": TIMESTEPS * nb,
                        "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
             "model_tflops": round(value * flop_design / 1e12, 2),
             "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if guided:
+            line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r02_force_kernel_stats_v5.txt"
+        if not args.no_cpu_baseline and world == 1 and not guided:
             line["cpu_baseline"] = cpu_baseline_2d(cpu_state_dict(model))
         print(json.dumps(line), flush=True)
     if distributed:
@@ -313,12 +327,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2, 64 for cfg5)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
-                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg5 = the 2-D airfoil configuration")
+    ap.add_argument("--workload", choices=("cfg2", "cfg5", "cfg5g"), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg5 = the 2-D airfoil configuration; "
+                         "cfg5g = cfg5 under the ForceUnet design objective (force-guided sampling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     spawn_ranks_if_needed(args)
-    if args.workload == "cfg5":
+    if args.workload in ("cfg5", "cfg5g"):
         return main_cfg5(args)
     args.batch = args.batch or BATCH
 
