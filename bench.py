@@ -6,12 +6,16 @@ batch of 256 nbody-2 designs through TemporalUnet1D(dim=64, horizon=24) (BASELIN
 synthetic generator-defined weights (cindm_amd.synthetic), x_T and per-step noise from the in-kernel counter-based generator.
 Inputs (weights, state) are resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W            (--workload cfg5: the 2-D airfoil configuration, see DESIGN.md;
-                                                              --workload cfg5g --steps 1 --warmup 1: the same under the force
-                                                              objective, ~55 s per chain)
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank samples its own 256 designs
+    python bench.py --gpus N --steps K --warmup W [--workload W]
+        cfg2 (default)  BASELINE configs[1]: the metric's configuration
+        cfg3            configs[2]: time composition, three 24-step windows -> 56 steps, batch 256
+        cfg4            configs[3]: 4-body composition (6 pair + 4 single-body evaluations, 400 steps), 128 designs per GPU
+        cfg2-ddim250    cfg2 with the inference scripts' default 250 DDIM steps
+        cfg5 / cfg5g    configs[4]: the 2-D airfoil configuration, plain / under the ForceUnet design objective
+                        (cfg5g: --steps 1 --warmup 1, ~35-55 s per chain)
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank samples its own designs
 (weak scaling, no communication inside the loop) and the final designs are all-gathered over RCCL.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0, with `roofline`, `cpu_baseline` and `rel_err` for every workload.
 """
 import argparse
 import json
@@ -41,11 +45,21 @@ def cpu_state_dict(model):
 
 
 def pmc_step_traffic(fname):
-    """Memory-side bytes of one whole reverse step (all kernels) from the committed PMC passes; None if absent."""
+    """(memory-side bytes of one whole reverse step from the committed PMC passes, provenance note).  The file records the
+    source hash of the library it was measured on (tools/pmc_traffic.py); when that differs from the library loaded now
+    the numbers describe other kernels and are dropped: (None, why)."""
+    path = os.path.join(ROOT, "profiles", fname)
     try:
-        return int(json.load(open(os.path.join(ROOT, "profiles", fname)))["bytes_per_step"])
+        rec = json.load(open(path))
     except Exception:
-        return None
+        return None, f"profiles/{fname} not present: PMC-derived fields are null"
+    from cindm_amd import _ffi
+    have = _ffi.lib().cindm_source_hash().decode()
+    want = rec.get("source_hash")
+    if want != have:
+        return None, (f"profiles/{fname} was measured on library {str(want)[:12]}, the loaded library is {have[:12]}: "
+                      "PMC-derived fields dropped (re-run tools/r3_measure.sh)")
+    return int(rec["bytes_per_step"]), f"profiles/{fname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on library {have[:12]}"
 
 
 def cpu_info():
@@ -69,59 +83,6 @@ def cpu_info():
     except OSError:
         pass
     return model, phys or os.cpu_count()
-
-
-def cpu_baseline(sd, diffusion=None, dev=None, budget_s=20.0):
-    """The oracle (a torch-CPU port of the reference's path; oracle/ is test infrastructure and is imported ONLY in the
-    two cpu_baseline legs) timed on this box's host cores on a bounded sample of the same workload: reverse steps of
-    the batch-256 config, extrapolated to 1000 steps.  The thread count is swept first (the tiny convolutions of this
-    model do not scale to every core of a large host) and the FASTEST setting is the one reported.  The same steps, on
-    the same inputs and explicit noise, are then taken by the HIP path: `rel_err` is the metric's second half."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cindm_oracle as O
-    d = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
-    g = torch.Generator().manual_seed(0)
-    x0 = torch.randn((BATCH, 24, 8), generator=g)
-    kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
-    model, phys = cpu_info()
-    default_threads = torch.get_num_threads()
-    sweep = {}
-    with torch.no_grad():
-        nz = torch.randn((BATCH, 24, 8), generator=g)
-        for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)}):
-            torch.set_num_threads(nt)
-            O.p_sample_compose_outside(d, x0, None, 500, nz, **kw)          # warm-up
-            t0 = time.time()
-            for _ in range(2):
-                O.p_sample_compose_outside(d, x0, None, 500, nz, **kw)
-            sweep[nt] = (time.time() - t0) / 2
-        best = min(sweep, key=sweep.get)
-        torch.set_num_threads(best)
-        x = x0.clone()
-        noises = []
-        n, t0 = 0, time.time()
-        while True:
-            nzk = torch.randn((BATCH, 24, 8), generator=g)
-            noises.append(nzk)
-            x, _ = O.p_sample_compose_outside(d, x, None, 500 - n, nzk, **kw)
-            n += 1
-            if time.time() - t0 > budget_s or n >= 100:
-                break
-        dt = (time.time() - t0) / n
-        torch.set_num_threads(default_threads)
-    out = {"value": BATCH / (dt * TIMESTEPS), "unit": "samples/s", "cores": best, "kind": "port",
-           "sample": f"{n} reverse steps of batch {BATCH} ({dt * 1e3:.1f} ms/step), extrapolated x{TIMESTEPS}",
-           "cpu_model": model, "physical_cores": phys,
-           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())}}
-    rel_err = None
-    if diffusion is not None:
-        xg = x0.to(dev)
-        for k, nzk in enumerate(noises):
-            xg, _ = diffusion.p_sample_compose_outside(xg, None, 500 - k, compose_mode="mean", n_composed=0, compose_start_step=4,
-                                                       single_model_step=24, compose_n_bodies=2, noise=nzk.to(dev))
-        torch.cuda.synchronize(dev)
-        rel_err = float((xg.cpu() - x).abs().max() / x.abs().max())
-    return out, rel_err
 
 
 def spawn_ranks_if_needed(args):
@@ -272,7 +233,8 @@ def main_cfg5(args):
             achieved = k3[2] / (k3[1] * 1e-3) / 1e12
             h3 = os.environ.get("CINDM_MFMA") != "f32"
             step_s = elapsed / args.steps / TIMESTEPS
-            pmc = pmc_step_traffic("r02_pmc_traffic_cfg5.json")
+            pmc_file = "r03_pmc_traffic_cfg5.json"
+            pmc, pmc_note = pmc_step_traffic(pmc_file)
             if h3:
                 # the 3x3 convolutions evaluate every fp32 product as 3 fp16 MFMA products: price the pipe actually
                 # used (executed fp16 FLOPs against the dense fp16 peak), not algorithmic fp32 FLOPs against the fp32 peak
@@ -284,7 +246,8 @@ def main_cfg5(args):
             else:
                 roof = {"bound": "mfma", "kernel": "conv2d_tile_kernel<3x3 / upsampled 3x3> (fp32 MFMA)", "achieved": round(achieved, 2),
                         "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4)}
-            roof.update({"traffic": pmc_traffic("r02_pmc_traffic_cfg5.json", "conv2d_ws_kernel<0, 0" if h3 else "conv2d_tile_kernel<0"),
+            roof.update({"traffic": pmc_traffic(pmc_file, "conv2d_ws_kernel<0, 0" if h3 else "conv2d_tile_kernel<0") if pmc else None,
+                         "pmc_provenance": pmc_note,
                          "launches_per_forward": k3[0] // reps, "avg_launch_us": round(k3[1] / k3[0] * 1e3, 2),
                          "timing": "HIP events around every launch on the launch stream (cindm_unet2d_profile), 5 forwards",
                          "share_of_forward_time": round(k3[1] / tot_ms, 3),
@@ -313,7 +276,7 @@ def main_cfg5(args):
             "roofline": roof,
         }
         if guided:
-            line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r02_force_kernel_stats_v5.txt"
+            line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r03_force_kernel_stats*.txt"
         if not args.no_cpu_baseline and world == 1 and not guided:
             line["cpu_baseline"] = cpu_baseline_2d(cpu_state_dict(model))
         print(json.dumps(line), flush=True)
@@ -321,21 +284,155 @@ def main_cfg5(args):
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# 1-D workloads.  Each entry builds (diffusion, chain(i, rank) -> local designs, description) and the CPU leg's step.
+FLOP_PER_EVAL_F4 = 160_300_000     # the single-body model (F = 4) of config 4
+
+
+def build_1d(workload, B, dev):
+    """The models / diffusion object of a 1-D workload and everything bench needs to run and describe it."""
+    import cindm_amd
+    from cindm_amd.synthetic import synthetic_init_
+    pair = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64,
+                                                    dim_mults=(1, 2, 4, 8), attention=True), seed=0)
+    w = {"pair": pair, "single": None, "steps_per_design": TIMESTEPS}
+    if workload in ("cfg2", "cfg2-ddim250"):
+        S = 250 if workload == "cfg2-ddim250" else TIMESTEPS
+        d = cindm_amd.GaussianDiffusion1D(pair, image_size=24, conditioned_steps=0, timesteps=TIMESTEPS, sampling_timesteps=S,
+                                          loss_type="l1").to(dev)
+        w.update(diffusion=d, out_shape=(24, 8), rows=(B, 0), evals=(1, 0), steps_per_design=S,
+                 chain=lambda i, off: d.sample(batch_size=B, cond=None, n_composed=0, compose_n_bodies=2, seed=1234 + i, sample_offset=off),
+                 text=(f"nbody-2 TemporalUnet1D dim=64 horizon=24 attention, single model, batch {B}/GPU, {TIMESTEPS} DDPM steps per design "
+                       "(BASELINE configs[1])") if S == TIMESTEPS else
+                      (f"nbody-2 TemporalUnet1D dim=64 horizon=24 attention, single model, batch {B}/GPU, DDIM with sampling_timesteps=250 "
+                       "(the inference scripts' default, inference_1d_composing_multibodies.py:38; eta = 0) of the 1000-step schedule"))
+    elif workload == "cfg3":
+        d = cindm_amd.GaussianDiffusion1D(pair, image_size=24, conditioned_steps=0, timesteps=TIMESTEPS, sampling_timesteps=TIMESTEPS,
+                                          loss_type="l1").to(dev)
+        kw = dict(n_composed=2, compose_start_step=16, compose_mode="mean-inside", compose_n_bodies=2)
+        w.update(diffusion=d, out_shape=(56, 8), rows=(3 * B, 0), evals=(3, 0), compose_kw=kw,
+                 chain=lambda i, off: d.sample(batch_size=B, cond=None, seed=1234 + i, sample_offset=off, **kw),
+                 text=f"nbody-2 time composition: three 24-step windows of one TemporalUnet1D (dim=64) composed to a 56-step trajectory "
+                      f"(compose_start_step 16, mean-inside), batch {B}/GPU = {3 * B} U-Net rows per reverse step, {TIMESTEPS} DDPM steps "
+                      "(BASELINE configs[2])")
+    elif workload == "cfg4":
+        single = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=4, cond_dim=False, dim=64,
+                                                          dim_mults=(1, 2, 4, 8), attention=True), seed=1)
+        d = cindm_amd.GaussianDiffusion1D(pair, image_size=20, conditioned_steps=4, timesteps=TIMESTEPS, sampling_timesteps=TIMESTEPS,
+                                          loss_type="l1").to(dev)
+        d.model_unconditioned = single.to(dev)
+        N = 400
+        cond = torch.rand((B, 4, 16), generator=torch.Generator().manual_seed(0)).to(dev)
+        w.update(diffusion=d, single=single, out_shape=(20, 16), rows=(6 * B, 4 * B), evals=(6, 4), steps_per_design=N, cond=cond,
+                 chain=lambda i, off: d.sample_compose_multibodies(cond, N, 0, 4, seed=1234 + i, sample_offset=off),
+                 text=f"nbody-4 body composition (inference_1d_composing_multibodies.py): six 2-body evaluations + four single-body "
+                      f"evaluations (coefficient 1.4) per step, {N} reverse steps, 4 conditioning + 20 predicted steps, {B} designs/GPU = "
+                      f"{6 * B} + {4 * B} U-Net rows per step (BASELINE configs[3]; 1024 designs at --gpus 8)")
+    else:
+        raise ValueError(workload)
+    return w
+
+
+def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0):
+    """cpu_baseline + rel_err of a 1-D workload: the oracle's reverse steps (t = 500 downwards) on the host cores for
+    ~budget_s, the fastest thread count of a short sweep, extrapolated to the chain length; then the same steps on the
+    same inputs and explicit noise through the HIP path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cindm_oracle as O
+    d = w["diffusion"]
+    sd = cpu_state_dict(w["pair"])
+    g = torch.Generator().manual_seed(0)
+    L, F = w["out_shape"]
+    x0 = torch.randn((B, L, F), generator=g)
+    cond = w["cond"].cpu() if "cond" in w else None
+    if workload == "cfg4":
+        od = O.Diffusion1D(sd, image_size=20, conditioned_steps=4, sd_uncond=cpu_state_dict(w["single"]))
+        t_first = 399
+        cpu_step = lambda x, t, nz: O.p_sample(od, x, cond, t, nz)[0]
+        gpu_step = lambda x, t, nz: d.p_sample(x, w["cond"], t, noise=nz)[0]
+    elif workload == "cfg3":
+        od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+        kw = dict(w["compose_kw"], single_model_step=24)
+        t_first = 500
+        cpu_step = lambda x, t, nz: O.p_sample_compose_inside(od, x, None, t, nz, **kw)[0]
+        gpu_step = lambda x, t, nz: d.p_sample_compose_inside(x, None, t, noise=nz, **kw)[0]
+    else:
+        od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+        kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+        t_first = 500
+        cpu_step = lambda x, t, nz: O.p_sample_compose_outside(od, x, None, t, nz, **kw)[0]
+        gpu_step = lambda x, t, nz: d.p_sample_compose_outside(x, None, t, noise=nz, **kw)[0]
+    model, phys = cpu_info()
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    with torch.no_grad():
+        nz = torch.randn((B, L, F), generator=g)
+        for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)}):
+            torch.set_num_threads(nt)
+            cpu_step(x0, t_first, nz)
+            t0 = time.time()
+            cpu_step(x0, t_first, nz)
+            sweep[nt] = time.time() - t0
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        x, noises, n, t0 = x0.clone(), [], 0, time.time()
+        while True:
+            nzk = torch.randn((B, L, F), generator=g)
+            noises.append(nzk)
+            x = cpu_step(x, t_first - n, nzk)
+            n += 1
+            if time.time() - t0 > budget_s or n >= 100:
+                break
+        dt = (time.time() - t0) / n
+        torch.set_num_threads(default_threads)
+    S = w["steps_per_design"]
+    out = {"value": B / (dt * S), "unit": "samples/s", "cores": best, "kind": "port",
+           "sample": f"{n} reverse steps of batch {B} ({dt * 1e3:.1f} ms/step), extrapolated x{S}"
+                     + (" (a DDIM step costs the same U-Net evaluation)" if workload == "cfg2-ddim250" else ""),
+           "cpu_model": model, "physical_cores": phys,
+           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())}}
+    xg = x0.to(dev)
+    for k, nzk in enumerate(noises):
+        xg = gpu_step(xg, t_first - k, nzk.to(dev))
+    torch.cuda.synchronize(dev)
+    rel = float((xg.cpu() - x).abs().max() / x.abs().max())
+    extra = {}
+    if workload == "cfg2-ddim250":
+        # teacher-forced DDIM parity (the deterministic sampler with random-init weights is chaotic: a 1e-6 perturbation of
+        # the CPU reference's own U-Net output moves a 50-step result by 1e-3, DESIGN.md section 2): every one of the first
+        # 10 DDIM steps (eta = 0) is taken by the HIP path FROM THE CPU PATH'S STATE and compared with the CPU path's next state
+        times = O.ddim_time_pairs(TIMESTEPS, 250)[:10]
+        img, worst = x0.clone(), 0.0
+        with torch.no_grad():
+            for i, (time_, time_next) in enumerate(times):
+                pn, xs = O.model_predictions(od, img, None, time_, clip_x_start=True)
+                san, c, _ = O.ddim_coefs(od, time_, time_next, 0.0)
+                nxt = xs * san + c * pn
+                gi = d.ddim_sample((B, L, F), None, init_img=img.to(dev), step_range=(i, i + 1), seed=0)
+                worst = max(worst, float((gi.cpu() - nxt).abs().max() / nxt.abs().max()))
+                img = nxt
+        extra["rel_err_ddim_teacher_forced"] = worst
+        extra["rel_err_ddim_note"] = "max over the first 10 DDIM steps, each taken from the CPU path's state (eta = 0)"
+    return out, rel, extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2, 64 for cfg5)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg5", "cfg5g"), default="cfg2",
-                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg5 = the 2-D airfoil configuration; "
-                         "cfg5g = cfg5 under the ForceUnet design objective (force-guided sampling)")
+    ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2 / cfg3, 128 for cfg4, 64 for cfg5)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg2-ddim250", "cfg5", "cfg5g"), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] (time composition, 3 windows -> "
+                         "56 steps); cfg4 = configs[3] (4-body composition, script path, 128 designs per GPU); cfg2-ddim250 = cfg2 with the "
+                         "scripts' default 250 DDIM steps; cfg5 = configs[4] (2-D airfoil); cfg5g = cfg5 under the ForceUnet design objective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     spawn_ranks_if_needed(args)
     if args.workload in ("cfg5", "cfg5g"):
         return main_cfg5(args)
-    args.batch = args.batch or BATCH
+    wl = args.workload
+    args.batch = args.batch or (128 if wl == "cfg4" else BATCH)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -347,22 +444,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    import cindm_amd
     from cindm_amd import dist as cdist
-
-    from cindm_amd.synthetic import synthetic_init_
-    model = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64,
-                                                     dim_mults=(1, 2, 4, 8), attention=True), seed=0)
-    diffusion = cindm_amd.GaussianDiffusion1D(model, image_size=24, conditioned_steps=0, timesteps=TIMESTEPS,
-                                              sampling_timesteps=TIMESTEPS, loss_type="l1").to(dev)
     B = args.batch
     total = B * world
+    w = build_1d(wl, B, dev)
+    model, diffusion = w["pair"], w["diffusion"]
     stream = torch.cuda.Stream(device=dev)
 
     def one_chain(i):
         # rank r owns global designs [r*B, (r+1)*B): noise is keyed by the global index
-        local = diffusion.sample(batch_size=B, cond=None, n_composed=0, compose_n_bodies=2, seed=1234 + i,
-                                 sample_offset=rank * B)
+        local = w["chain"](i, rank * B)
         return cdist.all_gather_designs(local, total) if distributed else local
 
     def fence():
@@ -383,17 +474,21 @@ def main():
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        assert tuple(out.shape) == (total, 24, 8) and bool(torch.isfinite(out).all())
+        assert tuple(out.shape) == (total,) + w["out_shape"] and bool(torch.isfinite(out).all())
+        step_launches, step_fused = diffusion.last_step_info()
 
         # ---- roofline leg (rank 0): per-dispatch begin / end timestamps of one forward in launch order ----
         # (hipExtLaunchKernelGGL start / stop events: the kernel's own duration, what rocprofv3 --kernel-trace reports;
-        # one pass per forward, so weights and activations are as cold as inside the replayed step)
+        # one pass per forward, so weights and activations are as cold as inside the replayed step), at the row count the
+        # pair model sees in this workload
         roof = None
+        S = w["steps_per_design"]
         if rank == 0:
-            x = torch.randn((B, 24, 8), device=dev)
+            rows = w["rows"][0]
+            x = torch.randn((rows, 24, 8), device=dev)
             model.profile(x, 500)
             acc = {}
-            reps = 20
+            reps = 20 if rows <= 256 else 8
             for _ in range(reps):
                 for k, (n, ms, fl) in model.profile(x, 500).items():
                     a = acc.setdefault(k, [0, 0.0, 0.0])
@@ -403,16 +498,19 @@ def main():
             achieved = k5[2] / (k5[1] * 1e-3) / 1e12          # algorithmic FLOPs of the k=5 conv launches / their time
             f32_path = os.environ.get("CINDM_MFMA") == "f32"
             kname = "conv_gemm_kernel<5,32,48,*> (fp32 MFMA)" if f32_path else \
-                "dconv_kernel<L,K0,K1,RES> (the 18 deep-level k=5 convolutions of a forward; fp32 products as 3 fp16 MFMAs, fp32 accumulate)"
-            step_s = elapsed / (args.steps * TIMESTEPS)
-            pmc = pmc_step_traffic("r02_pmc_traffic_cfg2.json")
+                "dconv_kernel<L,K0,K1,RES> (the deep-level k=5 convolutions of a forward; fp32 products as 3 fp16 MFMAs, fp32 accumulate)"
+            step_s = elapsed / (args.steps * S)
+            pmc_file = f"r03_pmc_traffic_{wl}.json"
+            pmc, pmc_note = pmc_step_traffic(pmc_file)
             roof = {"bound": "latency",
-                    "bound_note": "neither roofline binds: the reverse step is a chain of ~29 dependent launches; per launch ~2 us "
+                    "bound_note": f"neither roofline binds: the reverse step is a chain of {step_launches} dependent launches; per launch ~2 us "
                                   "dispatch gap + ~2 us prologue + ~3 us epilogue around ~3 us of weight streaming / MFMA work",
                     "kernel": kname, "achieved": round(achieved, 2),
                     "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
-                    "traffic": pmc_traffic("r02_pmc_traffic_cfg2.json", "conv_gemm_kernel<5" if f32_path else "dconv_kernel<"),
+                    "traffic": pmc_traffic(pmc_file, "conv_gemm_kernel<5" if f32_path else "dconv_kernel<") if pmc else None,
                     "launches_per_forward": k5[0] // reps, "avg_launch_us": round(k5[1] / k5[0] * 1e3, 2),
+                    "launches_per_reverse_step": step_launches, "update_fused_into_last_kernel": step_fused,
+                    "rows_profiled": rows,
                     "timing": "per-dispatch begin/end timestamps (hipExtLaunchKernelGGL events), one pass in forward order",
                     "share_of_forward_time": round(k5[1] / tot_ms, 3),
                     "forward_ms_sum_of_kernels": round(tot_ms / reps, 3),
@@ -424,28 +522,31 @@ def main():
                 roof["hbm_bytes_per_step"] = pmc
                 roof["hbm_gbps_whole_step"] = round(pmc / step_s / 1e9, 1)
                 roof["frac_of_hbm_peak"] = round(pmc / step_s / 1e9 / PEAK_HBM_GBPS, 4)
+            roof["pmc_provenance"] = pmc_note
 
     if rank == 0:
         chains = args.steps
         value = total * chains / elapsed
+        flop_design = S * (w["evals"][0] * FLOP_PER_EVAL + w["evals"][1] * FLOP_PER_EVAL_F4)
         line = {
             "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / chains * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"nbody-2 TemporalUnet1D dim=64 horizon=24 attention, single model, batch {B}/GPU, "
-                                   f"{TIMESTEPS} DDPM steps per design (BASELINE configs[1])",
-                       "designs_per_step": total, "unet_evals_per_design": TIMESTEPS,
-                       "parallelism": f"dp{world} (batch-sharded, one all-gather of final designs)"},
-            "sample_steps_per_s": round(value * TIMESTEPS, 1),
-            "model_tflops": round(value * TIMESTEPS * FLOP_PER_EVAL / 1e12, 2),
-            "frac_of_f32_mfma_peak_whole_job": round(value * TIMESTEPS * FLOP_PER_EVAL / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
+            "config": {"workload": w["text"], "designs_per_step": total, "unet_evals_per_design": S * sum(w["evals"]),
+                       "reverse_steps_per_design": S,
+                       "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
+            "us_per_reverse_step": round(elapsed / (chains * S) * 1e6, 1),
+            "sample_steps_per_s": round(value * S, 1),
+            "model_tflops": round(value * flop_design / 1e12, 2),
+            "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], line["rel_err"] = cpu_baseline(cpu_state_dict(model), diffusion, dev)
-            line["rel_err_note"] = "max-abs / max-abs of the state after the cpu_baseline leg's reverse steps (batch 256, t = 500 downwards, " \
-                                   "same weights, inputs and explicit noise on both sides); tolerance 1e-4"
+            line["cpu_baseline"], line["rel_err"], extra = cpu_baseline_1d(wl, w, B, dev)
+            line.update(extra)
+            line["rel_err_note"] = "max-abs / max-abs of the state after the cpu_baseline leg's reverse steps (same weights, inputs and explicit " \
+                                   "noise on both sides, free-running); tolerance 1e-4"
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

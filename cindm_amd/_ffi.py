@@ -99,6 +99,7 @@ SIGNATURES = {
                                              _u64, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _sz, _vp, _i32]),
     "cindm_fill_normal": (C.c_int, [_vp, _i64, _i64, _u64, _i64, _i32, _vp]),
     "cindm_ddpm1d_launches_per_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(ComposeDesc)]),
+    "cindm_ddpm1d_last_step_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "cindm_unet2d_create": (C.c_int, [C.POINTER(Unet2dDesc), C.POINTER(_vp)]),
     "cindm_unet2d_destroy": (None, [_vp]),
     "cindm_unet2d_num_params": (C.c_int, [_vp]),
@@ -124,16 +125,19 @@ SIGNATURES = {
     "cindm_forceunet_num_params": (C.c_int, [_vp]),
     "cindm_forceunet_param_info": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(_i64 * 4), C.POINTER(C.c_int)]),
     "cindm_forceunet_set_param": (C.c_int, [_vp, C.c_char_p, _vp, _i64, C.c_int]),
+    "cindm_forceunet_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "cindm_forceunet_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "cindm_forceunet_finalize": (C.c_int, [_vp, _vp]),
     "cindm_forceunet_workspace_bytes": (_sz, [_vp, _i64, _i32]),
     "cindm_forceunet_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "cindm_forceunet_grad": (C.c_int, [_vp, _vp, C.c_float, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "cindm_forceunet_vjp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "cindm_airfoil_design_workspace_bytes": (_sz, [_vp, _i64, _i32, _i32]),
     "cindm_airfoil_design_grad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, _i32,
-                                            _vp, _vp, _sz, _vp]),
+                                            _i32, _vp, _vp, _sz, _vp]),
     "cindm_ddpm2d_sample_force": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _i32, _i32,
-                                            C.c_float, C.c_float, C.c_float, C.c_float, _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp,
-                                            _i32]),
+                                            C.c_float, C.c_float, C.c_float, C.c_float, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _sz,
+                                            _vp, _i32]),
 }
 
 

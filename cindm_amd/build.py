@@ -30,13 +30,48 @@ def source_hash():
     return h.hexdigest()
 
 
+_MARK = b"CINDM_SRC_HASH="
+
+
+def embedded_hash(path=LIB):
+    """The source hash compiled into a built library (the marker string behind cindm_source_hash()), read from the file's
+    bytes -- no dlopen, so a stale library is never mapped into the process that is about to rebuild it."""
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+    except OSError:
+        return None
+    i = data.find(_MARK)
+    if i < 0:
+        return None
+    h = data[i + len(_MARK):i + len(_MARK) + 64]
+    try:
+        return h.decode("ascii") if len(h) == 64 and int(h, 16) >= 0 else None
+    except ValueError:
+        return None
+
+
 def needs_build():
-    """True when the library is missing or was built from different sources (hash recorded beside it at build time;
-    file times are not trusted: a snapshot copy resets them)."""
-    if not os.path.isfile(LIB) or not os.path.isfile(HASH_FILE):
+    """True when the library is missing or was built from different sources.  The hash recorded beside the library at
+    build time is a cache of the hash embedded IN it: a library that was copied without its side file (a shipped .so on a
+    machine without hipcc) is accepted when its embedded hash matches the tree.  File times are not trusted: a snapshot
+    copy resets them."""
+    if not os.path.isfile(LIB):
         return True
-    with open(HASH_FILE) as f:
-        return f.read().strip() != source_hash()
+    want = source_hash()
+    if os.path.isfile(HASH_FILE):
+        with open(HASH_FILE) as f:
+            if f.read().strip() == want:
+                return False
+    if embedded_hash(LIB) == want:
+        try:
+            with open(HASH_FILE + f".tmp{os.getpid()}", "w") as f:
+                f.write(want + "\n")
+            os.replace(HASH_FILE + f".tmp{os.getpid()}", HASH_FILE)
+        except OSError:
+            pass
+        return False
+    return True
 
 
 def build(force=False, verbose=False):

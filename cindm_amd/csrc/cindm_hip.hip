@@ -29,10 +29,18 @@ extern "C" int cindm_abi_version(void) { return CINDM_ABI_VERSION; }
 #ifndef CINDM_SRC_HASH
 #define CINDM_SRC_HASH "unknown"
 #endif
-extern "C" const char* cindm_source_hash(void) { return CINDM_SRC_HASH; }
+// the hash behind a marker the build script finds in the file's bytes (cindm_amd/build.py: embedded_hash)
+extern "C" const char cindm_source_hash_marker[] = "CINDM_SRC_HASH=" CINDM_SRC_HASH;
+extern "C" const char* cindm_source_hash(void) { return cindm_source_hash_marker + 15; }
 extern "C" const char* cindm_last_error(void) { return g_err.c_str(); }
 
 static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// Pack generations are drawn from one process-wide counter: a handle created at a recycled heap address can never
+// reproduce the (address, generation) pair of a destroyed one, so a cached step graph that embeds the old handle's
+// weight pointers is never replayed for the new one.
+#include <atomic>
+static std::atomic<int> g_generation{0};
 
 // ============================================================================ TemporalUnet1D
 
@@ -79,7 +87,9 @@ struct cindm_unet1d {
     int launches = 0;
     struct WReg { size_t off[2]; unsigned bytes[2]; unsigned stride[2]; };      // byte offsets into blob
     std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
-    int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag
+    int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag, [2] prefetch sink, [8] second epoch slot
+    int epoch_slot = 0;                    // which epoch slot (0 / 8) the forward being emitted reads (ping-pong sample loop)
+    const int* ep() const { return epoch_dev + epoch_slot; }
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
     int generation = 0;                    // bumped by every (re)pack: captured graphs that embed this handle's pointers check it
     bool force_f32 = false;                // calibration forward overflowed on the split-fp16 kernels: fp32 MFMA kernels in use
@@ -171,9 +181,13 @@ static const OptDef kUnet1dOpts[] = {
     {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
+    {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
+    {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
+    {"dconv2", 1, "CINDM_DCONV2"},     // a whole deep-level ResidualTemporalBlock per launch (dconv2_kernel: in-launch all-gather between its convolutions)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
     {"fuse_update", 1, "CINDM_FUSE_UPDATE"},   // plain single-model steps: the reverse-step update inside ups_last_kernel (no update launch)
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
+    {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
     {"dbg", 0, "CINDM_DBG"}, {"dbg3", 0, "CINDM_DBG3"}, {"dbg4", 0, "CINDM_DBG4"},   // timing ablations (wrong results)
@@ -805,6 +819,7 @@ static void dconv_launch(Emitter& E, int L, int k0, int k1, bool res, const Dcon
     const int S = 48 / L;
     const dim3 grid((unsigned)d.NT, (unsigned)((d.Bp + S - 1) / S));
     const_cast<DconvArgs&>(d).dbg = E.h->O("dbg") >= 30 ? E.h->O("dbg") - 30 : 0;      // dbg 31..35: dconv phase ablations
+    const_cast<DconvArgs&>(d).stress = E.h->O("stress");
     E.prof_begin(4, flops);
     if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }
     for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
@@ -843,6 +858,80 @@ static bool dconv_applicable(cindm_unet1d* h, const std::string& p, const Ten& x
     return dconv_instantiated(L, k0, k1, !identity) && dconv_instantiated(L, cout / 128, 0, false);
 }
 
+// ---- deep levels: the whole ResidualTemporalBlock as ONE dconv2_kernel launch (kernels_dconv.h; option "dconv2") --------
+static bool dconv2_instantiated(int L, int k0, int k1, bool res, int kb) {
+    if (L == 6) return kb == 2 && ((k0 == 1 && k1 == 0 && res) || (k0 == 2 && k1 == 0 && !res) || (k0 == 2 && k1 == 2 && res));
+    if (L == 3) return (kb == 4 && ((k0 == 2 && k1 == 0 && res) || (k0 == 4 && k1 == 0 && !res) || (k0 == 4 && k1 == 4 && res))) ||
+                       (kb == 2 && k0 == 4 && k1 == 0 && res);
+    return false;
+}
+
+static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, const Ten* x1, int cout) {
+    cindm_unet1d* h = E.h;
+    const int Bp = (int)E.rows, L = x0.L, S = 48 / L, gw = cout / 8, NT = cout / 32;
+    const int tiles = (Bp + S - 1) / S;
+    const Packed& w0 = h->packed.at(p + ".blocks.0.block.0");
+    const Packed& w1 = h->packed.at(p + ".blocks.1.block.0");
+    const bool identity = !h->packed.count(p + ".residual_conv");
+    const int k0 = x0.C / 128, k1 = x1 ? x1->C / 128 : 0, kb = cout / 128;
+    Ten y0; y0.L = L; y0.C = cout; y0.ld = cout; E.planes(y0);
+    Ten out = E.ten(L, cout); E.planes(out);
+    unsigned long long* fl = E.xchg((size_t)tiles * NT);
+    unsigned long long* xa = gw == 64 ? E.xchg((size_t)tiles * NT * 32) : nullptr;
+    unsigned long long* xb = gw == 64 ? E.xchg((size_t)tiles * NT * 32) : nullptr;
+    E.need_epoch();
+    ++E.launches;
+    {   // L2 warm-up registration: both convolutions' weights, tiled by n-tile
+        cindm_unet1d::WReg r{};
+        const size_t t0 = w0.sz * 4 / (size_t)NT, t1 = w1.sz * 4 / (size_t)NT;
+        if (NT % 8 == 0) { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
+                           r.off[1] = w1.off * 4; r.bytes[1] = (unsigned)t1; r.stride[1] = (unsigned)t1; }
+        else { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)std::min(w0.sz * 4, (size_t)2 << 20); }
+        Pf pf; E.pf_step(pf, r);
+        if (E.dry) { E.tap(p, out); return out; }
+        Dconv2Args d;
+        std::memset(&d, 0, sizeof(d));
+        d.pf = pf;
+        auto src = [](DSrc& s, const Ten& t) { s.f32 = t.pl ? nullptr : t.p; s.planes = t.pl; s.pstride = t.pst; s.C = t.C; s.ld = t.ld; };
+        src(d.src[0], x0); if (x1) src(d.src[1], *x1);
+        d.Wa = reinterpret_cast<const uint4*>(E.W(w0)); d.bias_a = E.B(w0); d.ncha = w0.CinP / 128;
+        d.Wb = reinterpret_cast<const uint4*>(E.W(w1)); d.bias_b = E.B(w1);
+        if (!identity) {
+            const Packed& rc = h->packed.at(p + ".residual_conv#h3");
+            d.W2 = reinterpret_cast<const uint4*>(E.W(rc)); d.bias2 = E.B(rc);
+        } else { d.res = x0.p; d.ldres = x0.ld; }
+        d.Bp = Bp; d.N = cout; d.NT = NT; d.gw = gw;
+        d.gamma_a = E.V(p + ".blocks.0.block.2.weight"); d.beta_a = E.V(p + ".blocks.0.block.2.bias");
+        d.gamma_b = E.V(p + ".blocks.1.block.2.weight"); d.beta_b = E.V(p + ".blocks.1.block.2.bias");
+        d.tb = h->ttable + h->tb_off.at(p); d.tb_ld = h->tb_ld; d.t_ptr = E.t_ptr; d.t_imm = E.t_imm;
+        d.y0 = y0.pl; d.y0_pstride = y0.pst; d.flags = reinterpret_cast<unsigned*>(fl);
+        d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
+        d.xchg_a = xa; d.xchg_b = xb; d.epoch = h->ep(); d.err_flag = h->epoch_dev + 1;
+        d.stress = h->O("stress"); d.dbg = h->O("dbg") >= 30 ? h->O("dbg") - 30 : 0;
+        const dim3 grid((unsigned)NT, (unsigned)tiles);
+        const double cin = (double)x0.C + (x1 ? (double)x1->C : 0.0);
+        E.prof_begin(4, 2.0 * Bp * L * cout * cin * (5.0 + (identity ? 0.0 : 1.0)) + 2.0 * Bp * L * cout * (double)cout * 5.0);
+        if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.ncha + kb; }
+#define DC2(L_, K0_, K1_, R_, KB_) KLAUNCH(E, (dconv2_kernel<L_, K0_, K1_, R_, KB_>), grid, dim3(256), 0, d)
+        if (L == 6) {
+            if (k0 == 1) DC2(6, 1, 0, true, 2);
+            else if (k1 == 2) DC2(6, 2, 2, true, 2);
+            else DC2(6, 2, 0, false, 2);
+        } else {
+            if (k0 == 2) DC2(3, 2, 0, true, 4);
+            else if (k1 == 4) DC2(3, 4, 4, true, 4);
+            else if (kb == 2) DC2(3, 4, 0, true, 2);
+            else DC2(3, 4, 0, false, 4);
+        }
+#undef DC2
+        E.prof_end();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess && E.err == hipSuccess) E.err = e;
+    }
+    E.tap(p, out);
+    return out;
+}
+
 static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const Ten* x1, int cout) {
     cindm_unet1d* h = E.h;
     const int Bp = (int)E.rows, L = x0.L, S = 48 / L, gw = cout / 8, NT = cout / 32;
@@ -850,13 +939,16 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
     const Packed& w0 = h->packed.at(p + ".blocks.0.block.0");
     const Packed& w1 = h->packed.at(p + ".blocks.1.block.0");
     const bool identity = !h->packed.count(p + ".residual_conv");
+    if (h->O("dconv2") && dconv2_instantiated(L, x0.C / 128, x1 ? x1->C / 128 : 0, !identity, cout / 128) &&
+        w0.CinP / 128 == x0.C / 128 + (x1 ? x1->C / 128 : 0))
+        return emit_rtb_dconv2(E, p, x0, x1, cout);
     Ten y0; y0.L = L; y0.C = cout; y0.ld = cout; E.planes(y0);
     Ten out = E.ten(L, cout); E.planes(out);
     Ten r; if (!identity) r = E.ten(L, cout);
     auto pair_setup = [&](DconvArgs& d) {
         if (gw != 64) return;
         d.xchg = E.xchg((size_t)tiles * NT * 32);
-        d.epoch = h->epoch_dev; d.err_flag = h->epoch_dev + 1;
+        d.epoch = h->ep(); d.err_flag = h->epoch_dev + 1;
         E.need_epoch();
     };
     auto src = [](DSrc& s, const Ten& t) { s.f32 = t.pl ? nullptr : t.p; s.planes = t.pl; s.pstride = t.pst; s.C = t.C; s.ld = t.ld; };
@@ -1006,7 +1098,8 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
             s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
             s.L = L; s.S = S; s.slot = slot; s.Bp = Bp;
-            s.xchg = xg; s.epoch = h->epoch_dev; s.err_flag = h->epoch_dev + 1;
+            s.xchg = xg; s.epoch = h->ep(); s.err_flag = h->epoch_dev + 1;
+            s.stress = h->O("stress");
             const dim3 grid(4, (unsigned)groups);
             E.prof_begin(5, 2.0 * Bp * L * 1024.0 * C + (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));
             for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
@@ -1133,6 +1226,31 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
     const Packed& w = h->packed.at(p + ".conv");
     const int Lout = up ? x.L * 2 : x.L / 2;
     Ten out = E.ten(Lout, x.C);
+    if (h->O("dresample") && h->O("dconv") && w.h3 && x.C == 256 && x.ld == x.C && x.L == (up ? 3 : 6) && w.CinP == x.C && w.T == (up ? 4 : 3)) {
+        // the resampling convolutions between the deep levels on dresample_kernel (LDS-resident tile, planes for the next layer)
+        const int Bp = (int)E.rows, NT = x.C / 32, tiles = (Bp + 15) / 16;
+        E.planes(out);
+        ++E.launches;
+        Pf pf;
+        E.pf_tiled(pf, w, NT);
+        if (!E.dry) {
+            DresArgs d;
+            std::memset(&d, 0, sizeof(d));
+            d.pf = pf;
+            d.x = x.p; d.ld = x.ld; d.W = reinterpret_cast<const uint4*>(E.W(w)); d.bias = E.B(w); d.nch = w.CinP / 128;
+            d.Bp = Bp; d.N = x.C; d.NT = NT; d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
+            const dim3 grid((unsigned)NT, (unsigned)tiles);
+            E.prof_begin(up ? 3 : 2, 2.0 * Bp * Lout * x.C * (double)x.C * (up ? 2.0 : 3.0));
+            if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }
+            if (up) KLAUNCH(E, (dresample_kernel<true, 2>), grid, dim3(256), 0, d);
+            else KLAUNCH(E, (dresample_kernel<false, 2>), grid, dim3(256), 0, d);
+            E.prof_end();
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess && E.err == hipSuccess) E.err = e;
+        }
+        E.tap(p, out);
+        return out;
+    }
     GemmArgs a;
     E.base(a, w, (int)E.rows, x.L, Lout);
     a.pad = 1;
@@ -1484,7 +1602,7 @@ static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
     emit_forward(D, nullptr, nullptr);
     h->launches = D.launches;
     h->pf_table = regs;
-    ++h->generation;
+    h->generation = ++g_generation;
     h->finalized = true;
     return 0;
 }
@@ -1492,6 +1610,7 @@ static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
 extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t rows);
 extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int32_t* t_dev,
                                     float* eps, int64_t rows, void* ws, size_t ws_bytes, void* stream);
+static int unet1d_check_flag(cindm_unet1d* h, hipStream_t stream);
 
 // Repack + time tables (unet1d_finalize_pack), then -- on the split-fp16 kernels with "auto_range" -- ONE calibration
 // forward per timestep in {0, T/2, T-1} on a fixed unit-scale batch: an activation that leaves fp16's exponent range
@@ -1527,6 +1646,7 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     }
     (void)hipFree(dx); (void)hipFree(de); (void)hipFree(ws);
     h->seen_ws = nullptr; h->seen_rows = 0; h->taps.clear();
+    if (unet1d_check_flag(h, stream) != 0) return -1;      // a calibration forward whose exchange timed out proves nothing
     if (!finite) {
         h->force_f32 = true;
         if (unet1d_finalize_pack(h, stream_) != 0) return -1;
@@ -1557,18 +1677,27 @@ static int unet1d_prepare_ws(cindm_unet1d* h, void* ws, int64_t rows, hipStream_
     return 0;
 }
 
-// Error flag of the in-kernel pair exchange (a partner that never arrived): synchronises the stream.
-extern "C" int cindm_unet1d_status(cindm_unet1d* h, void* stream) {
-    REQUIRE(h, "null handle");
-    if (!h->epoch_dev) return 0;
+// Error flag of the in-kernel exchanges (dconv_kernel's GroupNorm pairs, attn1d_head_kernel's head tiles): a partner
+// that never arrived leaves garbage statistics behind, so every entry point that hands results to the caller after a
+// synchronisation reads the flag (the sample loops once per chain; cindm_unet1d_status for the asynchronous calls).
+// Synchronises the stream; clears the flag when it was set.
+static int unet1d_check_flag(cindm_unet1d* h, hipStream_t stream) {
+    if (!h || !h->epoch_dev) return 0;
     int v[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(v, h->epoch_dev, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(v, h->epoch_dev, sizeof(v), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
     if (v[1]) {
-        (void)hipMemsetAsync(h->epoch_dev + 1, 0, sizeof(int), (hipStream_t)stream);
-        return fail("dconv_kernel: a GroupNorm pair exchange timed out (results of that forward are invalid)");
+        HIPCHK(hipMemsetAsync(h->epoch_dev + 1, 0, sizeof(int), stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return fail("an in-kernel exchange between workgroups timed out (GroupNorm pair / attention head exchange): "
+                    "the results of that forward are invalid");
     }
     return 0;
+}
+
+extern "C" int cindm_unet1d_status(cindm_unet1d* h, void* stream) {
+    REQUIRE(h, "null handle");
+    return unet1d_check_flag(h, (hipStream_t)stream);
 }
 
 extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int32_t* t_dev,
@@ -1666,10 +1795,14 @@ struct cindm_ddpm1d {
     // the instantiated graph of the last captured step and everything it embeds (handles + their pack generation,
     // descriptor, tensor / workspace pointers, batch): a loop with the same key replays it without a new capture
     std::vector<unsigned char> gkey; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    int last_step_launches = 0, last_step_fused = 0;     // what the last emitted reverse step consisted of (cindm_ddpm1d_last_step_info)
+    hipGraph_t graph1 = nullptr; hipGraphExec_t gexec1 = nullptr;      // ping-pong loops: the one-step graph that ends an odd count
     void drop_graph() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
         if (graph) (void)hipGraphDestroy(graph);
-        gexec = nullptr; graph = nullptr; gkey.clear();
+        if (gexec1) (void)hipGraphExecDestroy(gexec1);
+        if (graph1) (void)hipGraphDestroy(graph1);
+        gexec = nullptr; graph = nullptr; gexec1 = nullptr; graph1 = nullptr; gkey.clear();
     }
 };
 
@@ -1781,6 +1914,14 @@ extern "C" int cindm_ddpm1d_launches_per_step(const cindm_ddpm1d*, const cindm_u
     return n;
 }
 
+// Kernel launches of the reverse step emitted last (gather + U-Net(s) + update + step counter, as launched -- not a
+// model of it), and whether its update ran inside ups_last_kernel.  The captured graph replays exactly that sequence.
+extern "C" int cindm_ddpm1d_last_step_info(const cindm_ddpm1d* h, int32_t* launches, int32_t* fused_update) {
+    REQUIRE(h && launches && fused_update, "null argument");
+    *launches = h->last_step_launches; *fused_update = h->last_step_fused;
+    return 0;
+}
+
 struct StepIO {
     const float* x; const float* cond; float* mean_out; float* x0_out; float* eps_out; float* x_out;
     const float* noise; int64_t noise_t_stride; uint64_t seed; int64_t sample_off; int add_noise;
@@ -1791,6 +1932,7 @@ struct StepIO {
     const cindm_design_desc* dz;                       // built-in design objective (guided loop) or null
     int relax; const float* recur_noise; int64_t recur_t_stride; uint32_t recur_tag;
     const float* iso; int iso_steps;
+    int pingpong, parity;   // plain sample loop: step state in two slots, advanced by the update itself (no step_counter launch)
 };
 
 // clears the exchange regions of the U-Net workspaces inside a step workspace (before a step is captured into a graph)
@@ -1834,6 +1976,17 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.sqrt_ac = tb + 3 * T; a.sqrt_1mac = tb + 4 * T; a.sqrt_recip = tb + 6 * T; a.sqrt_recipm1 = tb + 7 * T;
     a.logvar = tb + 9 * T; a.coef1 = tb + 10 * T; a.coef2 = tb + 11 * T;
     a.t_ptr = t_dev; a.t_imm = t;
+    const int q = io.pingpong ? (io.parity & 1) : 0;
+    pair->epoch_slot = 8 * q;
+    if (uncond) uncond->epoch_slot = 8 * q;
+    if (io.pingpong) {
+        // this step reads t at t_dev[4 q] and its epochs at epoch_dev[8 q]; its update writes the other slots for the next step
+        t_dev = h->t_dev + 4 * q;
+        a.t_ptr = t_dev;
+        a.t_next = h->t_dev + 4 * (1 - q);
+        a.ep_cur0 = pair->epoch_dev + 8 * q; a.ep_next0 = pair->epoch_dev + 8 * (1 - q);
+        if (c->mode == CINDM_COMPOSE_MULTIBODY && uncond) { a.ep_cur1 = uncond->epoch_dev + 8 * q; a.ep_next1 = uncond->epoch_dev + 8 * (1 - q); }
+    }
     a.mean_out = io.mean_out; a.x0_out = io.x0_out; a.eps_out = io.eps_out; a.x_out = io.x_out;
     a.noise = io.noise; a.noise_t_stride = io.noise_t_stride; a.seed = io.seed; a.sample_off = io.sample_off; a.add_noise = io.add_noise;
     a.dyn = io.dyn;
@@ -1860,8 +2013,12 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     // update is element-wise and in place): ups_last_kernel runs the update on the rows it has just predicted, so the step
     // has no compose_update_kernel launch.  Everything else (composition over windows / pairs, a second U-Net, guidance,
     // DDIM, callers that want mean / x0 / eps back) keeps the separate kernel.
-    const bool can_fuse = c->mode == CINDM_COMPOSE_PLAIN && s.direct && !s.single_rows && !guided && !io.ddim_tab && io.x_out == io.x &&
-                          !io.mean_out && !io.x0_out && !io.eps_out && !io.inp_cond && pair->O("fuse_update") && (a.F & 3) == 0;
+    // sample() reaches this path as COMPOSE_MEAN_OUTSIDE with one window and one pair (p_sample_loop -> outside=True): for
+    // s.direct every mode 0..4 aggregates exactly one prediction with weight 1 -- (0 + e) / 1 -- so the element-wise result is
+    // the plain one (the bitwise identities outside(mean) == inside == plain are GPU tests) and all of them fuse.
+    const bool can_fuse = c->mode >= CINDM_COMPOSE_PLAIN && c->mode <= 4 && s.direct && !s.single_rows && !guided && !io.ddim_tab &&
+                          io.x_out == io.x && !io.mean_out && !io.x0_out && !io.eps_out && !io.inp_cond && pair->O("fuse_update") &&
+                          (a.F & 3) == 0;
     pair->fused_done = false;
     pair->fuse_upd = can_fuse ? &a : nullptr;
     const int frc = cindm_unet1d_forward(pair, unet_in, t, t_dev, (float*)(w + s.off_pair_eps), s.pair_rows, w + s.off_ws_pair,
@@ -1872,8 +2029,16 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
         cindm_unet1d_forward(uncond, a.single_in, t, t_dev, (float*)(w + s.off_single_eps), s.single_rows,
                              w + s.off_ws_single, ws_bytes - s.off_ws_single, stream) != 0) return -1;
     const int64_t ne = B * (int64_t)Ltot * a.F;
+    h->last_step_launches = (s.direct ? 0 : 1) + pair->launches + (s.single_rows ? uncond->launches : 0) + (pair->fused_done ? 0 : 1) +
+                            ((io.dec_t && !io.pingpong) ? 1 : 0);
+    h->last_step_fused = pair->fused_done ? 1 : 0;
     if (!pair->fused_done) hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);
-    if (io.dec_t) {
+    pair->epoch_slot = 0;
+    if (uncond) uncond->epoch_slot = 0;
+    if (io.pingpong) {                       // the update has advanced t and the epochs for the next step
+        pair->epoch_prebumped = true;
+        if (s.single_rows && uncond) uncond->epoch_prebumped = true;
+    } else if (io.dec_t) {
         // the counter kernel also advances the U-Nets' exchange epochs for the step that follows
         hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(64), 0, stream, h->t_dev, io.ddim_tab ? io.ddim_tnext : (const int*)nullptr,
                            pair->epoch_dev, (s.single_rows && uncond) ? uncond->epoch_dev : (int*)nullptr);
@@ -1931,31 +2096,57 @@ static void start_loop(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond
 // run one captured step n times (graph) or launch it n times (stream); shared tail of the sample loops.  The
 // instantiated graph is kept in the handle and reused while `key` (everything the captured launches embed) is unchanged.
 template <typename StepFn>
-static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, hipStream_t stream, int nsteps, int use_graph, StepFn step) {
-    if (!use_graph) {
-        for (int i = 0; i < nsteps; ++i) if (step() != 0) return -1;
-        HIPCHK(hipGetLastError());
+static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, hipStream_t stream, int nsteps, int use_graph, StepFn step,
+                        cindm_unet1d* pair, cindm_unet1d* uncond, bool pingpong = false) {
+    // a chain is only handed back after the exchange flags of its U-Nets have been read: a timed-out partner (not
+    // co-resident under foreign load) would otherwise return designs computed from garbage statistics
+    auto finish = [&]() -> int {
+        if (pingpong) {          // the slot an eager forward reads may hold an older epoch than the loop's last step used: bump next time
+            pair->epoch_prebumped = false;
+            if (uncond) uncond->epoch_prebumped = false;
+        }
+        if (unet1d_check_flag(pair, stream) != 0) return -1;
+        if (uncond && unet1d_check_flag(uncond, stream) != 0) return -1;
         return 0;
+    };
+    if (!use_graph) {
+        for (int i = 0; i < nsteps; ++i) if (step(i & 1) != 0) return -1;
+        HIPCHK(hipGetLastError());
+        return finish();
     }
+    // ping-pong loops (the step state alternates between two slots, the step's own update advances it): the graph holds TWO
+    // steps (parity 0 then 1); an odd count ends with a one-step graph of parity 0 -- after an even number of steps the
+    // current state is in slot 0 again
+    const int per = pingpong ? 2 : 1;
+    auto capture = [&](int nst, hipGraph_t* graph, hipGraphExec_t* exec) -> int {
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = 0;
+        for (int q = 0; q < nst && rc == 0; ++q) rc = step(q);
+        hipError_t ce = hipStreamEndCapture(stream, graph);
+        if (rc != 0) { if (*graph) (void)hipGraphDestroy(*graph); *graph = nullptr; return -1; }
+        if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { (void)hipGraphDestroy(*graph); *graph = nullptr; return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        return 0;
+    };
     if (!(h->gexec && h->gkey == key)) {
         h->drop_graph();
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        int rc = step();
-        hipError_t ce = hipStreamEndCapture(stream, &graph);
-        if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
-        if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-        hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        if (capture(per, &graph, &exec) != 0) return -1;
         h->graph = graph; h->gexec = exec; h->gkey = key;
     }
+    if (pingpong && (nsteps & 1) && !h->gexec1) {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        if (capture(1, &graph, &exec) != 0) return -1;
+        h->graph1 = graph; h->gexec1 = exec;
+    }
     hipError_t le = hipSuccess;
-    for (int i = 0; i < nsteps && le == hipSuccess; ++i) le = hipGraphLaunch(h->gexec, stream);
+    for (int i = 0; i < nsteps / per && le == hipSuccess; ++i) le = hipGraphLaunch(h->gexec, stream);
+    if (pingpong && (nsteps & 1) && le == hipSuccess) le = hipGraphLaunch(h->gexec1, stream);
     hipError_t se = hipStreamSynchronize(stream);
     if (le != hipSuccess) { h->drop_graph(); return fail(std::string("hipGraphLaunch: ") + hipGetErrorString(le)); }
     if (se != hipSuccess) { h->drop_graph(); return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(se)); }
-    return 0;
+    return finish();
 }
 
 static void key_common(KeyBuilder& K, int kind, const cindm_unet1d* pair, const cindm_unet1d* uncond, const cindm_compose_desc* c, const StepIO& io,
@@ -1993,8 +2184,13 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
     KeyBuilder K;
     key_common(K, 0, pair, uncond, c, io, B, ws, ws_bytes);
+    // the step state lives in two slots and the step's own update advances it (no step_counter_kernel launch)
+    const bool pp = pair->O("pingpong") != 0;
+    K(pp);
+    io.pingpong = pp ? 1 : 0;
     return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph,
-                        [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
+                        [&](int q) { StepIO it = io; it.parity = q; return run_step(h, pair, uncond, c, it, 0, h->t_dev, B, ws, ws_bytes, stream); },
+                        pair, c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr, pp);
 }
 
 extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -2040,7 +2236,8 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     KeyBuilder K;
     key_common(K, 1, pair, uncond, c, io, B, ws, ws_bytes);
     return replay_steps(h, K.k, stream, n_steps, use_graph,
-                        [&]() { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); });
+                        [&](int) { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); },
+                        pair, c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr);
 }
 
 extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -2077,7 +2274,7 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
     start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
     // one reverse step (:1286-1370): R x [p_mean_variance, mean - grad, overwrite, relaxation]; the last iteration's
     // relaxation is never used by the reference, its pred + sigma z is the step's result
-    auto step = [&]() -> int {
+    auto step = [&](int) -> int {
         const int iters = R > 0 ? R : 1;
         for (int r = 0; r < iters; ++r) {
             StepIO it = io;
@@ -2092,7 +2289,7 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
     KeyBuilder K;
     key_common(K, 2, pair, uncond, c, io, B, ws, ws_bytes);
     K(*dz)(recur_noise_steps)(R);
-    return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph, step);
+    return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph, step, pair, c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr);
 }
 
 extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed, int64_t sample_offset,

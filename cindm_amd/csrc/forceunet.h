@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restric
     __shared__ float red[256];
     __shared__ float tot[8];
     const int img = blockIdx.x, tid = threadIdx.x, f4 = C >> 2, tpg = f4 >> 3, ppp = 256 / f4;      // pixels per pass
-    if (amax_reset && img == 0 && tid == 0) *amax_reset = 0u;   // the backward pass of this block accumulates max |dx| here
+    if (amax_reset && tid == 0) amax_reset[img] = 0u;           // the backward pass of this block accumulates the image's max |dx| here
     const int c4 = tid % f4, p0 = tid / f4;
     const float4* base = reinterpret_cast<const float4*>(x + (size_t)img * HW * C) + c4;
     const float n = (float)HW * (float)(C / 8);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restric
 __global__ __launch_bounds__(64) void fu_gn_merge_kernel(const float* __restrict__ part, float* __restrict__ stats, int P, float cnt,
                                                          unsigned* __restrict__ amax_reset) {
     const int img = blockIdx.x, lane = threadIdx.x;
-    if (amax_reset && img == 0 && lane == 0) *amax_reset = 0u;
+    if (amax_reset && lane == 0) amax_reset[img] = 0u;
     float m, r;
     merge_stats8(part + (size_t)img * 8 * P * 2, P, cnt, lane, m, r);
     if ((lane & 7) == 0) { stats[((size_t)img * 8 + (lane >> 3)) * 2] = m; stats[((size_t)img * 8 + (lane >> 3)) * 2 + 1] = r; }
@@ -321,8 +321,10 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
     if (beta != 0.f) { const float4 o = reinterpret_cast<float4*>(dx)[i]; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
     reinterpret_cast<float4*>(dx)[i] = v;
     if (amax) {
-        // max |dx| over the tensor, as a bit pattern (monotone for non-negative floats; a maximum does not depend on the
-        // order: the result repeats bit for bit).  One atomic per workgroup, and only while it still raises the value.
+        // max |dx| over THIS IMAGE, as a bit pattern (monotone for non-negative floats; a maximum does not depend on the
+        // order: the result repeats bit for bit; per image, so that an image's gradient does not depend on what else is in
+        // the batch).  A workgroup's 1024 elements lie inside one image.  One atomic per workgroup, and only while it still
+        // raises the value.
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (!(m <= 3.0e38f)) m = 3.0e38f;                                 // inf / nan: saturate (the products are garbage either way)
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -331,8 +333,9 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
-            if (mb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_fetch_max(amax, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* am = amax + (int)(((int64_t)blockIdx.x * 256) / ((int64_t)HW * f4));
+            if (mb > __hip_atomic_load(am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_fetch_max(am, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -723,11 +726,13 @@ __global__ __launch_bounds__(64) void fu_attn_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// max |x| of a tensor as a bit pattern (for conv2d_ws_kernel<.., SRC2_SCALED> when the gradient's producer did not leave
-// one): grid-stride float4 pass, one atomic maximum per workgroup; *amax is zeroed by the host before the launch
-__global__ __launch_bounds__(256) void fu_absmax_kernel(const float* __restrict__ x, int64_t total4, unsigned* __restrict__ amax) {
+// max |x| of every image of a tensor as bit patterns (for conv2d_ws_kernel<.., SRC2_SCALED> when the gradient's producer did
+// not leave them): grid (blocks per image, images), grid-stride float4 pass over the image, one atomic maximum per
+// workgroup; amax[images] is zeroed by the host before the launch.  per4 = float4 elements per image.
+__global__ __launch_bounds__(256) void fu_absmax_kernel(const float* __restrict__ x, int64_t per4, unsigned* __restrict__ amax) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    x += (size_t)blockIdx.y * per4 * 4; amax += blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
@@ -763,11 +768,13 @@ __global__ __launch_bounds__(256) void fu_head_kernel(const float* __restrict__ 
     if (tid == 0) { out[img * 2] = red[0][0] + b[0]; out[img * 2 + 1] = red[1][0] + b[1]; }
 }
 // seed of the backward pass: force = lambda * |out0| + out1  ->  d force / d x[img][p][c] = (lambda * sign(out0) * W[0][c] + W[1][c]) / HW
+// dout != null: a caller-given upstream gradient [img][2] instead (vector-Jacobian product: torch.autograd through the model)
 __global__ void fu_head_bwd_kernel(const float* __restrict__ out, const float* __restrict__ W, float lambda_force, float* __restrict__ dx,
-                                   int HW, int C, int64_t total) {
+                                   int HW, int C, int64_t total, const float* __restrict__ dout) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % C), img = (int)(i / ((int64_t)HW * C));
+    if (dout) { dx[i] = (dout[img * 2] * W[c] + dout[img * 2 + 1] * W[C + c]) / (float)HW; return; }
     const float o0 = out[img * 2];
     const float sg = o0 > 0.f ? 1.f : (o0 < 0.f ? -1.f : 0.f);
     dx[i] = (lambda_force * sg * W[c] + W[C + c]) / (float)HW;
@@ -788,22 +795,32 @@ __global__ void fu_bsum_kernel(const float* __restrict__ x, float* __restrict__ 
     bsum[i] = fminf(fmaxf(s, 0.f), 1.f);
 }
 // inp[img][pixel][4] = (unnormalised pressure of frame f, bsum)
+// bsum == null (force_fn's sum_boundary = False branch, :122-130): the NORMALISED pressure and the image's own boundary channels
 __global__ void fu_build_input_kernel(const float* __restrict__ x, const float* __restrict__ bsum, float* __restrict__ inp, int f, int nb, int HW,
-                                      int CP, float p_min, float p_max, int64_t total) {
+                                      int CP, int Cs, float p_min, float p_max, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][pixel]
     if (i >= total) return;
     const int img = (int)(i / HW), p = (int)(i % HW), b = img / nb;
+    if (!bsum) {
+        const float* xb = x + i * CP + Cs - 3;
+        *reinterpret_cast<float4*>(inp + i * 4) = make_float4(x[i * CP + 2 + 3 * f], xb[0], xb[1], xb[2]);
+        return;
+    }
     const float pr = (0.5f * x[i * CP + 2 + 3 * f] + 0.5f) * (p_max - p_min) + p_min;
     const float* bs = bsum + ((size_t)b * HW + p) * 3;
     *reinterpret_cast<float4*>(inp + i * 4) = make_float4(pr, bs[0], bs[1], bs[2]);
 }
 // gradient of one frame's network input: pressure channel -> gx, boundary channels accumulate into gb[img][pixel][3]
+// pscale: d(network pressure input)/d(state) -- 0.5 (p_max - p_min) behind unnormalize_state, 1 for the normalised pressure;
+// gscale: 1, or num_boundaries in the sum_boundary = False branch, whose summed force is expanded over the boundaries before
+// grad(.., grad_outputs = ones) (:128-130): every image's contribution is counted once per boundary copy
 __global__ void fu_scatter_input_grad_kernel(const float* __restrict__ dinp, float* __restrict__ gx, float* __restrict__ gb, int f, int first,
-                                             int CP, float p_min, float p_max, int64_t total) {
+                                             int CP, float pscale, float gscale, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][pixel]
     if (i >= total) return;
-    const float4 d = *reinterpret_cast<const float4*>(dinp + i * 4);
-    gx[i * CP + 2 + 3 * f] = d.x * 0.5f * (p_max - p_min);
+    float4 d = *reinterpret_cast<const float4*>(dinp + i * 4);
+    if (gscale != 1.0f) { d.x *= gscale; d.y *= gscale; d.z *= gscale; d.w *= gscale; }
+    gx[i * CP + 2 + 3 * f] = d.x * pscale;
     float* g = gb + i * 3;
     if (first) { g[0] = d.y; g[1] = d.z; g[2] = d.w; } else { g[0] += d.y; g[1] += d.z; g[2] += d.w; }
 }
@@ -819,8 +836,9 @@ __global__ void fu_overlap_dm_kernel(const float* __restrict__ x, float* __restr
     dm[i] = s / (float)(F * F);
 }
 // final assembly of the boundary channels: gx[.., Cs-3+c] = clamp'(sum) * sum_k' gb[b, k'] + lambda_overlap * overlap gradient (c = 0)
+// sum_boundary = 0: every image was fed its own boundary channels, so their force gradient is gb itself
 __global__ void fu_finish_grad_kernel(const float* __restrict__ x, const float* __restrict__ gb, const float* __restrict__ dm, float* __restrict__ gx,
-                                      int nb, int Hs, int F, int CP, int Cs, float lambda_overlap, int64_t total) {
+                                      int nb, int Hs, int F, int CP, int Cs, float lambda_overlap, int sum_boundary, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // [img][pixel]
     if (i >= total) return;
     const int HW = Hs * Hs, img = (int)(i / HW), p = (int)(i % HW), b = img / nb, k = img - b * nb;
@@ -831,6 +849,7 @@ __global__ void fu_finish_grad_kernel(const float* __restrict__ x, const float* 
             g += gb[((size_t)(b * nb + k2) * HW + p) * 3 + c];
         }
         float v = (s >= 0.f && s <= 1.f) ? g : 0.f;                      // torch.clamp passes the gradient on [min, max]
+        if (!sum_boundary) v = gb[i * 3 + c];
         if (c == 0) {
             const float m = x[i * CP + Cs - 3];
             if (m >= 0.f && m <= 1.f) {

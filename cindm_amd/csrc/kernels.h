@@ -75,6 +75,19 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
 // x * stride[k] (tiled weights: the n-tiles an XCD will own; stride 0: weights every workgroup reads).  Block b runs on
 // XCD b % 8 (observed dispatch rule; a wrong guess only loses the benefit).  The loaded dwords are parked in registers
 // and "used" at the very end of the kernel, so the loads cost no wait.
+// Stress mode of the kernels that hand data between waves / workgroups inside a launch (option "stress" = seed > 0): a
+// pseudo-random pause, keyed by (seed, workgroup, wave, site), in front of every producer -> consumer hand-over.  A
+// protocol that is correct gives bit-identical results under any such skew; one that only works at the natural timing
+// does not.  Zero cost when off (one scalar compare).
+__device__ __forceinline__ void stress_delay(int stress, unsigned site) {
+    if (stress <= 0) return;
+    const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)threadIdx.x >> 6);
+    unsigned h = (unsigned)stress * 0x9E3779B9u + ((blockIdx.y * gridDim.x + blockIdx.x) * 16u + wv) * 0x85EBCA6Bu + site * 0xC2B2AE35u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    const int n = (int)(h & 15u);                            // 0 .. 15 x 512 cycles: up to ~4 us at 2 GHz
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+}
+
 struct Pf { const char* base[2]; unsigned bytes[2]; unsigned stride[2]; int* sink; };
 struct PfRegs { unsigned v[2][2]; };
 __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
@@ -2174,7 +2187,18 @@ struct ComposeArgs {
     int64_t recur_t_stride; uint32_t recur_tag;
     const float* iso; int iso_steps;     // initial_state_overwrite [B, iso_steps, F] (:1352-1361) or null
     const float* betas; const float* ac; const float* acp;     // schedule tables for eta_t and the relaxation
+    // Ping-pong step state of the plain sample loop: the kernels of this step read t / the exchange epochs from one slot; ONE
+    // thread of the step's last kernel (this update) writes the OTHER slot for the step that follows -- nothing in this step
+    // reads that slot, so no launch of its own is needed to advance the counter (step_counter_kernel is for the other loops).
+    int* t_next;                                         // null: off
+    const int* ep_cur0; int* ep_next0; const int* ep_cur1; int* ep_next1;     // exchange epochs of the U-Nets the next step runs (or null)
 };
+__device__ __forceinline__ void compose_advance(const ComposeArgs& a, int t) {
+    if (!a.t_next) return;
+    a.t_next[0] = t - 1;
+    if (a.ep_next0) a.ep_next0[0] = a.ep_cur0[0] + 1;
+    if (a.ep_next1) a.ep_next1[0] = a.ep_cur1[0] + 1;
+}
 // the update of state element i = (b * Ltot + row) * F + f (compose_update_kernel's body)
 __device__ void compose_update_element(const ComposeArgs& a, int64_t i);
 __device__ __forceinline__ void counter_normal4(uint64_t seed, uint64_t sample, uint32_t step, uint32_t elem4, float (&z)[4]);
@@ -2480,6 +2504,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
                                     plain_step_value(u, tu, xq[nt].z, o.z, zq[nt].z), plain_step_value(u, tu, xq[nt].w, o.w, zq[nt].w));
             }
         }
+        if (a.fuse_upd && blockIdx.x == 0 && lane == 0) compose_advance(u, tu);
     }
     l2_prefetch_done(a.pf, pfr);
 }
@@ -2826,6 +2851,7 @@ __device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
     const int sidx = a.ddim_tab ? *a.step_idx : 0;
     const uint64_t dseed = a.dyn ? (uint64_t)a.dyn[0] : a.seed;
     const int64_t dsoff = a.dyn ? (int64_t)a.dyn[1] : a.sample_off;
+    if (i == 0) compose_advance(a, t);
     if (i < a.B * (int64_t)a.Ltot * a.F) {
     const int f = (int)(i % a.F);
     const int lx = (int)((i / a.F) % a.Ltot);
@@ -3009,8 +3035,8 @@ __global__ void step_counter_kernel(int* t_dev, const int* ddim_tnext, int* e0, 
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (ddim_tnext) { const int sidx = t_dev[2]; t_dev[0] = max(ddim_tnext[sidx], 0); t_dev[2] = sidx + 1; }
         else t_dev[0] -= 1;
-        if (e0) e0[0] += 1;
-        if (e1) e1[0] += 1;
+        if (e0) e0[0] = max(e0[0], e0[8]) + 1;      // (slot 8: the ping-pong loop's other epoch slot; tags must never repeat)
+        if (e1) e1[0] = max(e1[0], e1[8]) + 1;
     }
 }
 

@@ -44,6 +44,7 @@ struct Conv2dArgs {
     float* ln_out;                      // LayerNorm partials per pixel and 32-column block: [rows][Npad/32][2]
     const int* t_ptr; int t_imm;
     int dbg;                            // timing ablations (CINDM_DBG2; results are wrong when set)
+    int stress;                         // conv2d_ws_kernel: > 0 = pseudo-random pauses before the hand-overs (stress_delay, kernels.h)
     // conv1x1_wide_kernel only: rows = pixels (2-D) or sequence positions (the 1-D path's qkv projections); blockIdx.y
     // selects a group of tiles_per_group output tiles (0 = all tiles in one workgroup)
     int64_t rows_total; int tiles_per_group;
@@ -2050,13 +2051,36 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
         const float sigma = (a.add_noise && t > 0) ? expf(0.5f * a.logvar[t]) : 0.f;
         const bool noisy = a.add_noise && t > 0;
         // shared prediction of the state channels: mean (or sum) over the boundary copies
-        float es[4] = {0.f, 0.f, 0.f, 0.f};
+        // use_avg bit 1 = share_noise False (p_mean_variance :757-773): the prediction is NOT shared; the clamped x_start of the
+        // state channels is (x0s), and then the posterior mean computed from it (ms)
+        const bool late = (a.use_avg & 2) != 0, avg = (a.use_avg & 1) != 0;
+        float es[4] = {0.f, 0.f, 0.f, 0.f}, x0s[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f};
         if (c0 < Cs) {
+            const float inv = (float)a.nb;
             for (int k = 0; k < a.nb; ++k) {
-                const float4 e = *reinterpret_cast<const float4*>(a.eps + (((size_t)(b * a.nb + k) * a.HW) + pix) * a.CP + c0);
-                es[0] += e.x; es[1] += e.y; es[2] += e.z; es[3] += e.w;
+                const size_t o = (((size_t)(b * a.nb + k) * a.HW) + pix) * a.CP + c0;
+                const float4 e = *reinterpret_cast<const float4*>(a.eps + o);
+                if (!late) { es[0] += e.x; es[1] += e.y; es[2] += e.z; es[3] += e.w; continue; }
+                const float4 x4 = *reinterpret_cast<const float4*>(a.x + o);
+                const float ev[4] = {e.x, e.y, e.z, e.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x0 = __fsub_rn(__fmul_rn(ra, xv[j]), __fmul_rn(rb, ev[j]));
+                    if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                    x0s[j] += x0;
+                }
             }
-            if (a.use_avg) { const float inv = (float)a.nb; es[0] /= inv; es[1] /= inv; es[2] /= inv; es[3] /= inv; }
+            if (!late && avg) { es[0] /= inv; es[1] /= inv; es[2] /= inv; es[3] /= inv; }
+            if (late) {
+                if (avg) { x0s[0] /= inv; x0s[1] /= inv; x0s[2] /= inv; x0s[3] /= inv; }
+                for (int k = 0; k < a.nb; ++k) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(a.x + (((size_t)(b * a.nb + k) * a.HW) + pix) * a.CP + c0);
+                    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ms[j] += __fadd_rn(__fmul_rn(k1, x0s[j]), __fmul_rn(k2, xv[j]));
+                }
+                if (avg) { ms[0] /= inv; ms[1] /= inv; ms[2] /= inv; ms[3] /= inv; }
+            }
         }
         float zs[4] = {0.f, 0.f, 0.f, 0.f};
         if (noisy && c0 < Cs) {
@@ -2089,10 +2113,11 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + j;
-                const float e = (c < Cs) ? es[j] : ev[j];
+                const float e = (c < Cs && !late) ? es[j] : ev[j];
                 float x0 = __fsub_rn(__fmul_rn(ra, xv[j]), __fmul_rn(rb, e));
                 if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                const float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[j]));
+                float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[j]));
+                if (late && c < Cs) { x0 = x0s[j]; mean = ms[j]; }
                 const float z = (c < Cs) ? zs[j] : zb[j];
                 const bool real = c < a.C;
                 r0[j] = real ? x0 : 0.f; rm[j] = real ? mean : 0.f;

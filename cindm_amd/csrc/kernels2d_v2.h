@@ -132,6 +132,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             }
         };
         { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
+        stress_delay(a.stress, 100u);
         __syncthreads();                                     // S0: item 0 is staged
         // tile -> n-tile -> chunk: the same item order as decode(); nested so that the accumulators are defined by the
         // first chunk's tap 0 (zero C operand), updated by the other chunks and consumed by the reduce below
@@ -150,12 +151,14 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                             for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                     }
                     ++k;
+                    stress_delay(a.stress, 101u + 8u * (unsigned)k);
                     __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
                 }
                 for (int ch = 1; ch < nch; ++ch) {
                     const int nt2 = ch + 1 < nch ? nt : nt_after, ch2 = ch + 1 < nch ? ch + 1 : 0;
                     if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
                     ++k;
+                    stress_delay(a.stress, 102u + 8u * (unsigned)k);
                     __syncthreads();                         // S1
                 }
                 // the accumulators' 4 row registers are 4 consecutive pixels of one channel: one ds_write_b128 per (pixel
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                             *reinterpret_cast<float4*>(trow + nb * 16 * V2LDT + mb * 16) = v;
                         }
                 }
+                stress_delay(a.stress, 103u + 8u * (unsigned)k);
                 __syncthreads();                             // S2
                 if (kg == 0) {
                     float bias[2];
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                             *tp = v;
                         }
                 }
+                stress_delay(a.stress, 104u + 8u * (unsigned)k);
                 __syncthreads();                             // S3: the finished tile is in LDS
             }
         return;
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const float* const sp1 = a.src[1].p;
     float* const outp = a.out;
     float* const stats_out = a.stats_out;
-    const int so_gw = a.so_gw, dbg = a.dbg;
+    const int so_gw = a.so_gw, dbg = a.dbg, stress = a.stress;
     const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
     const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
     const float* const gn_stats = a.src[0].stats;
@@ -241,17 +246,19 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const unsigned src_bytes0 = (unsigned)a.NI * (PAIR ? 2u : 1u) * (unsigned)HWi * (unsigned)ld0 * 4u;
     const unsigned src_bytes1 = (unsigned)a.NI * (PAIR ? 2u : 1u) * (unsigned)HWi * (unsigned)ld1 * 4u;
     // MODE SRC2_SCALED (ForceUnet's input-gradient pass): the source is a gradient tensor whose magnitudes sit far below
-    // fp16's normal range; src[0].stats points at ONE word, the bit pattern of max |source| (atomicMax by the producer).
-    // The source is staged times the power of two that puts that maximum in [2^13, 2^14) and the tile is written times
-    // its inverse: both exact.  a.res (may alias a.out: every element is read by the thread that writes it) is added.
-    float in_s = 1.0f, out_s = 1.0f;
-    if constexpr (MODE == SRC2_SCALED) {
-        const unsigned mb = *reinterpret_cast<const unsigned*>(a.src[0].stats);
+    // fp16's normal range; src[0].stats points at one word PER IMAGE, the bit pattern of max |source| over that image
+    // (atomicMax by the producer).  An image's rows are staged times the power of two that puts ITS maximum in [2^13, 2^14)
+    // and its tile is written times the inverse: both exact -- and a function of that image alone, so its gradient does
+    // not depend on the rest of the batch (PAIR kind: the two images of a tile share the larger of their two maxima).
+    // a.res (may alias a.out: every element is read by the thread that writes it) is added.
+    const unsigned* const amax = reinterpret_cast<const unsigned*>(a.src[0].stats);
+    auto scale_exp = [&](int img) -> int {                      // biased exponent of the staging scale of tile image `img`
+        unsigned mb = PAIR ? max(amax[2 * img], amax[2 * img + 1]) : amax[img];
+        mb = __builtin_amdgcn_readfirstlane(mb);
         const int e = (int)(mb >> 23);                          // biased exponent of the maximum (the sign bit is clear)
-        const int se = e == 0 ? 127 : min(max(267 - e, 1), 253);
-        in_s = __builtin_bit_cast(float, (unsigned)se << 23);
-        out_s = __builtin_bit_cast(float, (unsigned)(254 - se) << 23);
-    }
+        return e == 0 ? 127 : min(max(267 - e, 1), 253);
+    };
+    float in_s = 1.0f;                                          // of the item loaded last (set by load_item, used by store_item)
     const float* const resp = a.res;
     const int ldres = a.ldres;
     float4 racc[8];
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         cok = cl < Cc;
         okmask = m_valid & ~((ty0 == 0 ? m_top : 0u) | (ty0 + V2Y == Hout ? m_bot : 0u) | (PAIR || tx0 == 0 ? m_left : 0u) |
                              (PAIR || tx0 + V2X == Wout ? m_right : 0u));
+        if constexpr (MODE == SRC2_SCALED) in_s = __builtin_bit_cast(float, (unsigned)scale_exp(img) << 23);
         const int origin = (KIND == CONV_UP2) ? img * HWi + (ty0 >> 1) * Win + (tx0 >> 1) : (PAIR ? 2 * img : img) * HWi + ty0 * Win + tx0;
         const int t4 = (origin * ld + clc) * 4;               // byte offset of the tile origin's float4 of this thread
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, first ? src_bytes0 : src_bytes1, 0x00020000);
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             v[4 * jj + 3] = make_float4(f[jj][0].w, f[jj][1].w, f[jj][2].w, f[jj][3].w);
         }
         if constexpr (MODE == SRC2_SCALED) {
+            const float out_s = __builtin_bit_cast(float, (unsigned)(254 - scale_exp(img)) << 23);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[j].x *= out_s; v[j].y *= out_s; v[j].z *= out_s; v[j].w *= out_s; }
             if (resp) {
@@ -450,9 +459,11 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     store_item(0);
     bool staged_skip = false;                                // the item waiting for its staging needs none
     if (nitems > 1) { decode(1, mtn, ntn, chn); load_item(mtn, chn); }
+    stress_delay(stress, 200u);
     __syncthreads();                                         // S0
     int pmt = -1, pnt = 0;                                   // finished tile waiting in LDS
     for (int k = 0; k < nitems; ++k) {
+        if (stress > 0) stress_delay(stress, 204u + 8u * (unsigned)k);
         if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1); }
         if (pmt >= 0) load_acc(pmt, pnt);
         if (k + 2 < nitems && dbg != 5) {
@@ -460,10 +471,13 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             staged_skip = (mtn == mt && chn == ch);                // its buffer, (k + 2) & 1, holds item k's planes: these
             if (!staged_skip && dbg != 2) load_item(mtn, chn);
         }
+        if (stress > 0) stress_delay(stress, 201u + 8u * (unsigned)k);
         if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt); pmt = -1; }
+        if (stress > 0) stress_delay(stress, 202u + 8u * (unsigned)k);
         __syncthreads();                                     // S1
         if (ch == nch - 1) {
             __syncthreads();                                 // S2
+            if (stress > 0) stress_delay(stress, 203u + 8u * (unsigned)k);
             __syncthreads();                                 // S3
             pmt = mt; pnt = nt;
         }

@@ -22,6 +22,7 @@
 // Weights: pack_weight_h3 / pack_weight_h3_res layouts of conv_gemm_h3_kernel (shared).
 #pragma once
 #include "kernels.h"
+#include <type_traits>
 
 namespace cindm {
 
@@ -46,11 +47,14 @@ struct DconvArgs {
     const uint4* W2; const float* bias2; float* out2; int ldo2;     // riding 1x1 residual_conv: out2 = W2 . x + bias2
     unsigned long long* xchg; const int* epoch; int* err_flag;     // gw == 64: pair exchange of GroupNorm halves
     Pf pf;                                      // L2 warm-up for the next launch (kernels.h)
+    int stress;                                 // > 0: pseudo-random pauses before the hand-overs (stress_delay, kernels.h)
     int dbg;                                    // timing ablations (wrong results): 1 return at entry, 2 after staging,
-                                                // 3 no K loop, 4 no epilogue, 5 no pair exchange, 6 return after the cross-wave reduce, 7 before the stores, 8 no planes store
+                                                // 3 no K loop, 4 no epilogue, 5 no pair exchange, 6 return after the cross-wave reduce, 7 before the stores, 8 no planes store,
+                                                // 9 (tests) odd n-tiles skip their publish and the spin bound is short: forces the exchange time-out
 };
 
-__global__ void dconv_epoch_kernel(int* e) { if (threadIdx.x == 0 && blockIdx.x == 0) e[0] += 1; }
+// e[0]: the epoch eager forwards and the first step of a loop read; e[8]: the ping-pong sample loop's second slot
+__global__ void dconv_epoch_kernel(int* e) { if (threadIdx.x == 0 && blockIdx.x == 0) e[0] = max(e[0], e[8]) + 1; }
 
 template <int L, int KPW0, int KPW1, bool RES>
 __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         }
     };
     float v[6];
+    stress_delay(a.stress, 3u);
     reduce_to(accM, accL, bias, v);
     if (a.dbg == 6) { if (v[0] + v[5] == 123.456f) a.out2[0] = 1.f; return; }
 
@@ -320,17 +325,19 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     }
     if (a.gw == 64 && a.dbg != 5) {
         // the group's other 32 columns belong to the workgroup nt ^ 1 of the same m-tile: swap (mean, M2) halves
+        stress_delay(a.stress, 1u);
         const int sbase = ((mt * a.NT + nt) * 16) * 2, pbase = ((mt * a.NT + (nt ^ 1)) * 16) * 2;
 #pragma unroll
         for (int js = 0; js < NSAMP; ++js) {
             const int s = (S == 16) ? rq + 8 * js : rq;
-            if (n == 0) {
+            if (n == 0 && !(a.dbg == 9 && (nt & 1))) {       // dbg 9 (tests): odd n-tiles never publish -> their partners time out
                 const unsigned long long g0 = ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, mean[js]);
                 const unsigned long long g1 = ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, rstd[js]);
                 __hip_atomic_store(a.xchg + sbase + s * 2, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.xchg + sbase + s * 2 + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        stress_delay(a.stress, 2u);
 #pragma unroll
         for (int js = 0; js < NSAMP; ++js) {
             const int s = (S == 16) ? rq + 8 * js : rq;
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
                 g1 = __hip_atomic_load(a.xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
                 if (__all(ok)) break;
-                if (++spins > (1 << 20)) { if (lane == 0) atomicExch(a.err_flag, 1); break; }     // never hang the GPU
+                if (++spins > (a.dbg == 9 ? (1 << 8) : (1 << 20))) { if (lane == 0) atomicExch(a.err_flag, 1); break; }     // never hang the GPU
                 __builtin_amdgcn_s_sleep(2);
             }
             const float mp = __builtin_bit_cast(float, (unsigned)g0), M2p = __builtin_bit_cast(float, (unsigned)g1);
@@ -383,6 +390,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
             const uint32_t word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
             tw[(odd ? 48 * TP : 0) + r * TP + (n >> 1)] = word;
         }
+        stress_delay(a.stress, 4u);
         __syncthreads();
         for (int i = tid; i < 384; i += 256) {
             const int pl = i >= 192 ? 1 : 0, within = i - pl * 192;
@@ -392,12 +400,609 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
         }
     }
     if constexpr (RES) {
+        stress_delay(a.stress, 5u);
         __syncthreads();                                          // Red is reused
         float r2[6];
         reduce_to(accRM, accRL, bias2, r2);
 #pragma unroll
         for (int q = 0; q < 6; ++q)
             if (sok[q]) a.out2[(size_t)grow[q] * a.ldo2 + gn] = r2[q];
+    }
+    l2_prefetch_done(a.pf, pfr);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dconv2_kernel<L, KPW0, KPW1, RES, KPWB>: a whole deep-level ResidualTemporalBlock (model/diffusion_1d.py:483-511) in ONE
+// launch -- both Conv1dBlocks, the time bias, the riding 1x1 residual_conv and the residual add:
+//     y0  = Mish(GN(conv5(x) + b0)) + tbias_t          (phase A: dconv_kernel's launch A)
+//     out = Mish(GN(conv5(y0) + b1)) + (x | Wr x + br)  (phase B: its launch B)
+// The seam between the two convolutions is an all-gather inside the m-tile's column of workgroups: workgroup (nt, mt)
+// produces channels [32 nt, 32 nt + 32) of y0 for the tile's 48 rows, and needs ALL channels of those rows for phase B.
+// Each workgroup publishes its 6 KB of planes with write-through (sc1) 16-byte stores, drains, and raises ONE flag word
+// (tag = the forward's epoch; MI355X_MICROARCH.md "handoff-flag", recipe R1); wave w of a consumer polls the flags of
+// the k-steps it owns (k-step ks = channels of producer nt = ks), then fetches them with sc1 loads (no acquire fence: both
+// sides are sc1) straight into the staging registers of phase B's K loop.  What the merge removes per block: one kernel
+// boundary (dispatch + drain), the fp32 round trip of r = Wr x + br (it stays in registers) and the cold first loads of
+// launch B (phase B's first weight taps are requested before phase A's epilogue).  The workgroups of a column are
+// adjacent block indices, so they are dispatched together; the spins are bounded and report through err_flag.
+struct Dconv2Args {
+    DSrc src[2];
+    const uint4* Wa; const float* bias_a; int ncha;      // conv A: stages of 128 input channels (KPW0 + KPW1)
+    const uint4* Wb; const float* bias_b;                // conv B: N -> N
+    const uint4* W2; const float* bias2;                 // riding 1x1 residual_conv (RES)
+    int Bp, N, NT, gw;
+    const float* gamma_a; const float* beta_a; const float* gamma_b; const float* beta_b;
+    const float* tb; int tb_ld; const int* t_ptr; int t_imm;
+    const float* res; int ldres;                          // identity residual x (fp32, sample-major rows) when !RES
+    uint4* y0; size_t y0_pstride;                         // hand-over planes [plane][tile][N/32][192] (global)
+    unsigned* flags;                                      // [tiles][NT] publish flags (8-byte slots, tag = epoch)
+    float* out_f32; int ldo; uint4* out_planes; size_t out_pstride;
+    unsigned long long* xchg_a; unsigned long long* xchg_b; const int* epoch; int* err_flag;     // gw == 64 pair exchanges
+    Pf pf; int stress; int dbg;
+};
+
+template <int L, int KPW0, int KPW1, bool RES, int KPWB>
+__global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
+    constexpr int T = 5;
+    constexpr int S = 48 / L, PB = 16 / S, H = PB - 1, RPAD = (L + 2 * H) * S, NWIN = L + H;
+    constexpr int KPWA = KPW0 > KPW1 ? KPW0 : KPW1;
+    constexpr int KPWM = KPWA > KPWB ? KPWA : KPWB;
+    constexpr int KST = 4 * KPWM;
+    constexpr int PLANE_U4 = KST * 4 * RPAD;
+    static_assert(L == 3 || L == 6, "3 or 6 positions per sample");
+    __shared__ uint4 Img[2][PLANE_U4];
+    __shared__ float Red[4][TM * LDR];
+    __shared__ uint4 Tile[2 * 48 * 5];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int b0 = mt * S;
+    const int ns = min(S, a.Bp - b0);
+    const int n = tid & 31, rq = tid >> 5;
+    const int gn = nt * TN + n;
+    int grow[6];
+    bool sok[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int pos = (S == 16) ? (q >> 1) : q;
+        const int s = (S == 16) ? rq + 8 * (q & 1) : rq;
+        sok[q] = s < ns;
+        grow[q] = (b0 + min(s, ns - 1)) * L + pos;
+    }
+
+    // ---- staging of phase A (as dconv_kernel) ------------------------------------------------------------------------
+    struct Stg { const uint4* base[3]; size_t kstride, second; int slot[3]; bool f32; };
+    auto stg_init = [&](const DSrc& s, Stg& g) {
+        g.f32 = s.planes == nullptr;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int item = lane + 64 * i;
+            if (!g.f32) {
+                const int kq = item / 48, row = item - kq * 48;
+                g.base[i] = s.planes + (size_t)mt * (s.C >> 5) * 192 + item;
+                g.slot[i] = kq * RPAD + H * S + row;
+            } else {
+                const int row = item >> 2, kq = item & 3;
+                const int sm = row % S, pos = row / S;
+                g.base[i] = reinterpret_cast<const uint4*>(s.f32 + (size_t)((b0 + min(sm, ns - 1)) * L + pos) * s.ld + kq * 8);
+                g.slot[i] = kq * RPAD + H * S + row;
+            }
+        }
+        g.kstride = g.f32 ? 8 : 192;
+        g.second = g.f32 ? 1 : s.pstride;
+    };
+    auto load_raw = [&](const Stg& g, int j, uint4 (&raw)[3][2]) {
+        const size_t ko = (size_t)(4 * j + w) * g.kstride;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { raw[i][0] = g.base[i][ko]; raw[i][1] = g.base[i][ko + g.second]; }
+    };
+    auto store_raw = [&](bool f32, const int (&slot)[3], int j, const uint4 (&raw)[3][2]) {
+        const int kb = (4 * j + w) * 4 * RPAD;
+        if (!f32) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Img[0][kb + slot[i]] = raw[i][0]; Img[1][kb + slot[i]] = raw[i][1]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float4 v0 = __builtin_bit_cast(float4, raw[i][0]), v1 = __builtin_bit_cast(float4, raw[i][1]);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                half8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hi[e] = (_Float16)v[e];
+                    lo[e] = (_Float16)((v[e] - (float)hi[e]) * H3_SCALE);
+                }
+                Img[0][kb + slot[i]] = __builtin_bit_cast(uint4, hi);
+                Img[1][kb + slot[i]] = __builtin_bit_cast(uint4, lo);
+            }
+        }
+    };
+
+    Stg g0, g1;
+    stg_init(a.src[0], g0);
+    uint4 raw0[KPW0][3][2];
+#pragma unroll
+    for (int j = 0; j < KPW0; ++j) load_raw(g0, j, raw0[j]);
+
+    half8 breg[T][2][2];
+    const uint4* wbase = a.Wa + (size_t)nt * a.ncha * (T * 4) * 256 + tid;
+    const uint4* wbase_b = a.Wb + (size_t)nt * KPWB * (T * 4) * 256 + tid;
+    auto load_b_tap = [&](const uint4* wb, int ch, int tap) {
+        const uint4* wp = wb + ((size_t)ch * (T * 4) + tap * 4) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[tap][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+    };
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase, 0, tap);
+    half8 rreg[2][2];
+    const uint4* rbase = a.W2 + (size_t)nt * a.ncha * 4 * 256 + tid;
+    auto load_r = [&](int ch) {
+        if constexpr (RES) {
+            const uint4* wp = rbase + (size_t)ch * 4 * 256;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rreg[q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+        }
+    };
+    load_r(0);
+    uint4 raw1[KPW1 > 0 ? KPW1 : 1][3][2];
+    if constexpr (KPW1 > 0) {
+        stg_init(a.src[1], g1);
+#pragma unroll
+        for (int j = 0; j < KPW1; ++j) load_raw(g1, j, raw1[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue operands of both phases ----------------------------------------------------------------------------
+    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const unsigned tag = (unsigned)*a.epoch;
+    const float bias_a = a.bias_a ? a.bias_a[gn] : 0.f, bias_b = a.bias_b ? a.bias_b[gn] : 0.f;
+    const float gam_a = a.gamma_a[gn], bet_a = a.beta_a[gn], gam_b = a.gamma_b[gn], bet_b = a.beta_b[gn];
+    const float tbv = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : 0.f;
+    float bias2 = 0.f;
+    if constexpr (RES) bias2 = a.bias2 ? a.bias2[gn] : 0.f;
+    float rs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (!RES) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rs[q] = a.res[(size_t)grow[q] * a.ldres + gn];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (H > 0) {
+        const uint4 z = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < KPWM * 4 * 2 * H * S; i += 64) {
+            const int blk = i / (2 * H * S), r = i - blk * (2 * H * S);
+            const int ks = 4 * (blk >> 2) + w, kq = blk & 3;
+            const int row = r < H * S ? r : (L + H) * S + (r - H * S);
+            Img[0][(ks * 4 + kq) * RPAD + row] = z;
+            Img[1][(ks * 4 + kq) * RPAD + row] = z;
+        }
+    }
+
+    f32x4 accM[3][2], accL[3][2], accRM[3][2], accRL[3][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    };
+    zero_acc();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accRM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accRL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // one k-step against all five taps (dconv_kernel's); WB: the weight stream this phase reads; RIDE: the 1x1 on the centre tap
+    auto kstep = [&](const uint4* wb, int j, int chn, auto pf, auto ride) {
+        constexpr bool PF = decltype(pf)::value;
+        constexpr bool RIDE = decltype(ride)::value;
+        const int base = ((4 * j + w) * 4 + (lane >> 4)) * RPAD + (lane & 15);
+        half8 fh[NWIN], fl[NWIN];
+#pragma unroll
+        for (int p = 0; p < NWIN; ++p) {
+            fh[p] = __builtin_bit_cast(half8, Img[0][base + p * S]);
+            fl[p] = __builtin_bit_cast(half8, Img[1][base + p * S]);
+        }
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb) {
+                const int p = mb * PB + tap - 2 + H;
+                if (p < 0 || p >= NWIN) continue;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][0], accM[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][1], accL[mb][nb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], breg[tap][nb][0], accL[mb][nb], 0, 0, 0);
+            }
+            if constexpr (RIDE) if (tap == 2) {
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb) {
+                    const int p = mb * PB + H;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        accRM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], rreg[nb][0], accRM[mb][nb], 0, 0, 0);
+                        accRL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], rreg[nb][1], accRL[mb][nb], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        accRL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], rreg[nb][0], accRL[mb][nb], 0, 0, 0);
+                }
+                if constexpr (PF) load_r(chn);
+            }
+            if constexpr (PF) load_b_tap(wb, chn, tap);
+        }
+    };
+    constexpr std::true_type YES{};
+    constexpr std::false_type NO{};
+    constexpr std::integral_constant<bool, RES> RIDE_A{};
+    // ---- phase A K loop; its last k-step requests phase B's first stage of weights instead of nothing ------------------
+    if constexpr (KPW1 == 0) {
+#pragma unroll
+        for (int j = 0; j < KPW0 - 1; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A); }
+        store_raw(g0.f32, g0.slot, KPW0 - 1, raw0[KPW0 - 1]);
+        kstep(wbase, KPW0 - 1, 0, NO, RIDE_A);
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPW0; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A); }
+#pragma unroll
+        for (int j = 0; j < KPW1 - 1; ++j) { store_raw(g1.f32, g1.slot, j, raw1[j]); kstep(wbase, j, KPW0 + j + 1, YES, RIDE_A); }
+        store_raw(g1.f32, g1.slot, KPW1 - 1, raw1[KPW1 - 1]);
+        kstep(wbase, KPW1 - 1, 0, NO, RIDE_A);
+    }
+    // phase B's first stage of weights: in flight during phase A's epilogue and the hand-over
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
+
+    // ---- shared epilogue pieces ---------------------------------------------------------------------------------------
+    auto reduce_to = [&](const f32x4 (&m)[3][2], const f32x4 (&l)[3][2], float bs, float (&v)[6]) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = m[mb][nb][rg] + l[mb][nb][rg] * H3_INV;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int r = rq + 8 * q;
+            v[q] = ((Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n])) + bs;
+        }
+    };
+    constexpr int NSAMP = (S == 16) ? 2 : 1;
+    const int gwt = a.gw < TN ? a.gw : TN;
+    const float cnt = (float)(L * gwt);
+    // GroupNorm + Mish of the reduced tile v (dconv_kernel's, incl. the pair exchange through `xchg` when gw == 64)
+    auto gn_mish = [&](const float (&v)[6], unsigned long long* xchg, float gam, float bet, float (&y)[6]) {
+        float mean[NSAMP], rstd[NSAMP];
+#pragma unroll
+        for (int js = 0; js < NSAMP; ++js) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int pos = 0; pos < L; ++pos) s1 += v[(S == 16) ? 2 * pos + js : pos];
+            s1 = row16_sum(s1);
+            if (gwt == 32) s1 = xsum16(s1);
+            const float m = s1 / cnt;
+            float s2 = 0.f;
+#pragma unroll
+            for (int pos = 0; pos < L; ++pos) { const float d = v[(S == 16) ? 2 * pos + js : pos] - m; s2 += d * d; }
+            s2 = row16_sum(s2);
+            if (gwt == 32) s2 = xsum16(s2);
+            mean[js] = m; rstd[js] = s2;
+        }
+        if (a.gw == 64) {
+            stress_delay(a.stress, 1u);
+            const int sbase = ((mt * a.NT + nt) * 16) * 2, pbase = ((mt * a.NT + (nt ^ 1)) * 16) * 2;
+#pragma unroll
+            for (int js = 0; js < NSAMP; ++js) {
+                const int s = (S == 16) ? rq + 8 * js : rq;
+                if (n == 0) {
+                    const unsigned long long q0 = ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, mean[js]);
+                    const unsigned long long q1 = ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, rstd[js]);
+                    __hip_atomic_store(xchg + sbase + s * 2, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(xchg + sbase + s * 2 + 1, q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            stress_delay(a.stress, 2u);
+#pragma unroll
+            for (int js = 0; js < NSAMP; ++js) {
+                const int s = (S == 16) ? rq + 8 * js : rq;
+                unsigned long long q0 = 0, q1 = 0;
+                int spins = 0;
+                while (true) {
+                    q0 = __hip_atomic_load(xchg + pbase + s * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q1 = __hip_atomic_load(xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = (unsigned)(q0 >> 32) == tag && (unsigned)(q1 >> 32) == tag;
+                    if (__all(ok)) break;
+                    if (++spins > (1 << 20)) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                const float mp = __builtin_bit_cast(float, (unsigned)q0), M2p = __builtin_bit_cast(float, (unsigned)q1);
+                const float m = 0.5f * (mean[js] + mp);
+                const float d0 = mean[js] - m, d1 = mp - m;
+                mean[js] = m;
+                rstd[js] = (rstd[js] + M2p) + cnt * (d0 * d0 + d1 * d1);
+            }
+        }
+        const float cnt_all = a.gw == 64 ? 2.f * cnt : cnt;
+#pragma unroll
+        for (int js = 0; js < NSAMP; ++js) rstd[js] = 1.0f / sqrtf(rstd[js] / cnt_all + 1e-5f);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int js = (S == 16) ? (q & 1) : 0;
+            y[q] = mish_f((v[q] - mean[js]) * rstd[js] * gam + bet);
+        }
+    };
+    // the tile's planes into LDS `Tile` (row-major [plane][row][16 dwords + 4 pad]; dconv_kernel's DPP pairing)
+    constexpr int TP = 20;
+    auto planes_to_tile = [&](const float (&y)[6]) {
+        uint32_t* tw = reinterpret_cast<uint32_t*>(Tile);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int r = rq + 8 * q;
+            const _Float16 hi = (_Float16)y[q];
+            const _Float16 lo = (_Float16)((y[q] - (float)hi) * H3_SCALE);
+            const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            const uint32_t nbr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);
+            const bool odd = n & 1;
+            const uint32_t word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
+            tw[(odd ? 48 * TP : 0) + r * TP + (n >> 1)] = word;
+        }
+    };
+
+    // ---- phase A epilogue: y0 tile -> planes, published to the column --------------------------------------------------
+    float v[6], y[6];
+    stress_delay(a.stress, 3u);
+    reduce_to(accM, accL, bias_a, v);
+    gn_mish(v, a.xchg_a, gam_a, bet_a, y);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) y[q] += tbv;
+    planes_to_tile(y);
+    stress_delay(a.stress, 4u);
+    __syncthreads();
+    {
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(Tile);
+        const size_t plane_bytes = a.y0_pstride * 16;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.y0), 0, (unsigned)(2 * plane_bytes), 0x00020000);
+        for (int i = tid; i < 384; i += 256) {
+            const int pl = i >= 192 ? 1 : 0, within = i - pl * 192;
+            const int kq = within / 48, row = within - kq * 48;
+            const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * 48 * TP + row * TP + kq * 4);
+            const unsigned off = (unsigned)(pl * plane_bytes + (((size_t)mt * a.NT + nt) * 192 + within) * 16);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rsrc, off, 0, 16);     // aux 16 = sc1: write-through
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+    stress_delay(a.stress, 6u);
+    __syncthreads();
+    if (tid == 0 && !(a.dbg == 9 && (nt & 1)))
+        __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // r = Wr x + br stays in registers (Red is free again: the barrier above)
+    float r2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (RES) { reduce_to(accRM, accRL, bias2, r2); __syncthreads(); }
+
+    // ---- hand-over: this wave's k-steps of y0 (k-step ks = the 32 channels of producer nt = ks) -----------------------
+    uint4 rawb[KPWB][3][2];
+    int slotb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int item = lane + 64 * i, kq = item / 48, row = item - kq * 48; slotb[i] = kq * RPAD + H * S + row; }
+    {
+        stress_delay(a.stress, 7u);
+        int spins = 0;
+        const int spin_max = a.dbg == 9 ? (1 << 8) : (1 << 20);
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < KPWB; ++j)
+                ok = ok && __hip_atomic_load(a.flags + 2 * ((size_t)mt * a.NT + 4 * j + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+            if (ok) break;                                        // (every lane reads the same words: uniform)
+            if (++spins > spin_max) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const size_t plane_bytes = a.y0_pstride * 16;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.y0), 0, (unsigned)(2 * plane_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < KPWB; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned off = (unsigned)((((size_t)mt * a.NT + 4 * j + w) * 192 + lane + 64 * i) * 16);
+                rawb[j][i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16));            // sc1: past L1
+                rawb[j][i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (unsigned)plane_bytes, 0, 16));
+            }
+    }
+    // ---- phase B K loop --------------------------------------------------------------------------------------------------
+    zero_acc();
+#pragma unroll
+    for (int j = 0; j < KPWB - 1; ++j) { store_raw(false, slotb, j, rawb[j]); kstep(wbase_b, j, j + 1, YES, NO); }
+    store_raw(false, slotb, KPWB - 1, rawb[KPWB - 1]);
+    kstep(wbase_b, KPWB - 1, 0, NO, NO);
+
+    // ---- phase B epilogue: out = Mish(GN(.)) + (x | r) -------------------------------------------------------------------
+    stress_delay(a.stress, 8u);
+    reduce_to(accM, accL, bias_b, v);
+    gn_mish(v, a.xchg_b, gam_b, bet_b, y);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) y[q] += RES ? r2[q] : rs[q];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if (a.out_f32 && sok[q]) a.out_f32[(size_t)grow[q] * a.ldo + gn] = y[q];
+    if (a.out_planes) {
+        __syncthreads();                                          // Tile: the publish above has been read
+        planes_to_tile(y);
+        __syncthreads();
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(Tile);
+        for (int i = tid; i < 384; i += 256) {
+            const int pl = i >= 192 ? 1 : 0, within = i - pl * 192;
+            const int kq = within / 48, row = within - kq * 48;
+            const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * 48 * TP + row * TP + kq * 4);
+            a.out_planes[pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within] = t4;
+        }
+    }
+    l2_prefetch_done(a.pf, pfr);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dresample_kernel<UP, KPW>: the two resampling convolutions between the deep levels -- Downsample1d = Conv1d(C, C, 3,
+// stride 2, pad 1) from 6 to 3 positions and Upsample1d = ConvTranspose1d(C, C, 4, stride 2, pad 1) from 3 to 6
+// (model/diffusion_1d.py:92-106) -- in dconv_kernel's form: 16 samples per workgroup, the whole input tile resident in
+// LDS as position-major split-fp16 planes (staged from the attention site's fp32 output, k-step by k-step behind the
+// first MFMAs), K split over the four waves, one (output position, tap) pair = one aligned 16-row window, pairs that fall
+// into the padding / the wrong parity dropped at compile time (8 of 9 remain going down, 10 of 24 going up).  The output
+// leaves as fp32 AND as planes in the NEXT layer's tile format (3 positions x 16 samples, or two tiles of 6 x 8).
+// conv_gemm_h3_kernel<3 | 4> needed 11 us per launch for these 0.3 GFLOP: its per-stage restaging, generic tap
+// addressing and statistics epilogue are all overhead here.  Weights: pack_weight_h3 (T = 3 / 4).
+struct DresArgs {
+    const float* x; int ld;                      // input fp32 [sample * Lin + position][ld]
+    const uint4* W; const float* bias; int nch;  // stages of 128 input channels
+    int Bp, N, NT;
+    float* out_f32; int ldo;
+    uint4* out_planes; size_t out_pstride;
+    Pf pf;
+};
+
+template <bool UP, int KPW>
+__global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
+    constexpr int T = UP ? 4 : 3, LIN = UP ? 3 : 6, LOUT = UP ? 6 : 3, S = 16;
+    constexpr int RIN = LIN * S, ROUT = LOUT * S, NBLK = LOUT, NQ = ROUT / 8;
+    constexpr int KST = 4 * KPW, TP = 20;
+    __shared__ uint4 Img[2][KST * 4 * RIN];
+    __shared__ float Red[4][ROUT * LDR];
+    __shared__ uint4 Tile[2 * ROUT * 5];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int b0 = mt * S, ns = min(S, a.Bp - b0);
+    const int n = tid & 31, rq = tid >> 5, gn = nt * TN + n;
+
+    // staging: item = (input row, k-quarter); row = position * 16 + sample; a row's 32 channels are one 128-byte line
+    constexpr int NIT = RIN * 4 / 64;
+    const float* ibase[NIT];
+    int islot[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int item = lane + 64 * i, row = item >> 2, kq = item & 3, sm = row % S, pos = row / S;
+        ibase[i] = a.x + (size_t)((b0 + min(sm, ns - 1)) * LIN + pos) * a.ld + kq * 8;
+        islot[i] = kq * RIN + row;
+    }
+    float4 raw[KPW][NIT][2];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const float4* p4 = reinterpret_cast<const float4*>(ibase[i] + (4 * j + w) * 32);
+            raw[j][i][0] = p4[0]; raw[j][i][1] = p4[1];
+        }
+    half8 breg[T][2][2];
+    const uint4* wbase = a.W + (size_t)nt * a.nch * (T * 4) * 256 + tid;
+    auto load_b_tap = [&](int ch, int tap) {
+        const uint4* wp = wbase + ((size_t)ch * (T * 4) + tap * 4) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[tap][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+    };
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
+    const float bias = a.bias ? a.bias[gn] : 0.f;
+    PfRegs pfr;
+    l2_prefetch(a.pf, pfr);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 accM[NBLK][2], accL[NBLK][2];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto kstep = [&](int j, int chn, auto pf) {
+        constexpr bool PF = decltype(pf)::value;
+        const int kb = (4 * j + w) * 4 * RIN;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const float v[8] = {raw[j][i][0].x, raw[j][i][0].y, raw[j][i][0].z, raw[j][i][0].w, raw[j][i][1].x, raw[j][i][1].y, raw[j][i][1].z, raw[j][i][1].w};
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)((v[e] - (float)hi[e]) * H3_SCALE); }
+            Img[0][kb + islot[i]] = __builtin_bit_cast(uint4, hi);
+            Img[1][kb + islot[i]] = __builtin_bit_cast(uint4, lo);
+        }
+        const int base = kb + (lane >> 4) * RIN + (lane & 15);
+        half8 fh[LIN], fl[LIN];
+#pragma unroll
+        for (int p = 0; p < LIN; ++p) {
+            fh[p] = __builtin_bit_cast(half8, Img[0][base + p * S]);
+            fl[p] = __builtin_bit_cast(half8, Img[1][base + p * S]);
+        }
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+#pragma unroll
+            for (int lo = 0; lo < LOUT; ++lo) {
+                // down: x[2 lo - 1 + tap];  up: lo = 2 li - 1 + tap  <=>  li = (lo + 1 - tap) / 2 when that is an integer
+                const int num = UP ? lo + 1 - tap : 2 * lo - 1 + tap;
+                if (UP && (num & 1)) continue;
+                const int p = UP ? num / 2 : num;
+                if (num < 0 || p >= LIN) continue;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    accM[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][0], accM[lo][nb], 0, 0, 0);
+                    accL[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][1], accL[lo][nb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    accL[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], breg[tap][nb][0], accL[lo][nb], 0, 0, 0);
+            }
+            if constexpr (PF) load_b_tap(chn, tap);
+        }
+    };
+    constexpr std::true_type YES{};
+    constexpr std::false_type NO{};
+#pragma unroll
+    for (int j = 0; j < KPW - 1; ++j) kstep(j, j + 1, YES);
+    kstep(KPW - 1, 0, NO);
+
+    // cross-wave K reduction; thread (n, rq) ends with column n of rows rq + 8 q (row = position * 16 + sample)
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV;
+    __syncthreads();
+    uint32_t* tw = reinterpret_cast<uint32_t*>(Tile);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int r = rq + 8 * q, sm = r & 15, pos = r >> 4;
+        const float y = ((Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n])) + bias;
+        if (sm < ns) a.out_f32[(size_t)((b0 + sm) * LOUT + pos) * a.ldo + gn] = y;
+        const _Float16 hi = (_Float16)y;
+        const _Float16 lo = (_Float16)((y - (float)hi) * H3_SCALE);
+        const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+        const uint32_t nbr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);
+        const bool odd = n & 1;
+        const uint32_t word = odd ? ((nbr >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (nbr << 16));
+        tw[(odd ? ROUT * TP : 0) + r * TP + (n >> 1)] = word;
+    }
+    if (a.out_planes) {
+        __syncthreads();
+        // the next layer's tiles: down -> one tile of 3 positions x 16 samples (rows as here); up -> two tiles of 6 positions x
+        // 8 samples (tile 2 mt + (sample >> 3), row position * 8 + (sample & 7)); item = (plane, k-quarter, row) = 16 bytes
+        for (int i = tid; i < 2 * 4 * ROUT; i += 256) {
+            const int pl = i / (4 * ROUT), within = i - pl * 4 * ROUT, kq = within / ROUT, r = within - kq * ROUT;
+            const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * ROUT * TP + r * TP + kq * 4);
+            size_t dst;
+            if constexpr (!UP) dst = ((size_t)mt * a.NT + nt) * 192 + kq * 48 + r;
+            else {
+                const int sm = r & 15, pos = r >> 4, tile = 2 * mt + (sm >> 3);
+                if (tile * 8 >= a.Bp) continue;                  // (a ragged batch: the second 8-sample tile does not exist)
+                dst = ((size_t)tile * a.NT + nt) * 192 + kq * 48 + pos * 8 + (sm & 7);
+            }
+            a.out_planes[pl * a.out_pstride + dst] = t4;
+        }
     }
     l2_prefetch_done(a.pf, pfr);
 }
@@ -424,6 +1029,7 @@ struct AttnHeadArgs {
     int L, S, slot, Bp;
     unsigned long long* xchg; const int* epoch; int* err_flag;
     Pf pf;
+    int stress;                                  // > 0: pseudo-random pauses before the hand-overs (stress_delay)
 };
 
 template <int C>
@@ -558,6 +1164,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
         }
     }
     // cross-wave sum in the fixed order (w0 + w1) + (w2 + w3): every wave ends with the complete tiles
+    stress_delay(a.stress, 13u);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -580,6 +1187,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     // ---- core: wave w owns sample w of the group ----
     f32x4 att[2][1];
     attn_site_core_range<1>(qa, ka, va, att, w, min(w + 1, s_here), nend, slot, L, lq, lr);
+    stress_delay(a.stress, 11u);
     // publish this wave's sample columns (positions [w * slot, (w + 1) * slot)) of the head's 32 x 16 tile, and keep a
     // copy for the own projection.  Granule (hd, e, n) of group grp: value att[e][n], tag = epoch.
     unsigned long long* gx = a.xchg + (size_t)grp * 4 * 512;
@@ -604,6 +1212,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
                 __hip_atomic_store(gx + hd * 512 + (et * 16 + lq * 4 + i) * 16 + lr, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // gather all four heads' tiles (own head included: one code path) -> att planes [position][128 channels]
+    stress_delay(a.stress, 12u);
     {
         unsigned long long gq[8];
         int spins = 0;

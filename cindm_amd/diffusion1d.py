@@ -166,6 +166,13 @@ class GaussianDiffusion1D(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return h, un, self._ws
 
+    def last_step_info(self):
+        """(kernel launches, update fused into the U-Net's last kernel?) of the reverse step emitted last -- as launched
+        by the library, not a model of it (``cindm_ddpm1d_last_step_info``)."""
+        n, f = C.c_int32(), C.c_int32()
+        _ffi.check(_ffi.lib().cindm_ddpm1d_last_step_info(self._handle(), C.byref(n), C.byref(f)))
+        return int(n.value), bool(f.value)
+
     @staticmethod
     def _f32(t, device=None):
         return None if t is None else t.detach().to(device=device or t.device, dtype=torch.float32).contiguous()
@@ -190,9 +197,17 @@ class GaussianDiffusion1D(nn.Module):
             return int(t.reshape(-1)[0])
         return int(t)
 
+    def _check_status(self, desc, device):
+        """The exchange flags of the U-Nets a step with ``desc`` runs (CindmError on a timed-out exchange); synchronises."""
+        self.model.check_status(device)
+        if desc.mode == _ffi.COMPOSE_MULTIBODY:
+            self.model_unconditioned.check_status(device)
+
     @torch.no_grad()
-    def _predict(self, x, cond, t, desc):
-        """(model_mean, x_start, pred_noise) = p_mean_variance(x, cond, t, ...) (:1033-1044) on the device."""
+    def _predict(self, x, cond, t, desc, check=True):
+        """(model_mean, x_start, pred_noise) = p_mean_variance(x, cond, t, ...) (:1033-1044) on the device.
+        ``check``: read the U-Nets' exchange flags before returning (the Python loops pass False and check once at
+        their end: the predictions of a step only feed the next one until then)."""
         if not x.is_cuda:
             raise _ffi.CindmError("sampling needs ROCm device tensors; there is no CPU execution path")
         x = self._f32(x)
@@ -204,6 +219,8 @@ class GaussianDiffusion1D(nn.Module):
             _ffi.check(_ffi.lib().cindm_ddpm1d_predict(h, self.model._h, un, C.byref(desc), _ffi.ptr(x), _ffi.ptr(cond_d),
                                                        int(t), None, B, _ffi.ptr(mean), _ffi.ptr(x0), _ffi.ptr(eps),
                                                        _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+        if check:
+            self._check_status(desc, x.device)
         return mean, x0, eps
 
     def model_predictions(self, x, cond, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, **kwargs):
@@ -271,7 +288,7 @@ class GaussianDiffusion1D(nn.Module):
 
     @torch.no_grad()
     def _guided_step(self, x, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, noise, recur_noise,
-                     ddim_return=False):
+                     ddim_return=False, check=True):
         """Shared body of p_sample / p_sample_compose_inside / p_sample_compose_outside.  ``ddim_return``: the
         sampling_timesteps != timesteps convention of the recurrence branch (:1372-1376): returns
         (pred_noise + grad_design_final, x_start) of the last iteration."""
@@ -281,7 +298,7 @@ class GaussianDiffusion1D(nn.Module):
         x_start = None
         eps = shift = None
         for r in range(max(R, 1)):
-            mean, x_start, eps = self._predict(x, cond, t, desc)
+            mean, x_start, eps = self._predict(x, cond, t, desc, check=check)
             pred = mean
             if design_fn is not None:
                 shift = self._design_shift(design_fn, design_guidance, x, x_start, t)
@@ -422,10 +439,12 @@ class GaussianDiffusion1D(nn.Module):
         for t in reversed(range(t_stop, self.num_timesteps)):
             nz = None if noise is None else noise.step[t]
             rn = None if (noise is None or noise.recur is None) else noise.recur[t]
-            img, _ = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, nz, rn)
+            img, _ = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, nz, rn,
+                                       check=False)
             if inpaint is not None:
                 zc = noise.cond[t] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
                 img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
+        self._check_status(desc, device)
         return img
 
     @torch.no_grad()
@@ -551,7 +570,7 @@ class GaussianDiffusion1D(nn.Module):
         for i, (t, tn) in enumerate(zip(times[:-1], times[1:])):
             rn = None if (noise is None or noise.recur is None) else noise.recur[i]
             eps, x_start = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite,
-                                             None, rn, ddim_return=True)
+                                             None, rn, ddim_return=True, check=False)
             if tn < 0:
                 img = x_start
                 continue
@@ -560,4 +579,5 @@ class GaussianDiffusion1D(nn.Module):
             if inpaint is not None:
                 zc = noise.cond[i] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
                 img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
+        self._check_status(desc, device)
         return img

@@ -8,8 +8,8 @@ What runs where
     step replayed per timestep), the state staying in the library's channel-last layout for the whole chain;
   * ``design_fn`` is a user Python callable returning a gradient tensor (:813); it is evaluated between library
     calls, exactly where the reference evaluates it.
-Training, DDIM, self-conditioning, objectives other than pred_noise and ``share_noise=False`` are outside this
-build's scope and raise NotImplementedError.
+Training, DDIM, self-conditioning and objectives other than pred_noise are outside this build's scope and raise
+NotImplementedError.
 """
 import ctypes as C
 
@@ -55,8 +55,6 @@ class GaussianDiffusion(nn.Module):
         assert not model.random_or_learned_sinusoidal_cond
         if objective != "pred_noise":
             raise NotImplementedError("only objective='pred_noise' is built (the airfoil checkpoints' objective)")
-        if not share_noise:
-            raise NotImplementedError("share_noise=False is not built")
         if schedule_fn_kwargs or min_snr_loss_weight:
             raise NotImplementedError("schedule_fn_kwargs / min_snr_loss_weight only matter for training")
         self.model = model
@@ -97,6 +95,11 @@ class GaussianDiffusion(nn.Module):
             except Exception:
                 pass
             self.__dict__["_h"] = None
+
+    def _share_mode(self):
+        """The library's ``use_average_share`` word: bit 0 = mean (1) / sum (0) over the boundary copies of a design, bit 1 =
+        share_noise False -- the clamped x_start and the posterior mean are shared instead of the prediction (:757-773)."""
+        return int(bool(self.use_average_share)) | (0 if self.share_noise else 2)
 
     # ------------------------------------------------------------------ library handle
     def _handle(self):
@@ -183,7 +186,7 @@ class GaussianDiffusion(nn.Module):
             ns = _state_cl(nz[:, :1, :-3])
             nbnd = _boundary_cl(nz[:, :, -3:])
         with torch.cuda.device(x.device):
-            _ffi.check(_ffi.lib().cindm_ddpm2d_step(h, self.model._h, _ffi.ptr(xd), B, nb, int(self.use_average_share),
+            _ffi.check(_ffi.lib().cindm_ddpm2d_step(h, self.model._h, _ffi.ptr(xd), B, nb, self._share_mode(),
                                                     int(clip_denoised), _ffi.ptr(ns), _ffi.ptr(nbnd), 0, 0, int(t), None,
                                                     _ffi.ptr(x0), _ffi.ptr(mean), _ffi.ptr(ws), ws.numel(),
                                                     _ffi.current_stream(x.device)))
@@ -288,7 +291,7 @@ class GaussianDiffusion(nn.Module):
                 ns = _state_cl(noise.step_state.to(device, torch.float32))
                 nbnd = _boundary_cl(noise.step_boundary.to(device, torch.float32))
             with torch.cuda.device(device):
-                _ffi.check(L.cindm_ddpm2d_sample(h, self.model._h, _ffi.ptr(x), B, nb, int(self.use_average_share),
+                _ffi.check(L.cindm_ddpm2d_sample(h, self.model._h, _ffi.ptr(x), B, nb, self._share_mode(),
                                                  _ffi.ptr(ns), _ffi.ptr(nbnd), seed, sample_offset, T - 1, int(t_stop),
                                                  _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
             return from_device_layout(x, Cc, H, W).reshape(B, nb, Cc, H, W)
@@ -310,10 +313,10 @@ class GaussianDiffusion(nn.Module):
                 ns = _state_cl(noise.step_state.to(device, torch.float32))
                 nbnd = _boundary_cl(noise.step_boundary.to(device, torch.float32))
             with torch.cuda.device(device):
-                _ffi.check(L.cindm_ddpm2d_sample_force(h, self.model._h, fo.model._h, _ffi.ptr(x), B, nb, int(self.use_average_share),
+                _ffi.check(L.cindm_ddpm2d_sample_force(h, self.model._h, fo.model._h, _ffi.ptr(x), B, nb, self._share_mode(),
                                                        _ffi.ptr(ns), _ffi.ptr(nbnd), seed, sample_offset, T - 1, int(t_stop),
                                                        fo.frames, fo.p_min, fo.p_max, fo.lambda_force, fo.lambda_overlap, fo.factor,
-                                                       _ffi.ptr(eta), _ffi.ptr(g), _ffi.ptr(ws), ws.numel(), _ffi.ptr(wsf),
+                                                       int(fo.sum_boundary), _ffi.ptr(eta), _ffi.ptr(g), _ffi.ptr(ws), ws.numel(), _ffi.ptr(wsf),
                                                        wsf.numel(), _ffi.current_stream(device), int(use_graph)))
             return from_device_layout(x, Cc, H, W).reshape(B, nb, Cc, H, W)
         img = from_device_layout(x, Cc, H, W)

@@ -79,12 +79,27 @@ class ForceUnet(nn.Module):
             _ffi.check(L.cindm_forceunet_finalize(self._h, _ffi.current_stream(dev)))
         self._sig = sig
 
+    def set_option(self, key, value):
+        """Selects a kernel path of this model (``cindm_forceunet_set_option``): ``h3`` / ``h3_bwd`` = 0 run the forward /
+        input-gradient 3x3 convolutions on the exact fp32 MFMA kernel, ``auto_range`` = 0 skips the range rule's calibration
+        forward.  Takes effect at the next call."""
+        _ffi.check(_ffi.lib().cindm_forceunet_set_option(self._h, key.encode(), int(value)))
+        self._sig = None
+        return self
+
+    def get_option(self, key):
+        """Current option value; ``get_option("range_fallback")`` is 1 after the calibration forward left fp16's range."""
+        self.sync_weights()
+        v = C.c_int32()
+        _ffi.check(_ffi.lib().cindm_forceunet_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
-    def _run(self, x, lambda_force=None):
+    def _run(self, x, lambda_force=None, dout=None):
         if not x.is_cuda:
             raise _ffi.CindmError("ForceUnet needs a ROCm device tensor; there is no CPU execution path")
         n, c, hh, ww = x.shape
@@ -94,7 +109,7 @@ class ForceUnet(nn.Module):
         L = _ffi.lib()
         xd = x.detach().float().permute(0, 2, 3, 1).reshape(n, hh * ww, c).contiguous()
         out = torch.empty((n, 2), dtype=torch.float32, device=x.device)
-        with_grad = lambda_force is not None
+        with_grad = lambda_force is not None or dout is not None
         ws = self._workspace(L.cindm_forceunet_workspace_bytes(self._h, n, int(with_grad)), x.device)
         with torch.cuda.device(x.device):
             if not with_grad:
@@ -102,13 +117,24 @@ class ForceUnet(nn.Module):
                                                      _ffi.current_stream(x.device)))
                 return out, None
             dx = torch.empty_like(xd)
-            _ffi.check(L.cindm_forceunet_grad(self._h, _ffi.ptr(xd), float(lambda_force), _ffi.ptr(out), _ffi.ptr(dx), n,
-                                              _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+            if dout is not None:
+                do = dout.detach().to(device=x.device, dtype=torch.float32).reshape(n, 2).contiguous()
+                _ffi.check(L.cindm_forceunet_vjp(self._h, _ffi.ptr(xd), _ffi.ptr(do), _ffi.ptr(out), _ffi.ptr(dx), n,
+                                                 _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+            else:
+                _ffi.check(L.cindm_forceunet_grad(self._h, _ffi.ptr(xd), float(lambda_force), _ffi.ptr(out), _ffi.ptr(dx), n,
+                                                  _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
         return out, dx.reshape(n, hh, ww, c).permute(0, 3, 1, 2).contiguous()
 
-    @torch.no_grad()
     def forward(self, x, x_self_cond=None):
-        return self._run(x)[0]
+        """``[N, channels, H, W] -> [N, 2]`` (lift, drag).  Differentiable with respect to ``x`` under torch.autograd (the
+        reference's ``force_fn`` takes ``autograd.grad`` of a function of this output, inverse_design_2d.py:113-117): the
+        backward is the library's input-gradient pass (``cindm_forceunet_vjp``; the forward is recomputed there -- the
+        kernels keep no state between calls).  Weights are frozen: no parameter gradients exist."""
+        if x.requires_grad and torch.is_grad_enabled():
+            return _ForceUnetFn.apply(x, self)
+        with torch.no_grad():
+            return self._run(x)[0]
 
     @torch.no_grad()
     def input_grad(self, x, lambda_force=1.0):
@@ -116,12 +142,29 @@ class ForceUnet(nn.Module):
         return self._run(x, lambda_force)
 
 
+class _ForceUnetFn(torch.autograd.Function):
+    """ForceUnet.forward under autograd: input gradients only (frozen weights), computed by the HIP backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, model):
+        ctx.model = model
+        ctx.save_for_backward(x)
+        return model._run(x)[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        with torch.no_grad():
+            _, dx = ctx.model._run(x, dout=dout)
+        return dx.to(x.dtype), None
+
+
 class ForceObjective:
-    """``design_fn`` of the airfoil inverse design (inference/inverse_design_2d.py:208-214, ``sum_boundary=True``):
+    """``design_fn`` of the airfoil inverse design (inference/inverse_design_2d.py:208-214; ``sum_boundary`` as force_fn's):
     ``g = grad_force + lambda_overlap * grad_overlap`` for a state ``x [B * nb, 3 * frames + 3, 64, 64]``."""
 
     def __init__(self, force_model, batch_size, num_boundaries, frames, p_min, p_max, lambda_force=1.0, lambda_overlap=1.0,
-                 downsampling_factor=4, frames_per_pass=None):
+                 downsampling_factor=4, frames_per_pass=None, sum_boundary=True):
         self.model, self.B, self.nb, self.frames = force_model, int(batch_size), int(num_boundaries), int(frames)
         # all frames of a design as ONE surrogate batch by default (frames * B * nb images per pass; workspace scales with it)
         self.frames_per_pass = int(frames_per_pass or frames)
@@ -129,6 +172,7 @@ class ForceObjective:
             raise ValueError("frames_per_pass must divide frames")
         self.p_min, self.p_max = float(p_min), float(p_max)
         self.lambda_force, self.lambda_overlap, self.factor = float(lambda_force), float(lambda_overlap), int(downsampling_factor)
+        self.sum_boundary = bool(sum_boundary)          # force_fn's branch (:98-132); the script's default is True
         self._ws = None
 
     @torch.no_grad()
@@ -149,6 +193,6 @@ class ForceObjective:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
             _ffi.check(L.cindm_airfoil_design_grad(m._h, _ffi.ptr(xd), self.B, self.nb, self.frames, cp, self.p_min, self.p_max,
-                                                   self.lambda_force, self.lambda_overlap, self.factor, _ffi.ptr(g),
+                                                   self.lambda_force, self.lambda_overlap, self.factor, int(self.sum_boundary), _ffi.ptr(g),
                                                    _ffi.ptr(self._ws), self._ws.numel(), _ffi.current_stream(x.device)))
         return from_device_layout(g, c, hh, ww)

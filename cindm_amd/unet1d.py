@@ -185,7 +185,15 @@ class TemporalUnet1D(nn.Module):
         with torch.cuda.device(x.device):
             _ffi.check(_ffi.lib().cindm_unet1d_forward(self._h, _ffi.ptr(x), t, None, _ffi.ptr(out), x.shape[0],
                                                        _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+            self.check_status(x.device)
         return out
+
+    def check_status(self, device):
+        """Raises CindmError when an in-kernel exchange between workgroups of a forward issued so far timed out (its
+        results are invalid); synchronises the current stream.  ``forward`` and the sampling loops call it before they
+        hand results back."""
+        with torch.cuda.device(device):
+            _ffi.check(_ffi.lib().cindm_unet1d_status(self._h, _ffi.current_stream(device)))
 
     # kind 4 = the k=5 convolutions: conv_gemm_h3_kernel<5,48,*> (split-fp16 MFMA; default) or
     # conv_gemm_kernel<5,32,48,*> (fp32 MFMA; CINDM_MFMA=f32)

@@ -268,6 +268,12 @@ int  cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed,
 int  cindm_ddpm1d_launches_per_step(const cindm_ddpm1d* h, const cindm_unet1d* pair,
                                     const cindm_unet1d* uncond, const cindm_compose_desc* c);
 
+/* What the reverse step emitted LAST on this handle consisted of (by cindm_ddpm1d_step / _predict or by the
+ * capture of a sample loop): `launches` = kernels launched (gather + U-Net(s) + update + step counter), as
+ * launched, not modelled; `fused_update` = 1 when the reverse-step update (:1033-1044, :1281) ran inside the
+ * U-Net's last kernel instead of compose_update_kernel.  Tests assert the fused path through this. */
+int  cindm_ddpm1d_last_step_info(const cindm_ddpm1d* h, int32_t* launches, int32_t* fused_update);
+
 /* ===================================================================== 2-D airfoil path
  * Replaces Unet.forward (model/diffusion_2d.py:369-408) and GaussianDiffusion.p_sample /
  * p_sample_loop (model/diffusion_2d.py:788-907) of the reference for the sampling path
@@ -329,6 +335,8 @@ size_t cindm_ddpm2d_workspace_bytes(const cindm_unet2d* u, int64_t images);
  * nb boundaries: Unet on all B*nb images; the model output's state channels (all but the last
  * 3) are averaged (use_average_share=1) or summed over the nb boundaries of a design
  * (share_states_over_boundaries :712-725); x0 from eps, clamp; posterior mean; + sigma_t * z
+ * (use_average_share bit 1 set = the constructor's share_noise False, p_mean_variance :757-773: the
+ * prediction is left alone and the clamped x_start, then the posterior mean, are shared instead)
  * with z shared over the boundaries for the state channels (sample_noise :775-785).  z comes
  * from noise_state [B, H*W, C-3] / noise_boundary [B*nb, H*W, 3] when given, else from the
  * counter-based generator (seed, sample_offset + b, t).  In place on x.  Optional outputs:
@@ -371,9 +379,14 @@ void cindm_forceunet_destroy(cindm_forceunet* h);
 int  cindm_forceunet_num_params(const cindm_forceunet* h);
 int  cindm_forceunet_param_info(const cindm_forceunet* h, int idx, char* name, int name_cap, int64_t shape[4], int* ndim);
 int  cindm_forceunet_set_param(cindm_forceunet* h, const char* key, const float* src, int64_t numel, int on_device);
-/* folds weight standardisation, packs forward and backward-data fragments.  Environment, read here: CINDM_FORCE_H3=0 keeps
- * the forward 3x3 convolutions, CINDM_FORCE_H3_BWD=0 the input-gradient ones, on the exact fp32 MFMA kernel instead of the
- * split-fp16 one (diagnostics; both paths meet the 2e-5 parity bound). */
+/* Kernel-path options of a handle (as cindm_unet1d_set_option; take effect at the next finalize): "h3" = 0 keeps the
+ * forward 3x3 convolutions, "h3_bwd" = 0 the input-gradient ones, on the exact fp32 MFMA kernel instead of the
+ * split-fp16 one (both paths meet the 2e-5 parity bound); "auto_range" = 0 skips the calibration forward of the range
+ * rule; "range_fallback" (read-only) = 1 when that forward switched the handle to the fp32 convolutions; "stress" > 0:
+ * pseudo-random delays before the producer -> consumer hand-overs of the persistent convolution kernel (race tests). */
+int  cindm_forceunet_set_option(cindm_forceunet* h, const char* key, int32_t value);
+int  cindm_forceunet_get_option(const cindm_forceunet* h, const char* key, int32_t* value);
+/* folds weight standardisation, packs forward and backward-data fragments, runs the range rule's calibration forward */
 int  cindm_forceunet_finalize(cindm_forceunet* h, void* stream);
 size_t cindm_forceunet_workspace_bytes(const cindm_forceunet* h, int64_t images, int32_t with_grad);
 /* out[images, 2] = ForceUnet.forward(x)   (:460-486) */
@@ -381,15 +394,23 @@ int  cindm_forceunet_forward(cindm_forceunet* h, const float* x, float* out, int
 /* the same forward, and dx = d( sum_images lambda_force * |out[:,0]| + out[:,1] ) / dx  (what force_fn differentiates, :113-117) */
 int  cindm_forceunet_grad(cindm_forceunet* h, const float* x, float lambda_force, float* out, float* dx, int64_t images,
                           void* ws, size_t ws_bytes, void* stream);
+/* the same forward, and dx = d( sum_images dout[img] . out[img] ) / dx for a caller-given dout [images, 2]: the backward of
+ * ForceUnet.forward under torch.autograd (cindm_amd.ForceUnet registers it), so force_fn of inverse_design_2d.py:98-132
+ * runs against this model as written */
+int  cindm_forceunet_vjp(cindm_forceunet* h, const float* x, const float* dout, float* out, float* dx, int64_t images,
+                         void* ws, size_t ws_bytes, void* stream);
 /* grad[B*nb, H*W, CP] = design_fn(x) = grad_force + lambda_overlap * grad_overlap (inverse_design_2d.py:208-214), the
  * tensor GaussianDiffusion.p_sample subtracts under "standard" / "standard-alpha" guidance (model/diffusion_2d.py:813-817).
  * frames = (real channels - 3) / 3; p_min / p_max: the pressure normalisation of the data set (:85-87). */
 /* frames_per_pass: how many of the `frames` surrogate passes of one gradient run as one batch (a divisor of frames;
  * cindm_airfoil_design_grad uses the largest one whose workspace fits what it is given) */
 size_t cindm_airfoil_design_workspace_bytes(const cindm_forceunet* h, int64_t B, int32_t nb, int32_t frames_per_pass);
+/* sum_boundary: force_fn's switch (:98-132): 1 = the surrogate sees the clamped sum of a design's boundaries and the pressure
+ * in simulator units (:100-120, the script's default); 0 = each copy's own boundary channels and the normalised pressure,
+ * forces summed over the boundaries of a design (:122-130). */
 int  cindm_airfoil_design_grad(cindm_forceunet* h, const float* x, int64_t B, int32_t nb, int32_t frames, int32_t CP,
                                float p_min, float p_max, float lambda_force, float lambda_overlap, int32_t downsampling_factor,
-                               float* grad, void* ws, size_t ws_bytes, void* stream);
+                               int32_t sum_boundary, float* grad, void* ws, size_t ws_bytes, void* stream);
 /* Design-guided 2-D sampling with the airfoil objective inside the captured step (inference/inverse_design_2d.py:236-244
  * with design_guidance = "standard-alpha"; p_sample's guided tail model/diffusion_2d.py:806-845): per reverse step
  * g = cindm_airfoil_design_grad(x_t); x_{t-1} = p_sample(x_t) (as cindm_ddpm2d_sample); x_{t-1} -= eta[t] * g, with eta a
@@ -399,9 +420,9 @@ int  cindm_ddpm2d_sample_force(cindm_ddpm1d* sched, cindm_unet2d* u, cindm_force
                                int32_t use_average_share, const float* noise_state_steps,
                                const float* noise_boundary_steps, uint64_t seed, int64_t sample_offset,
                                int32_t t_start, int32_t t_end, int32_t frames, float p_min, float p_max,
-                               float lambda_force, float lambda_overlap, int32_t down_factor, const float* eta,
-                               float* grad, void* ws, size_t ws_bytes, void* ws_force, size_t ws_force_bytes,
-                               void* stream, int32_t use_graph);
+                               float lambda_force, float lambda_overlap, int32_t down_factor, int32_t sum_boundary,
+                               const float* eta, float* grad, void* ws, size_t ws_bytes, void* ws_force,
+                               size_t ws_force_bytes, void* stream, int32_t use_graph);
 
 
 #ifdef __cplusplus

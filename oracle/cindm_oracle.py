@@ -1082,22 +1082,29 @@ def force_unet_forward(sd, x, taps=None):
 
 
 def airfoil_design_grad(sd_force, x, batch_size, num_boundaries, frames, p_min, p_max, lambda_force=1.0, lambda_overlap=1.0,
-                        downsampling_factor=4, parts=None):
-    """The airfoil design_fn of inference/inverse_design_2d.py:208-214 = force_fn (:98-132, sum_boundary = True) +
-    lambda_overlap * overlap_fn (:134-143), restated with torch autograd.  x [B * nb, 3 * frames + 3, 64, 64];
-    returns the gradient, same shape.  The script itself cannot be imported (it parses arguments and loads data at
-    import time), so this composition is anchored on its lines; ForceUnet.forward is pinned against the reference class."""
+                        downsampling_factor=4, parts=None, sum_boundary=True):
+    """The airfoil design_fn of inference/inverse_design_2d.py:208-214 = force_fn (:98-132) + lambda_overlap * overlap_fn
+    (:134-143), restated with torch autograd.  x [B * nb, 3 * frames + 3, 64, 64]; returns the gradient, same shape.
+    ``sum_boundary`` selects force_fn's branch: True (:100-120, the script's default) feeds the clamped SUM of a design's
+    boundaries and the pressure in simulator units; False (:122-130) each copy's own boundary and the normalised pressure.
+    The script itself cannot be imported (it parses arguments and loads data at import time); oracle/make_golden_r3.py
+    extracts these functions from its text and pins this restatement against them (PINNING_REPORT_R3.json)."""
     x = x.detach().clone().requires_grad_(True)
     H = x.shape[-1]
     boundary = x[:, -3:]
-    boundary = boundary.view(batch_size, num_boundaries, 3, H, H).sum(dim=1, keepdim=True).clamp(0., 1.) \
-        .expand(-1, num_boundaries, -1, -1, -1).reshape(batch_size * num_boundaries, 3, H, H)
+    if sum_boundary:
+        boundary = boundary.view(batch_size, num_boundaries, 3, H, H).sum(dim=1, keepdim=True).clamp(0., 1.) \
+            .expand(-1, num_boundaries, -1, -1, -1).reshape(batch_size * num_boundaries, 3, H, H)
     forces = []
     for i in range(frames):
-        pressure = (0.5 * x[:, 2 + 3 * i] + 0.5) * (p_max - p_min) + p_min
+        pressure = x[:, 2 + 3 * i]
+        if sum_boundary:
+            pressure = (0.5 * pressure + 0.5) * (p_max - p_min) + p_min
         ld = force_unet_forward(sd_force, torch.cat([pressure.unsqueeze(1), boundary], dim=1))
         forces.append(lambda_force * torch.abs(ld[:, 0]) + ld[:, 1])
     summed = torch.sum(torch.stack(forces, dim=0), dim=0)
+    if not sum_boundary:         # summed over the boundaries of a design, then expanded back (:128-129): the gradient of
+        summed = summed.view(batch_size, num_boundaries).sum(dim=1, keepdim=True).expand(-1, num_boundaries).reshape(-1)
     g_force = torch.autograd.grad(summed, x, grad_outputs=torch.ones_like(summed))[0]
     x2 = x.detach().clone().requires_grad_(True)
     xv = x2.view(batch_size, num_boundaries, -1, H, H)
@@ -1118,10 +1125,12 @@ class Diffusion2D:
     """What GaussianDiffusion (2-D) holds for sampling, model/diffusion_2d.py:552-676."""
 
     def __init__(self, sd, *, image_size=64, frames=6, timesteps=1000, beta_schedule="sigmoid", objective="pred_noise",
-                 standard_fixed_ratio=0.01, coeff_ratio=0.1, share_noise=True, use_average_share=True):
+                 standard_fixed_ratio=0.01, coeff_ratio=0.1, share_noise=True, use_average_share=True,
+                 forward_fixed_ratio=0.01, backward_steps=5, backward_lr=0.01):
         self.sd, self.image_size, self.frames = sd, image_size, frames
         self.num_timesteps, self.objective = timesteps, objective
         self.standard_fixed_ratio, self.coeff_ratio = standard_fixed_ratio, coeff_ratio
+        self.forward_fixed_ratio, self.backward_steps, self.backward_lr = forward_fixed_ratio, backward_steps, backward_lr
         self.share_noise, self.use_average_share = share_noise, use_average_share
         self.tab = make_schedule(beta_schedule, timesteps, objective)
         self.channels = sd["final_conv.weight"].shape[0]
@@ -1152,16 +1161,21 @@ def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard
     mean is computed ONCE, every iteration subtracts the raw design gradient taken at the current relaxed x
     (``model_mean - grad_design``, not the scaled ``grad_design_final``) and re-noises with ``recur_noise[r]``
     [B*nb, C, H, W].  Returns (x_{t-1}, x_start)."""
-    assert d.objective == "pred_noise" and d.share_noise
+    assert d.objective == "pred_noise"
     B, nb = shape[0], shape[1]
     T = d.tab
     tt = torch.full((x.shape[0],), t, dtype=torch.long)
     eps = unet2d_forward(d.sd, x, tt)
-    eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
+    if d.share_noise:            # model_predictions :732-733
+        eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
     x_start = T["sqrt_recip_alphas_cumprod"][t] * x - T["sqrt_recipm1_alphas_cumprod"][t] * eps
     if clip_denoised:
         x_start = x_start.clamp(-1.0, 1.0)
+    if not d.share_noise:        # p_mean_variance :762-763: the clamped x_start is shared instead ...
+        x_start = share_states_over_boundaries(x_start, B, nb, d.use_average_share)
     mean = T["posterior_mean_coef1"][t] * x_start + T["posterior_mean_coef2"][t] * x
+    if not d.share_noise:        # ... and so is the posterior mean (:769-770)
+        mean = share_states_over_boundaries(mean, B, nb, d.use_average_share)
     if "recurrence" in design_guidance:
         R = int(design_guidance.split("-")[-1])
         ratio = T["alphas_cumprod"] / T["alphas_cumprod_prev"]
@@ -1190,6 +1204,28 @@ def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard
         else:
             raise ValueError(design_guidance)
     return pred, x_start
+
+
+def p_sample_2d_universal(d, shape, x, t, noise, design_fn, design_guidance, clip_denoised=True):
+    """The non-recurrence "universal-forward" / "universal-backward" branches of p_sample, model/diffusion_2d.py:821-843:
+    the design gradient is taken at x_start (forward), or after ``backward_steps`` gradient steps on x_start (backward:
+    the kk == 1 gradient times forward_fixed_ratio, minus the schedule coefficient times the accumulated delta)."""
+    T = d.tab
+    base, x_start = p_sample_2d(d, shape, x, t, noise, None, "standard", clip_denoised)
+    if design_guidance == "universal-forward":
+        shift = d.forward_fixed_ratio * design_fn(x_start.clone())
+    elif design_guidance == "universal-backward":
+        xc, shift = x_start.clone(), None
+        for kk in range(d.backward_steps):
+            g = design_fn(xc.clone())
+            if kk == 1:
+                shift = d.forward_fixed_ratio * g
+            xc = xc - g * d.backward_lr
+        coef = (T["sqrt_alphas_cumprod"] * T["betas"] / (torch.sqrt(1 - T["betas"]) * (1 - T["alphas_cumprod"])))[t]
+        shift = shift - coef * (xc - x_start)
+    else:
+        raise ValueError(design_guidance)
+    return base - shift, x_start
 
 
 def p_sample_loop_2d(d, shape, tape_init, tape_steps, design_fn=None, design_guidance="standard", t_stop=0, record=None):

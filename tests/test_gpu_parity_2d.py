@@ -237,3 +237,36 @@ def test_unet2d_other_configurations(device, size, mults, ch, n, served):
     ref = O.unet2d_forward(sd, x, torch.full((n,), 412, dtype=torch.long))
     out = m(x.to(device), 412)
     assert rel(out, ref) < TOL_FWD
+
+
+# ------------------------------------------------------------------ round-3 goldens (oracle/make_golden_r3.py)
+@pytest.mark.parametrize("guid", ["universal-forward", "universal-backward"])
+def test_step2d_universal_guidance_golden(gold_dir, device, unet2d, guid):
+    """The non-recurrence "universal-forward" / "universal-backward" branches of p_sample (model/diffusion_2d.py:821-843):
+    design gradient at x_start, resp. after ``backward_steps`` gradient steps on it."""
+    g = np.load(os.path.join(gold_dir, "steps_2d_r3.npz"))
+    d = cindm_amd.GaussianDiffusion(unet2d[0], image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                    loss_type="l2", forward_fixed_ratio=0.05, backward_steps=3, backward_lr=0.02).to(device)
+    nz = O.sample_noise_2d(torch.from_numpy(g[guid + ".state"]), torch.from_numpy(g[guid + ".boundary"])).reshape(2, 21, 64, 64)
+    out, x0 = d.p_sample((1, 2, 21, 64, 64), torch.from_numpy(g[guid + ".x"]).to(device), 500, None, design_fn=design_grad,
+                         design_guidance=guid, noise=nz.to(device))
+    assert rel(out, g[guid + ".out"]) < TOL_STEP and rel(x0, g[guid + ".x0"]) < TOL_STEP
+
+
+@pytest.mark.parametrize("avg", [True, False], ids=["mean", "sum"])
+def test_step2d_share_noise_false_golden(gold_dir, device, unet2d, avg):
+    """share_noise=False (p_mean_variance :757-773): the clamped x_start and then the posterior mean are shared over the
+    boundary copies instead of the predicted noise -- steps at t = 640 and t = 0 against the reference's outputs, and a
+    short chain whose states stay shared."""
+    g = np.load(os.path.join(gold_dir, "steps_2d_r3.npz"))
+    tag = "noshare_avg" if avg else "noshare_sum"
+    d = cindm_amd.GaussianDiffusion(unet2d[0], image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                    loss_type="l2", share_noise=False, use_average_share=avg).to(device)
+    for t in (640, 0):
+        nz = O.sample_noise_2d(torch.from_numpy(g[f"{tag}.t{t}.state"]), torch.from_numpy(g[f"{tag}.t{t}.boundary"])).reshape(2, 21, 64, 64)
+        out, x0 = d.p_sample((1, 2, 21, 64, 64), torch.from_numpy(g[f"{tag}.t{t}.x"]).to(device), t, None, noise=nz.to(device))
+        assert rel(out, g[f"{tag}.t{t}.out"]) < TOL_STEP and rel(x0, g[f"{tag}.t{t}.x0"]) < TOL_STEP, (tag, t)
+    if avg:
+        ch = d.sample(batch_size=2, num_boundaries=2, seed=4, t_stop=995)
+        assert bool(torch.isfinite(ch).all()) and torch.equal(ch[:, 0, :-3], ch[:, 1, :-3])
+        assert torch.equal(ch, d.sample(batch_size=2, num_boundaries=2, seed=4, t_stop=995, use_graph=False))

@@ -29,6 +29,9 @@ PATHS_1D = [
     {"level0": 0},                        # no level kernels: per-layer launches at every level
     {"level1": 2},                        # two samples per workgroup in level1_down_kernel
     {"level1": 0}, {"ups_last": 0}, {"ups_tail": 0},
+    {"pingpong": 0},                      # step counter / exchange epochs advanced by step_counter_kernel (one more launch per step)
+    {"dconv2": 0},                        # deep-level blocks as two dconv_kernel launches (no in-launch all-gather)
+    {"dresample": 0},                     # deep-level resampling convolutions on conv_gemm_h3_kernel<3 | 4>
     {"dconv": 0},                         # deep levels on conv_gemm_h3_kernel
     {"dconv_pair": 0},                    # dconv only where GroupNorm groups are tile-local (C_out <= 256)
     {"attn_head": 0},                     # deep attention sites on attn1d_site_h3_kernel
@@ -146,18 +149,143 @@ def test_fused_update_equals_update_kernel(device, unet8, objective):
     d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000,
                                       objective=objective).to(device)
     tape = _tape(5, (19, 24, 8), 1000)
-    res = {}
+    res, info = {}, {}
     try:
         for v in (0, 1):
             m.set_option("fuse_update", v)
             res[v] = (d.sample(batch_size=19, n_composed=0, compose_n_bodies=2, seed=17, sample_offset=3, t_stop=985),
                       d.sample(batch_size=19, n_composed=0, compose_n_bodies=2, noise=tape, t_stop=985),
                       d.sample(batch_size=19, n_composed=0, compose_n_bodies=2, seed=17, sample_offset=3, t_stop=985, use_graph=False))
+            # the step the library actually emitted: with the switch on there is no compose_update_kernel launch
+            info[v] = d.last_step_info()
     finally:
         m.set_option("fuse_update", 1)
+    assert info[1][1] is True and info[0][1] is False, info
+    assert info[1][0] == info[0][0] - 1, info
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
     assert torch.equal(res[1][0], res[1][2])
+
+
+@pytest.mark.parametrize("mode", ["mean", "noise_sum", "mean-inside", "sum-inside"])
+def test_fused_update_every_single_window_mode(device, unet8, mode):
+    """sample() reaches the library as an OUTSIDE / INSIDE composition with one window and one pair, never as the plain
+    descriptor: each of those modes must take the fused update (round 2's switch only matched the plain descriptor, so it
+    never fired from sample()) and reproduce the separate kernel bit for bit."""
+    m, _ = unet8
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    out = {}
+    try:
+        for v in (0, 1):
+            m.set_option("fuse_update", v)
+            out[v] = d.sample(batch_size=7, n_composed=0, compose_n_bodies=2, compose_mode=mode, seed=3, t_stop=990)
+            assert d.last_step_info()[1] is bool(v), (mode, v)
+    finally:
+        m.set_option("fuse_update", 1)
+    assert torch.equal(out[0], out[1])
+    # composition over windows keeps the separate kernel
+    d.sample(batch_size=3, n_composed=1, compose_start_step=16, compose_n_bodies=2, compose_mode=mode, seed=3, t_stop=998)
+    assert d.last_step_info()[1] is False
+
+
+@pytest.mark.parametrize("cfg", ["plain", "windows", "multibody"])
+def test_pingpong_step_state(device, unet8, cfg):
+    """The plain sample loop keeps its step counter and exchange epochs in two slots; a step reads one and its own update
+    writes the other (no step_counter_kernel launch; the graph holds two steps, an odd count ends with a one-step graph).
+    Odd and even step counts, repeated calls on one handle, an eager forward in between: bit-identical to the
+    counter-kernel loop, one launch fewer per step, no exchange time-out."""
+    m, _ = unet8
+    if cfg == "multibody":
+        m4, _ = build_unet(device, F=4)
+        d = cindm_amd.GaussianDiffusion1D(m, image_size=20, conditioned_steps=4, timesteps=1000, sampling_timesteps=1000).to(device)
+        d.model_unconditioned = m4
+        cond = torch.rand((9, 4, 16), generator=torch.Generator().manual_seed(1)).to(device)
+        run = lambda n, **kw: d.sample_compose_multibodies(cond, n, 0, 4, seed=3, **kw)
+        steps = (7, 6)
+    else:
+        d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+        kw0 = dict(n_composed=0) if cfg == "plain" else dict(n_composed=2, compose_start_step=16, compose_mode="mean-inside")
+        run = lambda n, **kw: d.sample(batch_size=21, compose_n_bodies=2, seed=3, t_stop=1000 - n, **kw0, **kw)
+        steps = (7, 6, 1)
+    ref, info = {}, {}
+    try:
+        for pp in (0, 1):
+            m.set_option("pingpong", pp)
+            outs = []
+            for n in steps:
+                outs.append(run(n))
+                outs.append(run(n))                          # the cached graphs again
+                info[(pp, n)] = d.last_step_info()[0]
+                m(torch.zeros((3, 24, 8), device=device), torch.zeros((3,), device=device))      # an eager forward between loops
+            outs.append(run(steps[0], use_graph=False))
+            ref[pp] = outs
+    finally:
+        m.set_option("pingpong", 1)
+    for a, b in zip(ref[0], ref[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(ref[1][0], ref[1][1]) and torch.equal(ref[1][0], ref[1][-1])
+    for n in steps:
+        assert info[(1, n)] == info[(0, n)] - 1, info
+    assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
+
+
+def test_exchange_timeout_is_reported(device):
+    """A pair exchange whose partner never publishes (ablation dbg = 39: odd n-tiles of dconv_kernel skip their publish,
+    short spin bound) must surface as CindmError from forward(), from sample() and from the status call -- never as
+    silently wrong designs -- and the handle must work again afterwards."""
+    m, sd = build_unet(device)
+    m.set_option("auto_range", 0)           # (the calibration forward at finalize would hit the ablation too)
+    m.set_option("dbg", 39)
+    x = torch.randn((32, 24, 8), generator=torch.Generator().manual_seed(2)).to(device)
+    t = torch.full((32,), 500, device=device)
+    with pytest.raises(cindm_amd.CindmError, match="exchange"):
+        m(x, t)
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    with pytest.raises(cindm_amd.CindmError, match="exchange"):
+        d.sample(batch_size=32, n_composed=0, compose_n_bodies=2, seed=1, t_stop=997)
+    with pytest.raises(cindm_amd.CindmError, match="exchange"):
+        d.p_sample_compose_outside(x, None, 500, compose_mode="mean", n_composed=0, single_model_step=24, compose_n_bodies=2)
+    m.set_option("dbg", 0)
+    m.set_option("auto_range", 1)
+    ref = O.unet1d_forward(sd, x[:4].cpu(), torch.full((4,), 500, dtype=torch.long))
+    assert rel(m(x[:4].contiguous(), t[:4]), ref) < TOL_FWD
+
+
+@pytest.mark.parametrize("seed", [1, 7919])
+def test_stress_mode_1d(device, seed):
+    """Pseudo-random pauses in front of every in-kernel hand-over (option "stress" = seed: dconv_kernel's GroupNorm pair
+    exchange and its LDS reductions, attn1d_head_kernel's head exchange): the 256-row forward and a 768-row forward
+    (three residency waves) must equal the unstressed results bit for bit, with no exchange time-out."""
+    m, _ = build_unet(device)
+    res = {}
+    for rows in (256, 768):
+        x = torch.randn((rows, 24, 8), generator=torch.Generator().manual_seed(rows)).to(device)
+        t = torch.full((rows,), 421, device=device)
+        m.set_option("stress", 0)
+        ref = m(x, t)
+        m.set_option("stress", seed)
+        for it in range(2):
+            assert torch.equal(m(x, t), ref), (rows, seed, it)
+    m.set_option("stress", 0)
+
+
+@pytest.mark.parametrize("seed", [1, 7919])
+def test_stress_mode_2d(device, seed):
+    """The same for conv2d_ws_kernel's matrix / memory wave pipeline at the 128-image bench shape: pauses before each of
+    its barriers on both sides, block outputs bit-identical to the unstressed forward."""
+    from test_gpu_parity_2d import build_unet2d
+    m, _ = build_unet2d(device)
+    x = torch.randn((128, 21, 64, 64), generator=torch.Generator().manual_seed(3)).to(device)
+    t = torch.full((128,), 500, device=device)
+    names = ["downs.0.1", "downs.1.3", "mid_block1", "mid_block2", "ups.0.1", "ups.1.1", "final_res_block"]
+    y0 = m(x, t)
+    ref = {n: m.tap(n, 128).clone() for n in names}
+    m.set_option("stress", seed)
+    y1 = m(x, t)
+    for n in names:
+        assert torch.equal(m.tap(n, 128), ref[n]), (seed, n)
+    assert torch.equal(y1, y0)
+    m.set_option("stress", 0)
 
 
 def test_chains_repeatable_at_bench_shape(device, unet8):

@@ -122,3 +122,94 @@ def test_weight_scale_2d_vs_oracle(device, scale, fallback):
     out = m(x.to(device), 321)
     assert bool(torch.isfinite(out).all()) and rel(out, ref) < TOL_FWD
     assert m.get_option("range_fallback") in fallback
+
+
+# ------------------------------------------------------------------ ForceUnet (the surrogate of the airfoil objective)
+def _force(device, sd, **opts):
+    m = cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device)
+    for k, v in opts.items():
+        m.set_option(k, v)
+    return m
+
+
+def _force_ref(sd, x, lam, dtype=torch.float32):
+    xo = x.to(dtype).clone().requires_grad_(True)
+    y = O.force_unet_forward({k: v.to(dtype) for k, v in sd.items()}, xo)
+    return y.detach(), torch.autograd.grad((lam * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
+
+
+@pytest.mark.parametrize("scale,fallback", [(1.0e-4, (1,)), (8.0, (0,)), (1.0e3, (1,))])
+def test_forceunet_weight_scale_vs_oracle(device, scale, fallback):
+    """Every convolution weight of the surrogate x 1e-4 / x 8 / x 1e3.  Its 3x3 Block convolutions are weight-standardised (the
+    scale is removed when the weights are folded at finalize); the others scale the un-normalised residual stream those
+    convolutions read: x 1e-4 leaves the weight window (fallback 1), x 8 stays on the split-fp16 kernels, x 1e3 overflows
+    fp16 in the calibration forward (fallback 1).  Forward and input gradient within 2e-5 of the oracle's autograd on
+    every side; the gradient pass rescales by the gradient's own maximum."""
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+    # (scales > 1 leave the q | k | v projections alone: x 1e3 there turns every attention soft-max into a one-hot and the
+    # gradient into noise -- in the fp64 oracle too; what is under test is the range of the residual stream)
+    sd = {k: (v * scale if (v.dim() == 4 and (scale < 1 or "to_qkv" not in k)) else v) for k, v in sd.items()}
+    m = _force(device, sd)
+    x = torch.randn((2, 4, 64, 64), generator=torch.Generator().manual_seed(5))
+    out, dx = m.input_grad(x.to(device), lambda_force=0.9)
+    y, ref = _force_ref(sd, x, 0.9)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(dx).all())
+    # Scaling the q / k projections sharpens the attention soft-maxes: at x 8 the input gradient is ill-conditioned in fp32
+    # itself (the CPU oracle in fp32 is 6e-4 away from its own fp64 evaluation).  The bar is therefore the fp64 oracle, with
+    # the larger of 2e-5 and four times the fp32 oracle's own distance to it.
+    y64, ref64 = _force_ref(sd, x, 0.9, torch.float64)
+    tol_g = max(TOL_FWD, 4.0 * rel(ref.double(), ref64))
+    tol_y = max(TOL_FWD, 4.0 * rel(y.double(), y64))
+    assert rel(out.double(), y64) < tol_y and rel(dx.double(), ref64) < tol_g, (scale, tol_y, tol_g)
+    assert m.get_option("range_fallback") in fallback
+
+
+def test_forceunet_large_groupnorm_gain_vs_oracle(device):
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+    sd = {k: (v * 50.0 if k.endswith(".norm.weight") else v) for k, v in sd.items()}
+    m = _force(device, sd)
+    x = torch.randn((2, 4, 64, 64), generator=torch.Generator().manual_seed(6))
+    out, dx = m.input_grad(x.to(device), lambda_force=1.0)
+    y, ref = _force_ref(sd, x, 1.0)
+    y64, ref64 = _force_ref(sd, x, 1.0, torch.float64)
+    # gains of 50 amplify every rounding of the chain: the bar is the fp64 oracle, within the larger of 2e-5 and four times
+    # the fp32 oracle's own distance to it (measured: fp32 oracle 1e-5, HIP path 2.6e-5 against the fp32 oracle)
+    assert rel(out.double(), y64) < max(TOL_FWD, 4.0 * rel(y.double(), y64))
+    assert rel(dx.double(), ref64) < max(TOL_FWD, 4.0 * rel(ref.double(), ref64))
+    assert m.get_option("range_fallback") == 0
+
+
+def test_forceunet_pressure_in_simulator_units(device):
+    """Pressure channel of +-6e4 (the airfoil data set's de-normalised range is far smaller; this is the edge of fp16's
+    range).  The residual stream behind the fp32 stem then exceeds 65504 in places: the split-fp16 path must either agree
+    with the oracle or be LOUD (non-finite) -- never a silently wrong finite value -- and the fp32 path (h3 = h3_bwd = 0)
+    must agree."""
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+    x = torch.randn((2, 4, 64, 64), generator=torch.Generator().manual_seed(7))
+    x[:, 0] = x[:, 0] / x[:, 0].abs().max() * 6.0e4
+    y, ref = _force_ref(sd, x, 1.0)
+    m32 = _force(device, sd, h3=0, h3_bwd=0)
+    out32, dx32 = m32.input_grad(x.to(device), lambda_force=1.0)
+    assert rel(out32, y) < TOL_FWD and rel(dx32, ref) < TOL_FWD
+    m = _force(device, sd)
+    out, dx = m.input_grad(x.to(device), lambda_force=1.0)
+    if bool(torch.isfinite(out).all()) and bool(torch.isfinite(dx).all()):
+        assert rel(out, y) < TOL_FWD and rel(dx, ref) < TOL_FWD
+    # at the data set's own scale (p in [-37.7, 57.6]) the default path is exact
+    x[:, 0] = x[:, 0] / 6.0e4 * 57.6
+    y, ref = _force_ref(sd, x, 1.0)
+    out, dx = m.input_grad(x.to(device), lambda_force=1.0)
+    assert rel(out, y) < TOL_FWD and rel(dx, ref) < TOL_FWD
+
+
+def test_forceunet_auto_range_option(device):
+    """auto_range = 0 skips the calibration forward; the option round-trips and the default handle reports no fallback."""
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+    m = _force(device, sd, auto_range=0)
+    assert m.get_option("auto_range") == 0 and m.get_option("range_fallback") == 0
+    with pytest.raises(cindm_amd.CindmError, match="unknown option"):
+        m.set_option("range_fallback", 1)
+    with pytest.raises(cindm_amd.CindmError, match="unknown option"):
+        m.set_option("no_such_switch", 1)

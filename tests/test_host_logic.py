@@ -279,10 +279,27 @@ def test_synthetic_init_is_a_function_of_seed_and_name():
     assert abs(float(a["downs.0.0.blocks.0.block.2.weight"].mean()) - 1.0) < 0.05
 
 
+def test_get_item_1d_golden(gold_dir):
+    """cindm_amd.data_utils.get_item_1d against the output of the reference's own utils.get_item_1d (utils.py:203-222),
+    captured by oracle/make_golden_r3.py from the imported function on a synthetic PyG-like batch: bit-equal (a reshape and
+    one division by 200 of every feature)."""
+    import numpy as np
+    from cindm_amd.data_utils import get_item_1d, to_simulator_units
+    g = np.load(os.path.join(gold_dir, "get_item_1d.npz"))
+
+    class Batch(dict):
+        dyn_dims = [0, 0, 0]
+
+    y = torch.from_numpy(g["y"])
+    out = get_item_1d(Batch(y=y), "y")
+    assert tuple(out.shape) == tuple(g["out"].shape) == (3, 24, 16)
+    assert torch.equal(out, torch.from_numpy(g["out"]))
+    assert torch.allclose(to_simulator_units(out, 4), y, rtol=0, atol=2e-5)
+
+
 def test_get_item_1d_matches_reference_formula():
-    """cindm_amd.data_utils.get_item_1d == the reference's utils.get_item_1d (utils.py:203-222) on a synthetic PyG-like
-    batch (vector captured from the imported reference by oracle/make_golden_r2.py is not needed: the function is a pure
-    reshape / scale, restated here from the reference's docstring shapes), and to_simulator_units inverts it."""
+    """The layout in words: sample b, step s, body k, feature f of the diffusion tensor is field[b * n_bodies + k, s, f] / 200,
+    and to_simulator_units inverts it."""
     from cindm_amd.data_utils import get_item_1d, to_simulator_units
 
     class Batch(dict):

@@ -352,3 +352,40 @@ def test_force_unet_oracle_vs_golden(gold_dir):
     assert rel(gx, g["gx"]) < TOL
     gd = O.airfoil_design_grad(sd, torch.from_numpy(g["design.x"]), 1, 2, 2, p_min=-37.7, p_max=57.6)
     assert rel(gd, g["design.grad"]) < TOL
+
+
+# ------------------------------------------------------------------ round-3 pins (oracle/make_golden_r3.py)
+@pytest.mark.parametrize("tag,B,nb,frames,lf,lo,pmin,pmax,sb", [("sum_b1_nb2_f2", 1, 2, 2, 0.7, 2.0, -37.7, 57.6, True),
+                                                                 ("own_b1_nb2_f2", 1, 2, 2, 0.7, 2.0, -37.7, 57.6, False)])
+def test_design_glue_vs_reference_script(gold_dir, tag, B, nb, frames, lf, lo, pmin, pmax, sb):
+    """airfoil_design_grad against the gradients the reference SCRIPT's own force_fn / overlap_fn produced (its functions
+    were extracted from the script's text and run with the reference ForceUnet): both sum_boundary branches."""
+    g = np.load(os.path.join(gold_dir, "force_glue_2d.npz"))
+    sdf = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+    out = O.airfoil_design_grad(sdf, torch.from_numpy(g[tag + ".x"]), B, nb, frames, p_min=pmin, p_max=pmax, lambda_force=lf,
+                                lambda_overlap=lo, sum_boundary=sb)
+    assert rel(out, g[tag + ".grad"]) < TOL
+
+
+def test_steps_2d_round3(gold_dir, sd2d):
+    """universal-forward / universal-backward guidance (:821-843) and share_noise=False (:757-773) single steps."""
+    from test_gpu_parity_2d import design_grad
+    g = np.load(os.path.join(gold_dir, "steps_2d_r3.npz"))
+    shape = (1, 2, 21, 64, 64)
+    od = O.Diffusion2D(sd2d, image_size=64, frames=6, forward_fixed_ratio=0.05, backward_steps=3, backward_lr=0.02)
+    for guid in ("universal-forward", "universal-backward"):
+        nz = O.sample_noise_2d(torch.from_numpy(g[guid + ".state"]), torch.from_numpy(g[guid + ".boundary"])).reshape(2, 21, 64, 64)
+        out, x0 = O.p_sample_2d_universal(od, shape, torch.from_numpy(g[guid + ".x"]), 500, nz, design_grad, guid)
+        assert rel(out, g[guid + ".out"]) < TOL and rel(x0, g[guid + ".x0"]) < TOL, guid
+    odn = O.Diffusion2D(sd2d, image_size=64, frames=6, share_noise=False, use_average_share=False)
+    nz = O.sample_noise_2d(torch.from_numpy(g["noshare_sum.t640.state"]), torch.from_numpy(g["noshare_sum.t640.boundary"])).reshape(2, 21, 64, 64)
+    out, x0 = O.p_sample_2d(odn, shape, torch.from_numpy(g["noshare_sum.t640.x"]), 640, nz)
+    assert rel(out, g["noshare_sum.t640.out"]) < TOL and rel(x0, g["noshare_sum.t640.x0"]) < TOL
+
+
+def test_pinning_report_round3(gold_dir):
+    with open(os.path.join(gold_dir, "PINNING_REPORT_R3.json")) as f:
+        rep = json.load(f)
+    for k in ("glue.sum_b1_nb2_f2", "glue.sum_b2_nb3_f1", "glue.own_b1_nb2_f2", "guided_chain_2d", "step2d.universal-forward",
+              "step2d.universal-backward", "step2d.noshare_avg", "step2d.noshare_sum", "get_item_1d"):
+        assert rep[k] <= 2e-6, (k, rep[k])

@@ -33,7 +33,11 @@ def main():
                   "hbm_bytes_per_launch": round(rd + wr)}
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # reverse steps the traced command ran (incl. warm-up)
     per_step = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in out.values()) / steps) if steps else None
-    json.dump({"bytes_per_step": per_step, "steps_traced": steps, "note": "FETCH_SIZE (KiB) x2 (gfx950: reports half of wide coalesced reads) + WRITE_SIZE (KiB), mean per launch; "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cindm_amd import build as _b
+    # the hash of the sources the measured library was built from: bench.py drops these numbers when it loads another one
+    json.dump({"bytes_per_step": per_step, "steps_traced": steps, "source_hash": _b.embedded_hash() or _b.source_hash(), "note": "FETCH_SIZE (KiB) x2 (gfx950: reports half of wide coalesced reads) + WRITE_SIZE (KiB), mean per launch; "
                        "Infinity-Cache hits are included in these memory-side counters", "kernels": out}, sys.stdout, indent=1)
 
 
