@@ -181,6 +181,7 @@ static const OptDef kUnet1dOpts[] = {
     {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
+    {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled (0: every intermediate keeps its own)
     {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
     {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
     {"dconv2", 1, "CINDM_DCONV2"},     // a whole deep-level ResidualTemporalBlock per launch (dconv2_kernel: in-launch all-gather between its convolutions)
@@ -590,7 +591,8 @@ static void pack_vec(cindm_unet1d* h, BlobBuilder& bb, const std::string& key) {
     } while (0)
 
 // ---- launch helpers ---------------------------------------------------------------------------
-struct Ten { float* p = nullptr; int L = 0, C = 0, ld = 0; uint4* pl = nullptr; size_t pst = 0; };   // pl: tiled split-fp16 planes (dconv_kernel)
+struct Ten { float* p = nullptr; int L = 0, C = 0, ld = 0; uint4* pl = nullptr; size_t pst = 0;   // pl: tiled split-fp16 planes (dconv_kernel)
+             size_t off_p = ~(size_t)0, sz_p = 0, off_pl = ~(size_t)0, sz_pl = 0; };      // workspace blocks behind p / pl (none: caller's memory)
 
 struct Emitter {
     cindm_unet1d* h;
@@ -657,6 +659,7 @@ struct Emitter {
         const size_t tiles = (size_t)((rows + S - 1) / S);
         t.pst = tiles * (size_t)(t.C / 32) * 192;
         t.pl = reinterpret_cast<uint4*>(alloc(t.pst * 2 * 4));
+        t.off_pl = last_off; t.sz_pl = last_bytes;
     }
     // the in-kernel exchanges of one forward are tagged with its epoch: advance it once, before the first of them
     void need_epoch() {
@@ -667,9 +670,8 @@ struct Emitter {
         if (!dry) hipLaunchKernelGGL(dconv_epoch_kernel, dim3(1), dim3(64), 0, stream, h->epoch_dev);
     }
     unsigned long long* xchg(size_t granules) {
-        const size_t off = ws_off;
-        float* p = alloc(granules * 2);
-        if (xregions) xregions->push_back({off, granules * 8});
+        float* p = alloc(granules * 2, false);
+        if (xregions) xregions->push_back({last_off, granules * 8});
         return reinterpret_cast<unsigned long long*>(p);
     }
 
@@ -684,12 +686,31 @@ struct Emitter {
     }
     void prof_end() { prof_cur = nullptr; }
 
-    float* alloc(size_t nfloats) {
-        size_t o = ws_off;
-        ws_off += ((nfloats * sizeof(float) + 255) / 256) * 256;
+    // Workspace blocks.  On the sampling path (option "taps" = 0, "ws_alias" = 1) a block goes back to a free list when the
+    // last launch that reads it has been emitted (drop): launches execute in stream order, so a later launch can only
+    // overwrite what every earlier launch has finished with.  Every activation of this U-Net has C * L = 1536 floats per row,
+    // so exact-size reuse finds a block almost always: the live set is the current tensor, the skips and a block's
+    // temporaries -- 157 MB -> ~20 MB at 256 rows, which keeps weights + activations of the 768 / 1280-row configurations inside
+    // the 256 MiB Infinity Cache.  With "taps" = 1 every intermediate keeps its own block (the tap API reads them afterwards).
+    // Exchange regions (xchg) are never recycled: their words are tags.
+    std::multimap<size_t, size_t> free_blocks;       // bytes -> offset
+    bool reuse = false;
+    size_t last_off = 0, last_bytes = 0;
+    float* alloc(size_t nfloats, bool recyclable = true) {
+        const size_t bytes = ((nfloats * sizeof(float) + 255) / 256) * 256;
+        size_t o;
+        auto it = (reuse && recyclable) ? free_blocks.find(bytes) : free_blocks.end();
+        if (it != free_blocks.end()) { o = it->second; free_blocks.erase(it); }
+        else { o = ws_off; ws_off += bytes; }
+        last_off = o; last_bytes = bytes;
         return dry ? nullptr : reinterpret_cast<float*>(ws + o);
     }
-    Ten ten(int L, int C) { Ten t; t.L = L; t.C = C; t.ld = C; t.p = alloc((size_t)rows * L * C); return t; }
+    void drop_block(size_t off, size_t bytes) { if (reuse && off != ~(size_t)0 && bytes) free_blocks.insert({bytes, off}); }
+    void drop(Ten& t) { drop_block(t.off_p, t.sz_p); drop_block(t.off_pl, t.sz_pl); t.off_p = t.off_pl = ~(size_t)0; }
+    struct Tmp { size_t off, bytes; };
+    float* tmp(size_t nfloats, Tmp& k) { float* p = alloc(nfloats); k = {last_off, last_bytes}; return p; }
+    void drop(const Tmp& k) { drop_block(k.off, k.bytes); }
+    Ten ten(int L, int C) { Ten t; t.L = L; t.C = C; t.ld = C; t.p = alloc((size_t)rows * L * C); t.off_p = last_off; t.sz_p = last_bytes; return t; }
     const float* W(const Packed& pk) const { return h->blob + pk.off; }
     const float* B(const Packed& pk) const { return pk.has_bias ? h->blob + pk.bias_off : nullptr; }
     const float* V(const std::string& k) const { return h->blob + h->vec_off.at(k); }
@@ -797,7 +818,7 @@ struct Emitter {
         if (e != hipSuccess && err == hipSuccess) err = e;
     }
     void tap(const std::string& name, const Ten& t) {
-        if (dry) return;
+        if (dry || reuse) return;            // (recycled workspace: an intermediate may be overwritten before the forward ends)
         h->taps[name] = {(size_t)(reinterpret_cast<char*>(t.p) - ws), t.L, t.C, t.ld};
     }
 };
@@ -888,7 +909,7 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
                            r.off[1] = w1.off * 4; r.bytes[1] = (unsigned)t1; r.stride[1] = (unsigned)t1; }
         else { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)std::min(w0.sz * 4, (size_t)2 << 20); }
         Pf pf; E.pf_step(pf, r);
-        if (E.dry) { E.tap(p, out); return out; }
+        if (E.dry) { E.drop(y0); return out; }
         Dconv2Args d;
         std::memset(&d, 0, sizeof(d));
         d.pf = pf;
@@ -928,6 +949,7 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
         hipError_t e = hipGetLastError();
         if (e != hipSuccess && E.err == hipSuccess) E.err = e;
     }
+    E.drop(y0);
     E.tap(p, out);
     return out;
 }
@@ -981,6 +1003,8 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
     pair_setup(d);
     E.pf_tiled(d.pf, w1, NT);
     dconv_launch(E, L, cout / 128, 0, false, d, 2.0 * Bp * L * cout * (double)cout * 5.0);
+    E.drop(y0);
+    if (!identity) E.drop(r);
     E.tap(p, out);
     return out;
 }
@@ -997,9 +1021,10 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
     const float cnt = (float)(L * (gw < TN ? gw : TN));
     const Packed& w0 = h->packed.at(p + ".blocks.0.block.0");
     const Packed& w1 = h->packed.at(p + ".blocks.1.block.0");
-    Ten y0 = E.ten(L, cout), y1 = E.ten(L, cout), out = E.ten(L, cout);
-    float* st0 = E.alloc((size_t)Bp * 8 * Pn * 2);
-    float* st1 = E.alloc((size_t)Bp * 8 * Pn * 2);
+    Ten out = E.ten(L, cout), y0 = E.ten(L, cout), y1 = E.ten(L, cout);
+    Emitter::Tmp k0, k1;
+    float* st0 = E.tmp((size_t)Bp * 8 * Pn * 2, k0);
+    float* st1 = E.tmp((size_t)Bp * 8 * Pn * 2, k1);
     GemmArgs a;
     // GroupNorm groups inside one 32-column tile (cout <= 256): the producers normalise + activate their own output
     const bool local_gn = gw <= TN && h->use_local_gn;
@@ -1043,6 +1068,8 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
         a.out = out.p; a.ldo = out.ld;
         if (want_ln) { *ln_out = E.alloc((size_t)Bp * L * (ceil_to(cout, TN) / TN) * 2); a.ln_out = *ln_out; }
         E.launch(5, a);
+        E.drop(y0); E.drop(y1); E.drop(k0); E.drop(k1);
+        if (fused_res) E.drop(r);
         E.tap(p, out);
         return out;
     }
@@ -1065,6 +1092,8 @@ static Ten emit_rtb(Emitter& E, const std::string& p, const Ten& x0, const Ten* 
     a.out = out.p; a.ldo = out.ld;
     if (want_ln) { *ln_out = E.alloc((size_t)Bp * L * (ceil_to(cout, TN) / TN) * 2); a.ln_out = *ln_out; }
     E.launch((identity || fused_res) ? 0 : 1, a);
+    E.drop(y0); E.drop(y1); E.drop(k0); E.drop(k1);
+    if (fused_res) E.drop(r);
     E.tap(p, out);
     return out;
 }
@@ -1078,7 +1107,6 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
     const int Bp = (int)E.rows, L = x.L, C = x.C;
     const Packed& wq = h->packed.at(p + ".fn.fn.to_qkv");
     const Packed& wo = h->packed.at(p + ".fn.fn.to_out");
-    Ten qkv = E.ten(L, 384), att = E.ten(L, 128), out = E.ten(L, C);
     GemmArgs a;
     auto site = h->packed.find(p + ".fn.fn.to_qkv#site");
     if (site != h->packed.end() && site->second.h3 && h->O("attn_head") && (C == 512 || (C == 256 && (L <= 4 || h->O("attn_head") > 1))) && L <= 16 && x.ld == C) {
@@ -1160,6 +1188,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
         E.tap(p, out);
         return out;
     }
+    Ten out = E.ten(L, C), qkv = E.ten(L, 384), att = E.ten(L, 128);       // three-launch path: q|k|v and the attention output are temporaries
     auto wide = h->packed.find(p + ".fn.fn.to_qkv#wide");
     if (wide != h->packed.end()) {
         // shallow levels (C = 64 / 128): 64-row tiles, the LayerNorm-ed input tile staged once per workgroup and its
@@ -1217,6 +1246,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
     a.res = x.p; a.ldres = x.ld;
     a.out = out.p; a.ldo = out.ld;
     E.launch(1, a);
+    E.drop(qkv); E.drop(att);
     E.tap(p, out);
     return out;
 }
@@ -1271,6 +1301,11 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
     Ten cur; cur.p = const_cast<float*>(x); cur.L = d.horizon; cur.C = d.transition_dim; cur.ld = d.transition_dim;
     std::vector<Ten> skips;
     float* lnp = nullptr;
+    E.reuse = !taps && h->O("ws_alias") != 0;
+    E.free_blocks.clear();
+    bool cur_is_skip = false;
+    // the chain moves on: the tensor left behind is dead unless it is a skip (or the caller's input)
+    auto move_to = [&](const Ten& next, bool next_is_skip = false) { if (!cur_is_skip) E.drop(cur); cur = next; cur_is_skip = next_is_skip; };
     // LayerNorm row partials from the producer are only needed where the attention site is not one fused launch
     auto need_ln = [&](const std::string& ap, int L) { return att && !(h->packed.count(ap + ".fn.fn.to_qkv#site") && L <= 32); };
     for (int ind = 0; ind < nres; ++ind) {
@@ -1280,7 +1315,9 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             h->packed.at("downs.0.2.fn.fn.to_qkv#site").h3 && cur.ld == cur.C) {
             // the whole level in one launch (level0_down_kernel)
             const int L = cur.L;
-            Ten h1 = E.ten(L, 64), h2 = E.ten(L, 64), sk = E.ten(L, 64), dn = E.ten(L / 2, 64);
+            Ten h1, h2;
+            if (taps) { h1 = E.ten(L, 64); h2 = E.ten(L, 64); }
+            Ten sk = E.ten(L, 64), dn = E.ten(L / 2, 64);
             ++E.launches;
             Pf pfl;
             E.pf_all(pfl, {&h->packed.at("downs.0.0.blocks.0.block.0#lvl"), &h->packed.at("downs.0.0.blocks.1.block.0#lvl"),
@@ -1314,14 +1351,16 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             if (taps) { E.tap("downs.0.0", h1); E.tap("downs.0.1", h2); }
             E.tap("downs.0.2", sk); E.tap("downs.0.3", dn);
             skips.push_back(sk);
-            cur = dn;
+            move_to(dn);
             continue;
         }
         const int lvl1 = h->O("level1");      // samples per workgroup: 1 (default) or 2; 0 = off
         if (ind == 1 && lvl1 && h->level1_ok && att && cur.L <= 16 && (cur.L & 1) == 0 && cur.C == 64 && cur.ld == 64 &&
             h->packed.count("downs.1.2.fn.fn.to_qkv#site") && h->packed.at("downs.1.2.fn.fn.to_qkv#site").h3) {
             const int L = cur.L;
-            Ten h1 = E.ten(L, 128), h2 = E.ten(L, 128), sk = E.ten(L, 128), dn = E.ten(L / 2, 128);
+            Ten h1, h2;
+            if (taps) { h1 = E.ten(L, 128); h2 = E.ten(L, 128); }
+            Ten sk = E.ten(L, 128), dn = E.ten(L / 2, 128);
             ++E.launches;
             Pf pfl;
             E.pf_all(pfl, {&h->packed.at("downs.1.0.blocks.0.block.0#lvl"), &h->packed.at("downs.1.0.blocks.1.block.0#lvl"),
@@ -1358,18 +1397,20 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             if (taps) { E.tap("downs.1.0", h1); E.tap("downs.1.1", h2); }
             E.tap("downs.1.2", sk); E.tap("downs.1.3", dn);
             skips.push_back(sk);
-            cur = dn;
+            move_to(dn);
             continue;
         }
-        cur = emit_rtb(E, p + ".0", cur, nullptr, co, false, nullptr);
-        cur = emit_rtb(E, p + ".1", cur, nullptr, co, need_ln(p + ".2", cur.L), &lnp);
-        if (att) cur = emit_attn(E, p + ".2", cur, lnp);
+        move_to(emit_rtb(E, p + ".0", cur, nullptr, co, false, nullptr));
+        move_to(emit_rtb(E, p + ".1", cur, nullptr, co, need_ln(p + ".2", cur.L), &lnp));
+        if (att) move_to(emit_attn(E, p + ".2", cur, lnp));
         skips.push_back(cur);
-        if (h->packed.count(p + ".3.conv")) cur = emit_resample(E, p + ".3", cur, false);
+        cur_is_skip = true;
+        if (h->packed.count(p + ".3.conv")) move_to(emit_resample(E, p + ".3", cur, false));
     }
-    cur = emit_rtb(E, "mid_block1", cur, nullptr, h->dims[nres], need_ln("mid_attn", cur.L), &lnp);
-    if (att) cur = emit_attn(E, "mid_attn", cur, lnp);
-    cur = emit_rtb(E, "mid_block2", cur, nullptr, h->dims[nres], false, nullptr);
+    // (the last down level has no resampling: its skip is also the tensor the middle blocks read, and stays a skip)
+    move_to(emit_rtb(E, "mid_block1", cur, nullptr, h->dims[nres], need_ln("mid_attn", cur.L), &lnp));
+    if (att) move_to(emit_attn(E, "mid_attn", cur, lnp));
+    move_to(emit_rtb(E, "mid_block2", cur, nullptr, h->dims[nres], false, nullptr));
     for (int ind = 0; ind < nres - 1; ++ind) {
         const int ci = h->dims[nres - 1 - ind], co = h->dims[nres - ind];
         const std::string p = "ups." + std::to_string(ind);
@@ -1380,7 +1421,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             h->packed.count(p + ".2.fn.fn.to_qkv#site") && h->packed.at(p + ".2.fn.fn.to_qkv#site").h3 && h->packed.count(p + ".3.conv")) {
             // the level and the output head in one launch (ups_last_kernel)
             const int L = cur.L;
-            Ten h1 = E.ten(L, 128), h2 = E.ten(L, 64), h3 = E.ten(L, 64), up = E.ten(2 * L, 64), ypre = E.ten(2 * L, 64);
+            Ten h1, h2, h3, up, ypre;
+            if (taps) { h1 = E.ten(L, 128); h2 = E.ten(L, 64); h3 = E.ten(L, 64); up = E.ten(2 * L, 64); ypre = E.ten(2 * L, 64); }
             ++E.launches;
             Pf pfl;
             E.pf_all(pfl, {&h->packed.at(p + ".0.blocks.0.block.0#lvl"), &h->packed.at(p + ".0.blocks.1.block.0#lvl"), &h->packed.at(p + ".0.residual_conv#lvl"),
@@ -1415,13 +1457,16 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             if (taps) { E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre); }
             return 0;
         }
-        cur = emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr);       // torch.cat((x, h.pop()), dim=1) :637
+        move_to(emit_rtb(E, p + ".0", cur, &skip, co, false, nullptr));       // torch.cat((x, h.pop()), dim=1) :637
+        E.drop(skip);
         const int upt = h->O("ups_tail");
         if (upt && ind == nres - 3 && h->ups_tail_ok && att && cur.L <= 8 && cur.C == 256 && cur.ld == 256 && ci == 128 &&
             h->packed.count(p + ".2.fn.fn.to_qkv#site") && h->packed.at(p + ".2.fn.fn.to_qkv#site").h3 && h->packed.count(p + ".3.conv")) {
             // the rest of the level in one launch (ups_tail128_kernel)
             const int L = cur.L;
-            Ten h2 = E.ten(L, 128), h3 = E.ten(L, 128), up = E.ten(2 * L, 128);
+            Ten h2, h3;
+            if (taps) { h2 = E.ten(L, 128); h3 = E.ten(L, 128); }
+            Ten up = E.ten(2 * L, 128);
             ++E.launches;
             Pf pfl;
             E.pf_all(pfl, {&h->packed.at(p + ".1.blocks.0.block.0#lvl"), &h->packed.at(p + ".1.blocks.1.block.0#lvl"),
@@ -1450,12 +1495,12 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
             }
             if (taps) { E.tap(p + ".1", h2); E.tap(p + ".2", h3); }
             E.tap(p + ".3", up);
-            cur = up;
+            move_to(up);
             continue;
         }
-        cur = emit_rtb(E, p + ".1", cur, nullptr, ci, need_ln(p + ".2", cur.L), &lnp);
-        if (att) cur = emit_attn(E, p + ".2", cur, lnp);
-        if (h->packed.count(p + ".3.conv")) cur = emit_resample(E, p + ".3", cur, true);
+        move_to(emit_rtb(E, p + ".1", cur, nullptr, ci, need_ln(p + ".2", cur.L), &lnp));
+        if (att) move_to(emit_attn(E, p + ".2", cur, lnp));
+        if (h->packed.count(p + ".3.conv")) move_to(emit_resample(E, p + ".3", cur, true));
     }
     // final_conv: Conv1dBlock(dim, dim, 5) then Conv1d(dim, F, 1) (:605-608)
     {

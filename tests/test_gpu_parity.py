@@ -90,11 +90,21 @@ def test_unet_blocks_golden(gold_dir, device, unet8):
             assert rel(m.tap(k, 2), g["tap." + k]) < TOL_FWD, k
     finally:
         m.set_option("taps", 0)
-    # the sampling configuration (no tap stores) computes the same prediction bit for bit and still serves the skips
+    # the sampling configuration (no tap stores, dead intermediates' workspace recycled) computes the same prediction bit for
+    # bit; it serves no taps at all (a block may have been overwritten before the forward ended)
     assert torch.equal(m(x, torch.full((2,), 500, device=device)), out)
-    assert rel(m.tap("downs.0.2", 2), g["tap.downs.0.2"]) < TOL_FWD
-    with pytest.raises(cindm_amd.CindmError):
-        m.tap("downs.0.0", 2)
+    for k in ("downs.0.2", "downs.0.0", "mid_block1"):
+        with pytest.raises(cindm_amd.CindmError):
+            m.tap(k, 2)
+    # ... and with recycling off the intermediates that reach HBM anyway (skips, deep-level blocks) can be read again
+    m.set_option("ws_alias", 0)
+    try:
+        assert torch.equal(m(x, torch.full((2,), 500, device=device)), out)
+        assert rel(m.tap("downs.0.2", 2), g["tap.downs.0.2"]) < TOL_FWD
+        with pytest.raises(cindm_amd.CindmError):
+            m.tap("downs.0.0", 2)
+    finally:
+        m.set_option("ws_alias", 1)
 
 
 @pytest.mark.parametrize("hz,F,att,key,xkey", [(24, 4, True, "eps_f4_t321", "x_f4"), (24, 16, True, "eps_f16_t321", "x_f16"),

@@ -29,6 +29,7 @@ PATHS_1D = [
     {"level0": 0},                        # no level kernels: per-layer launches at every level
     {"level1": 2},                        # two samples per workgroup in level1_down_kernel
     {"level1": 0}, {"ups_last": 0}, {"ups_tail": 0},
+    {"ws_alias": 0},                      # every intermediate keeps its own workspace block on the sampling path too
     {"pingpong": 0},                      # step counter / exchange epochs advanced by step_counter_kernel (one more launch per step)
     {"dconv2": 0},                        # deep-level blocks as two dconv_kernel launches (no in-launch all-gather)
     {"dresample": 0},                     # deep-level resampling convolutions on conv_gemm_h3_kernel<3 | 4>
@@ -227,6 +228,35 @@ def test_pingpong_step_state(device, unet8, cfg):
     for n in steps:
         assert info[(1, n)] == info[(0, n)] - 1, info
     assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
+
+
+def test_workspace_recycling(device, unet8):
+    """On the sampling path the workspace blocks of dead intermediates are recycled: a fraction of the bytes, the same bits."""
+    m, _ = unet8
+    L = cindm_amd._ffi.lib()
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    size, out = {}, {}
+    try:
+        for v in (0, 1):
+            m.set_option("ws_alias", v)
+            m.sync_weights()
+            size[v] = L.cindm_unet1d_workspace_bytes(m._h, 768)
+            out[v] = (d.sample(batch_size=37, n_composed=0, compose_n_bodies=2, seed=2, t_stop=988),
+                      d.sample(batch_size=5, n_composed=2, compose_start_step=16, compose_mode="mean-inside", seed=2, t_stop=994))
+    finally:
+        m.set_option("ws_alias", 1)
+    assert size[1] < 0.4 * size[0], size
+    assert size[1] < 120 << 20, size                     # 768 rows (config 3): weights (83 MB) + activations stay inside the 256 MiB Infinity Cache
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    x = torch.randn((19, 24, 8), generator=torch.Generator().manual_seed(5)).to(device)
+    t = torch.full((19,), 611, device=device)
+    y1 = m(x, t)
+    m.set_option("ws_alias", 0)
+    try:
+        assert torch.equal(m(x, t), y1)
+    finally:
+        m.set_option("ws_alias", 1)
 
 
 def test_exchange_timeout_is_reported(device):
