@@ -181,7 +181,7 @@ static const OptDef kUnet1dOpts[] = {
     {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
-    {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled (0: every intermediate keeps its own)
+    {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled: 0 never, 1 above 320 rows, 2 always
     {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
     {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
     {"dconv2", 1, "CINDM_DCONV2"},     // a whole deep-level ResidualTemporalBlock per launch (dconv2_kernel: in-launch all-gather between its convolutions)
@@ -1301,7 +1301,10 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
     Ten cur; cur.p = const_cast<float*>(x); cur.L = d.horizon; cur.C = d.transition_dim; cur.ld = d.transition_dim;
     std::vector<Ten> skips;
     float* lnp = nullptr;
-    E.reuse = !taps && h->O("ws_alias") != 0;
+    // "ws_alias": 0 never, 2 always, 1 (default) when the un-recycled workspace would not fit the Infinity Cache next to the
+    // weights (more than 320 rows: 0.6 MB per row + 83 MB against 256 MiB).  Measured same-box: 768 rows (config 3) 918 -> 910 us
+    // per step, 768 + 512 rows (config 4) 647 -> 628; at 256 rows recycling COSTS 3 us per step (364.6 -> 367.5), so it stays off there.
+    E.reuse = !taps && (h->O("ws_alias") == 2 || (h->O("ws_alias") == 1 && E.rows > 320));
     E.free_blocks.clear();
     bool cur_is_skip = false;
     // the chain moves on: the tensor left behind is dead unless it is a skip (or the caller's input)

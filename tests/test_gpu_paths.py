@@ -29,7 +29,7 @@ PATHS_1D = [
     {"level0": 0},                        # no level kernels: per-layer launches at every level
     {"level1": 2},                        # two samples per workgroup in level1_down_kernel
     {"level1": 0}, {"ups_last": 0}, {"ups_tail": 0},
-    {"ws_alias": 0},                      # every intermediate keeps its own workspace block on the sampling path too
+    {"ws_alias": 2},                      # dead intermediates' workspace blocks recycled at every batch size (default: above 320 rows)
     {"pingpong": 0},                      # step counter / exchange epochs advanced by step_counter_kernel (one more launch per step)
     {"dconv2": 0},                        # deep-level blocks as two dconv_kernel launches (no in-launch all-gather)
     {"dresample": 0},                     # deep-level resampling convolutions on conv_gemm_h3_kernel<3 | 4>
@@ -237,7 +237,7 @@ def test_workspace_recycling(device, unet8):
     d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
     size, out = {}, {}
     try:
-        for v in (0, 1):
+        for v in (0, 2):
             m.set_option("ws_alias", v)
             m.sync_weights()
             size[v] = L.cindm_unet1d_workspace_bytes(m._h, 768)
@@ -245,14 +245,17 @@ def test_workspace_recycling(device, unet8):
                       d.sample(batch_size=5, n_composed=2, compose_start_step=16, compose_mode="mean-inside", seed=2, t_stop=994))
     finally:
         m.set_option("ws_alias", 1)
-    assert size[1] < 0.4 * size[0], size
-    assert size[1] < 120 << 20, size                     # 768 rows (config 3): weights (83 MB) + activations stay inside the 256 MiB Infinity Cache
-    for a, b in zip(out[0], out[1]):
+    assert size[2] < 0.4 * size[0], size
+    assert size[2] < 120 << 20, size                     # 768 rows (config 3): weights (83 MB) + activations stay inside the 256 MiB Infinity Cache
+    for a, b in zip(out[0], out[2]):
         assert torch.equal(a, b)
+    m.set_option("ws_alias", 1)
+    m.sync_weights()
+    assert L.cindm_unet1d_workspace_bytes(m._h, 768) == size[2] and L.cindm_unet1d_workspace_bytes(m._h, 256) > size[2]     # automatic above 320 rows
     x = torch.randn((19, 24, 8), generator=torch.Generator().manual_seed(5)).to(device)
     t = torch.full((19,), 611, device=device)
     y1 = m(x, t)
-    m.set_option("ws_alias", 0)
+    m.set_option("ws_alias", 2)
     try:
         assert torch.equal(m(x, t), y1)
     finally:
