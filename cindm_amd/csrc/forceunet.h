@@ -321,23 +321,31 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
     if (beta != 0.f) { const float4 o = reinterpret_cast<float4*>(dx)[i]; v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
     reinterpret_cast<float4*>(dx)[i] = v;
     if (amax) {
-        // max |dx| over THIS IMAGE, as a bit pattern (monotone for non-negative floats; a maximum does not depend on the
-        // order: the result repeats bit for bit; per image, so that an image's gradient does not depend on what else is in
-        // the batch).  A workgroup's 1024 elements lie inside one image.  One atomic per workgroup, and only while it still
-        // raises the value.
+        // max |dx| of this workgroup's 1024 elements (they lie inside one image) -> pmax[workgroup]; fu_amax_reduce_kernel folds
+        // an image's workgroups into amax[image].  (One device-scope atomic maximum per workgroup on a per-image word was
+        // tried first: the workgroups of an image start together, all see the initial zero and all issue the atomic -- 196 000
+        // of them per launch at the 64 x 64 level, 1.1 ms per launch, 23 ms per design-gradient call.  A maximum does not
+        // depend on the order either way: the result repeats bit for bit.)
         float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (!(m <= 3.0e38f)) m = 3.0e38f;                                 // inf / nan: saturate (the products are garbage either way)
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         __shared__ float wm[4];
         if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
-            unsigned* am = amax + (int)(((int64_t)blockIdx.x * 256) / ((int64_t)HW * f4));
-            if (mb > __hip_atomic_load(am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_fetch_max(am, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (threadIdx.x == 0) amax[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
     }
+}
+
+// amax[img] = max over the image's `per` workgroup maxima (bit patterns of non-negative floats order like the floats)
+__global__ __launch_bounds__(256) void fu_amax_reduce_kernel(const unsigned* __restrict__ pmax, unsigned* __restrict__ amax, int per) {
+    __shared__ unsigned wm[4];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    unsigned m = 0u;
+    for (int i = tid; i < per; i += 256) m = max(m, pmax[(size_t)img * per + i]);
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((tid & 63) == 0) wm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) amax[img] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -251,14 +251,24 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     // and its tile is written times the inverse: both exact -- and a function of that image alone, so its gradient does
     // not depend on the rest of the batch (PAIR kind: the two images of a tile share the larger of their two maxima).
     // a.res (may alias a.out: every element is read by the thread that writes it) is added.
+    // The maxima are LOADED with the item's window (load_item) / the tile's addend (load_acc) and only turned into scales
+    // where the loaded data is consumed anyway (store_item / write_tile): a wait on them at the point of the load would
+    // drain the window loads issued just before (vmcnt retires in order) and stall the two-deep pipeline -- measured:
+    // 47 -> 61 ms per design-gradient call with the scale computed inside load_item.
     const unsigned* const amax = reinterpret_cast<const unsigned*>(a.src[0].stats);
-    auto scale_exp = [&](int img) -> int {                      // biased exponent of the staging scale of tile image `img`
-        unsigned mb = PAIR ? max(amax[2 * img], amax[2 * img + 1]) : amax[img];
-        mb = __builtin_amdgcn_readfirstlane(mb);
+    auto scale_exp = [&](unsigned m0, unsigned m1) -> int {     // biased exponent of the staging scale from the image's (pair's) maximum
+        const unsigned mb = PAIR ? max(m0, m1) : m0;
         const int e = (int)(mb >> 23);                          // biased exponent of the maximum (the sign bit is clear)
         return e == 0 ? 127 : min(max(267 - e, 1), 253);
     };
-    float in_s = 1.0f;                                          // of the item loaded last (set by load_item, used by store_item)
+    // The finished tile's scale is NOT loaded again when the tile is written: write_tile sits behind the next item's window
+    // loads, and a wait on any load issued there drains them too (measured: every input-gradient convolution 2x slower,
+    // 47 -> 70 ms per design-gradient call).  Instead the exponent of every staged item is kept for four items (an item
+    // is staged one phase before it is multiplied and its tile is written one phase after).
+    unsigned mx_in[2] = {0u, 0u};                               // raw maxima of the item loaded last
+    int se_h0 = 127, se_h1 = 127, se_h2 = 127, se_h3 = 127;     // four slots: items k - 1 (tile being written) .. k + 2 (just decoded) are live at once
+    auto hist_set = [&](int j, int v) { const int r = j & 3; if (r == 0) se_h0 = v; else if (r == 1) se_h1 = v; else if (r == 2) se_h2 = v; else se_h3 = v; };
+    auto hist_get = [&](int j) -> int { const int r = j & 3; return r == 0 ? se_h0 : (r == 1 ? se_h1 : (r == 2 ? se_h2 : se_h3)); };
     const float* const resp = a.res;
     const int ldres = a.ldres;
     float4 racc[8];
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         cok = cl < Cc;
         okmask = m_valid & ~((ty0 == 0 ? m_top : 0u) | (ty0 + V2Y == Hout ? m_bot : 0u) | (PAIR || tx0 == 0 ? m_left : 0u) |
                              (PAIR || tx0 + V2X == Wout ? m_right : 0u));
-        if constexpr (MODE == SRC2_SCALED) in_s = __builtin_bit_cast(float, (unsigned)scale_exp(img) << 23);
+        if constexpr (MODE == SRC2_SCALED) { mx_in[0] = amax[PAIR ? 2 * img : img]; if constexpr (PAIR) mx_in[1] = amax[2 * img + 1]; }
         const int origin = (KIND == CONV_UP2) ? img * HWi + (ty0 >> 1) * Win + (tx0 >> 1) : (PAIR ? 2 * img : img) * HWi + ty0 * Win + tx0;
         const int t4 = (origin * ld + clc) * 4;               // byte offset of the tile origin's float4 of this thread
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, first ? src_bytes0 : src_bytes1, 0x00020000);
@@ -333,9 +343,15 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             fb.z = (pb.z - gm * gr * pg.z) * sz + psh.z; fb.w = (pb.w - gm * gr * pg.w) * sw + psh.w;
         }
     };
-    auto store_item = [&](int buf) {
+    auto store_item = [&](int buf, int item) {
         unsigned char* S0 = &smem[buf][0];
         unsigned char* S1 = S0 + PLANE;
+        float in_s = 1.0f;
+        if constexpr (MODE == SRC2_SCALED) {
+            const int se = scale_exp(mx_in[0], mx_in[1]);
+            hist_set(item, se);
+            in_s = __builtin_bit_cast(float, (unsigned)se << 23);
+        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int r = r0 + 16 * p;
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         }
     };
     // the finished tile (mt, nt): wave lw stores tile pixels 32 lw .. 32 lw + 31 (two pixel rows) and their GroupNorm partial
-    auto write_tile = [&](int mt, int nt) {
+    auto write_tile = [&](int mt, int nt, int item) {
         const int img = mt / tpi, ti = mt - img * tpi;
         const int tyi = ti / tiles_x;
         const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             v[4 * jj + 3] = make_float4(f[jj][0].w, f[jj][1].w, f[jj][2].w, f[jj][3].w);
         }
         if constexpr (MODE == SRC2_SCALED) {
-            const float out_s = __builtin_bit_cast(float, (unsigned)(254 - scale_exp(img)) << 23);
+            const float out_s = __builtin_bit_cast(float, (unsigned)(254 - hist_get(item)) << 23);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[j].x *= out_s; v[j].y *= out_s; v[j].z *= out_s; v[j].w *= out_s; }
             if (resp) {
@@ -456,34 +472,35 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     decode(0, mt, nt, ch);
     load_item(mt, ch);
     finish_stats();
-    store_item(0);
+    store_item(0, 0);
     bool staged_skip = false;                                // the item waiting for its staging needs none
     if (nitems > 1) { decode(1, mtn, ntn, chn); load_item(mtn, chn); }
     stress_delay(stress, 200u);
     __syncthreads();                                         // S0
-    int pmt = -1, pnt = 0;                                   // finished tile waiting in LDS
+    int pmt = -1, pnt = 0, pk = 0;                           // finished tile waiting in LDS (pk: its last item)
     for (int k = 0; k < nitems; ++k) {
         if (stress > 0) stress_delay(stress, 204u + 8u * (unsigned)k);
-        if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1); }
+        if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1, k + 1); }
         if (pmt >= 0) load_acc(pmt, pnt);
         if (k + 2 < nitems && dbg != 5) {
             decode(k + 2, mtn, ntn, chn);
             staged_skip = (mtn == mt && chn == ch);                // its buffer, (k + 2) & 1, holds item k's planes: these
             if (!staged_skip && dbg != 2) load_item(mtn, chn);
+            else if constexpr (MODE == SRC2_SCALED) hist_set(k + 2, hist_get(k));      // (the same planes, the same image, the same scale)
         }
         if (stress > 0) stress_delay(stress, 201u + 8u * (unsigned)k);
-        if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt); pmt = -1; }
+        if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt, pk); pmt = -1; }
         if (stress > 0) stress_delay(stress, 202u + 8u * (unsigned)k);
         __syncthreads();                                     // S1
         if (ch == nch - 1) {
             __syncthreads();                                 // S2
             if (stress > 0) stress_delay(stress, 203u + 8u * (unsigned)k);
             __syncthreads();                                 // S3
-            pmt = mt; pnt = nt;
+            pmt = mt; pnt = nt; pk = k;
         }
         if (k + 1 < nitems) decode(k + 1, mt, nt, ch);
     }
-    if (pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt); }
+    if (pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
 }
 
 }  // namespace cindm
