@@ -12,8 +12,11 @@
 //     dv = dctx^T ks / n, dk = ks (dks - T) -> dy = dyq + Wk^T dk + Wv^T dv -> dx = dout + LayerNorm'(x; g1, dy) (+ what x.g holds)
 //
 // HBM traffic of a site's backward: x twice, dout twice, dyq written and read, dx written -- 7 tensors of [pixels, C] instead
-// of ~40.  Products of FORWARD quantities (q, k, v, att, z) run on the split-fp16 MFMA like the forward kernels; every
-// product with a GRADIENT operand runs on the exact fp32 MFMA (gradients sit far below fp16's range; no scaling needed).
+// of ~40.  Products of FORWARD quantities (q, k, v, att, z) run on the split-fp16 MFMA like the forward kernels.  The three
+// large products with a GRADIENT operand -- datt = Wo^T dz, dyq = Wq^T dq, dy = [Wk^T | Wv^T] [dk ; dv] -- do too: the
+// gradient matrix is staged as hi / scaled-lo planes times a power of two chosen PER PIXEL from that pixel's largest
+// magnitude (gradients sit far below fp16's range; the factor and its inverse are exact), 3 fp16 MFMAs of K = 32 instead of
+// 8 fp32 MFMAs of K = 4.  The small per-head products (32 x 32 contexts) stay on the exact fp32 MFMA.
 // Layout chains (no transposes through LDS except where a contraction runs over pixels):
 //   rows = channels, cols = pixels accumulators (A = weight fragment, B = pixel planes) are the B operand of the next
 //   channel contraction; contractions over PIXELS (dctx) read both operands back from a per-wave fp32 LDS tile.
@@ -27,7 +30,7 @@ struct FuLaArgs {
     const float* dout;                  // gradient with respect to the site output [NI * HW, C]
     const float* g1; const float* g2;   // PreNorm gain, to_out LayerNorm gain
     const float* Wqkv; const float* Wo; const float* bo;      // la2d split-fp16 fragments (24 tiles x C ; C/16 tiles x 128), bias [C]
-    const float* WoT; const float* WqT; const float* WkT; const float* WvT;      // fp32 fragments of the transposed products (host: fu_pack_la)
+    const float* WoT; const float* WqT; const float* WkvT;     // split-fp16 fragments of Wo^T [128 x C], Wq^T [C x 128], [Wk^T | Wv^T] [C x 256]
     const float* ctx;                   // [NI * 4][32][32] merged context (incl. 1 / n)
     const float* kst;                   // [NI * 4][32][2]: max_n k, 1 / sum_n exp(k - max)
     float* dctx_part;                   // [NI][wpi][4][1024] per-workgroup partials of pass A
@@ -37,6 +40,23 @@ struct FuLaArgs {
     int HW, tpw;                        // pixels per image ; NPX-pixel tiles per workgroup (NPX = 64 at C = 64, 32 at C = 128)
     float inv_n;
 };
+
+// max over groups of LPR consecutive lanes (as rowgroup_sum)
+template <int LPR>
+__device__ __forceinline__ float rowgroup_max(float v) {
+    v = fmaxf(v, dpp_get<0x128>(v)); v = fmaxf(v, dpp_get<0x124>(v)); v = fmaxf(v, dpp_get<0x4E>(v)); v = fmaxf(v, dpp_get<0xB1>(v));
+    if (LPR >= 32) v = xmax16(v);
+    if (LPR >= 64) v = xmax32(v);
+    return v;
+}
+// the power of two that puts a maximum magnitude mx into [2^13, 2^14) (fp16's upper normal range), and its inverse: gradient
+// operands are staged as split-fp16 planes times this factor (exact), the product is multiplied by the inverse (exact)
+__device__ __forceinline__ float grad_scale(float mx, float& inv) {
+    const int e = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+    const int se = e == 0 ? 127 : min(max(267 - e, 1), 253);
+    inv = __builtin_bit_cast(float, (unsigned)(254 - se) << 23);
+    return __builtin_bit_cast(float, (unsigned)se << 23);
+}
 
 // merged context + the column statistics of k that pass B needs (la2d_merge_kernel + kst): one workgroup per (image, head)
 __global__ __launch_bounds__(256) void fu_la_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, float* __restrict__ kst,
@@ -98,10 +118,12 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];       // y planes -> z -> dz (fp32 [pixel][ZP])
     __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NPX * APB];       // att planes -> dq (fp32 [128][NPX])
     __shared__ float QS[4][NPX * QP], DA[4][NPX * QP];                            // per wave: qs and datt with pixels as rows
+    __shared__ float SCZ[NPX], PM[4][NPX];                                        // 1 / scale of a pixel's dz ; per-head max |dq| of a pixel
     static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "Z aliases the y planes");
-    static_assert(128 * NPX * 4 <= 2 * NPX * APB, "dq aliases the att planes");
+    static_assert(2 * NPX * YPB <= 2 * NPX * APB, "the dz planes alias the att planes");
     float* Z = reinterpret_cast<float*>(&Yp[0][0]);
-    float* DQ = reinterpret_cast<float*>(&Ap[0][0]);
+    unsigned char* DZ0 = &Ap[0][0];                          // dz planes [pixel][C] (pitch YPB), then the dq planes [pixel][128] (pitch APB)
+    unsigned char* DZ1 = DZ0 + NPX * YPB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int wpi = a.HW / (NPX * a.tpw);
     const int img = blockIdx.x / wpi, wg = blockIdx.x % wpi, t0 = wg * a.tpw;
@@ -146,26 +168,25 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
                     cA[dt][et][i] = cp[(dt * 16 + lr) * 32 + et * 16 + lq * 4 + i];
                 }
     }
-    // Wo^T rows of head w (datt = Wo^T dz): woT[et][kk] = Wo[c = 4 kk + lq][w * 32 + et * 16 + lr]
-    // (tiles are 64 pixels at C = 64 and 32 at C = 128: every weight fragment stays resident in registers)
-    constexpr bool WRES = true;
-    const float* woTp = a.WoT + (size_t)w * 2 * KC4 * 64 + lane;
-    float woT[2][WRES ? KC4 : 1];
-    if constexpr (WRES) {
+    // Wo^T rows of head w (datt = Wo^T dz): tiles 2w, 2w + 1 of the [128 x C] fragments ; Wq^T rows of this wave's channel tiles
+    // (dyq = Wq^T dq over the 128 head channels): tiles w TPW + s of the [C x 128] fragments
+    const float4* WoT4 = reinterpret_cast<const float4*>(a.WoT);
+    const float4* WqT4 = reinterpret_cast<const float4*>(a.WqT);
+    half8 woh[2][K32], wol[2][K32], wqh[TPW][4], wql[TPW][4];
 #pragma unroll
-        for (int et = 0; et < 2; ++et)
+    for (int et = 0; et < 2; ++et)
 #pragma unroll
-            for (int kk = 0; kk < KC4; ++kk) woT[et][kk] = woTp[((size_t)et * KC4 + kk) * 64];
-    }
-    // Wq^T rows of this wave's channel tiles (dyq = Wq^T dq over all 128 head channels): wqT[s][kk] = Wq[hd = 4 kk + lq][c = (w TPW + s) 16 + lr]
-    const float* wqTp = a.WqT + (size_t)w * TPW * 32 * 64 + lane;
-    float wqT[WRES ? TPW : 1][32];
-    if constexpr (WRES) {
+        for (int k = 0; k < K32; ++k) {
+            woh[et][k] = __builtin_bit_cast(half8, WoT4[(((size_t)(2 * w + et) * K32 + k) * 2 + 0) * 64 + lane]);
+            wol[et][k] = __builtin_bit_cast(half8, WoT4[(((size_t)(2 * w + et) * K32 + k) * 2 + 1) * 64 + lane]);
+        }
 #pragma unroll
-        for (int s = 0; s < TPW; ++s)
+    for (int s = 0; s < TPW; ++s)
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) wqT[s][kk] = wqTp[((size_t)s * 32 + kk) * 64];
-    }
+        for (int k = 0; k < 4; ++k) {
+            wqh[s][k] = __builtin_bit_cast(half8, WqT4[(((size_t)(w * TPW + s) * 4 + k) * 2 + 0) * 64 + lane]);
+            wql[s][k] = __builtin_bit_cast(half8, WqT4[(((size_t)(w * TPW + s) * 4 + k) * 2 + 1) * 64 + lane]);
+        }
     f32x4 dctx[2][2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -275,22 +296,43 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             const float t0 = gv2.x * dor[r].x, t1 = gv2.y * dor[r].y, t2 = gv2.z * dor[r].z, t3 = gv2.w * dor[r].w;
             const float m1 = rowgroup_sum<LN::LPR>((t0 + t1) + (t2 + t3)) * (1.0f / C);
             const float m2 = rowgroup_sum<LN::LPR>((t0 * z0 + t1 * z1) + (t2 * z2 + t3 * z3)) * (1.0f / C);
-            *reinterpret_cast<float4*>(&Z[n * ZP + 4 * lcol]) =
-                make_float4(rstd * (t0 - m1 - z0 * m2), rstd * (t1 - m1 - z1 * m2), rstd * (t2 - m1 - z2 * m2), rstd * (t3 - m1 - z3 * m2));
+            const float g0 = rstd * (t0 - m1 - z0 * m2), g1 = rstd * (t1 - m1 - z1 * m2), g2 = rstd * (t2 - m1 - z2 * m2), g3 = rstd * (t3 - m1 - z3 * m2);
+            // dz of this pixel as split-fp16 planes times the power of two that puts the pixel's largest |dz| in [2^13, 2^14)
+            float inv;
+            const float sc = grad_scale(rowgroup_max<LN::LPR>(fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fmaxf(fabsf(g2), fabsf(g3)))), inv);
+            if (lcol == 0) SCZ[n] = inv;
+            const float s0 = g0 * sc, s1 = g1 * sc, s2 = g2 * sc, s3 = g3 * sc;
+            half4v hi, lo;
+            hi[0] = (_Float16)s0; hi[1] = (_Float16)s1; hi[2] = (_Float16)s2; hi[3] = (_Float16)s3;
+            lo[0] = (_Float16)((s0 - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((s1 - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((s2 - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((s3 - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(DZ0 + n * YPB + 8 * lcol) = hi;
+            *reinterpret_cast<half4v*>(DZ1 + n * YPB + 8 * lcol) = lo;
         }
-        __syncthreads();                                                            // (4) dz
+        __syncthreads();                                                            // (4) dz planes
         // datt (rows e of head w, cols pixels) = Wo^T dz ; dqs = ctx datt ; dq ; dctx += qs datt^T
         f32x4 dq[NTL][2];
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
-            f32x4 da[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 da[2];
+            {
+                f32x4 M[2], Lo[2];
 #pragma unroll
-            for (int kk = 0; kk < KC4; ++kk) {
-                const float b = Z[(nt * 16 + lr) * ZP + 4 * kk + lq];
-                const float w0 = WRES ? woT[0][WRES ? kk : 0] : woTp[(size_t)kk * 64];
-                const float w1 = WRES ? woT[1][WRES ? kk : 0] : woTp[((size_t)KC4 + kk) * 64];
-                da[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, b, da[0], 0, 0, 0);
-                da[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, b, da[1], 0, 0, 0);
+                for (int et = 0; et < 2; ++et) { M[et] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[et] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int k = 0; k < K32; ++k) {
+                    const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
+                    const half8 gh = *reinterpret_cast<const half8*>(DZ0 + off);
+                    const half8 gl = *reinterpret_cast<const half8*>(DZ1 + off);
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) {
+                        M[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(woh[et][k], gh, M[et], 0, 0, 0);
+                        Lo[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(woh[et][k], gl, Lo[et], 0, 0, 0);
+                        Lo[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wol[et][k], gh, Lo[et], 0, 0, 0);
+                    }
+                }
+                const float inv = SCZ[nt * 16 + lr];
+                da[0] = (M[0] + Lo[0] * H3_INV) * inv; da[1] = (M[1] + Lo[1] * H3_INV) * inv;
             }
 #pragma unroll
             for (int et = 0; et < 2; ++et)
@@ -310,19 +352,31 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dot += qs[nt][dt][i] * ds[dt][i];
             dot = xsum32(xsum16(dot)) * 5.656854249492381f;       // 1 / scale
+            float mxq = 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dq[nt][dt][i] = qs[nt][dt][i] * (ds[dt][i] - dot);
+                for (int i = 0; i < 4; ++i) { dq[nt][dt][i] = qs[nt][dt][i] * (ds[dt][i] - dot); mxq = fmaxf(mxq, fabsf(dq[nt][dt][i])); }
+            mxq = xmax32(xmax16(mxq));                       // over this head's 32 channels of pixel nt * 16 + lr
+            if (lq == 0) PM[w][nt * 16 + lr] = mxq;
         }
-        __syncthreads();                                                            // (5) dz consumed ; QS / DA of this wave complete
-        // dq of every head -> DQ[hd][pixel] (aliases the att planes)
+        __syncthreads();                                                            // (5) dz planes consumed ; QS / DA / PM complete
+        // dq of every head -> planes [pixel][128] (pitch APB, over the dz planes) times the pixel's power of two (common to the heads)
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
+        for (int nt = 0; nt < NTL; ++nt) {
+            const int px = nt * 16 + lr;
+            float inv;
+            const float sc = grad_scale(fmaxf(fmaxf(PM[0][px], PM[1][px]), fmaxf(PM[2][px], PM[3][px])), inv);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt) {
+                half4v hi, lo;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) DQ[(w * 32 + dt * 16 + lq * 4 + i) * NPX + nt * 16 + lr] = dq[nt][dt][i];
+                for (int i = 0; i < 4; ++i) { const float v = dq[nt][dt][i] * sc; hi[i] = (_Float16)v; lo[i] = (_Float16)((v - (float)hi[i]) * H3_SCALE); }
+                const int off = px * APB + 2 * (w * 32 + dt * 16 + lq * 4);
+                *reinterpret_cast<half4v*>(&Ap[0][off]) = hi;
+                *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
+            }
+        }
         // dctx[d][e] += sum_pixels qs[d][n] datt[e][n]: A[i = d][k = pixel], B[k = pixel][j = e] from the wave's own tiles
 #pragma unroll
         for (int kk = 0; kk < NPX / 4; ++kk) {
@@ -333,23 +387,31 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             dctx[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, dctx[1][0], 0, 0, 0);
             dctx[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, dctx[1][1], 0, 0, 0);
         }
-        __syncthreads();                                                            // (6) DQ
+        __syncthreads();                                                            // (6) dq planes
         // dyq (rows c of this wave's channel tiles, cols pixels) = Wq^T dq over the 128 head channels
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
             const int c = (w * TPW + s) * 16 + lq * 4;
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) {
-                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 oM = f32x4{0.f, 0.f, 0.f, 0.f}, oL = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
-                    const float wv = WRES ? wqT[WRES ? s : 0][kk] : wqTp[((size_t)s * 32 + kk) * 64];
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, DQ[(4 * kk + lq) * NPX + nt * 16 + lr], o, 0, 0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    const int off = (nt * 16 + lr) * APB + k * 64 + lq * 16;
+                    const half8 gh = *reinterpret_cast<const half8*>(&Ap[0][off]);
+                    const half8 gl = *reinterpret_cast<const half8*>(&Ap[1][off]);
+                    oM = __builtin_amdgcn_mfma_f32_16x16x32_f16(wqh[s][k], gh, oM, 0, 0, 0);
+                    oL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wqh[s][k], gl, oL, 0, 0, 0);
+                    oL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wql[s][k], gh, oL, 0, 0, 0);
                 }
-                *reinterpret_cast<float4*>(a.dyq + (row0 + nt * 16 + lr) * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+                const int px = nt * 16 + lr;
+                float inv;
+                (void)grad_scale(fmaxf(fmaxf(PM[0][px], PM[1][px]), fmaxf(PM[2][px], PM[3][px])), inv);
+                const f32x4 o = (oM + oL * H3_INV) * inv;
+                *reinterpret_cast<float4*>(a.dyq + (row0 + px) * C + c) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
-        __syncthreads();                                                            // (7) DQ consumed: the next tile rewrites Yp / Ap
+        __syncthreads();                                                            // (7) dq planes and PM consumed: the next tile rewrites Yp / Ap
     }
     float* rec = a.dctx_part + (((size_t)img * wpi + wg) * 4 + w) * 1024;
 #pragma unroll
@@ -366,7 +428,9 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
     using LN = LnTile<C, NPX>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];       // y planes -> dy (fp32 [pixel][ZP])
-    __shared__ float DK[128 * NPX], DV[128 * NPX];                                // dk, dv of every head: [hd][pixel]
+    constexpr int GPB = 2 * 256 + 16;                        // bytes per pixel and plane of the [dk | dv] planes
+    __shared__ __attribute__((aligned(16))) unsigned char Gp[2][NPX * GPB];       // dk (channels 0..127) | dv (128..255) of every head, scaled split-fp16
+    __shared__ float PM[4][NPX];                                                  // per-head max(|dk|, |dv|) of a pixel
     static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "dy aliases the y planes");
     float* DY = reinterpret_cast<float*>(&Yp[0][0]);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
@@ -408,18 +472,17 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
                 }
             }
     }
-    // Wk^T, Wv^T rows of this wave's channel tiles: w?T[s][kk] = W?[hd = 4 kk + lq][c = (w TPW + s) 16 + lr]
-    constexpr bool WRES = true;
+    // [Wk^T | Wv^T] rows of this wave's channel tiles (dy = Wk^T dk + Wv^T dv): tiles w TPW + s of the [C x 256] fragments
     constexpr int UNR = C == 64 ? NTL : 1;                   // (C = 128: the pixel-block loops stay rolled, or the registers spill)
-    const float* wkTp = a.WkT + (size_t)w * TPW * 32 * 64 + lane;
-    const float* wvTp = a.WvT + (size_t)w * TPW * 32 * 64 + lane;
-    float wkT[WRES ? TPW : 1][32], wvT[WRES ? TPW : 1][32];
-    if constexpr (WRES) {
+    const float4* WkvT4 = reinterpret_cast<const float4*>(a.WkvT);
+    half8 wgh[TPW][8], wgl[TPW][8];
 #pragma unroll
-        for (int s = 0; s < TPW; ++s)
+    for (int s = 0; s < TPW; ++s)
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) { wkT[s][kk] = wkTp[((size_t)s * 32 + kk) * 64]; wvT[s][kk] = wvTp[((size_t)s * 32 + kk) * 64]; }
-    }
+        for (int k = 0; k < 8; ++k) {
+            wgh[s][k] = __builtin_bit_cast(half8, WkvT4[(((size_t)(w * TPW + s) * 8 + k) * 2 + 0) * 64 + lane]);
+            wgl[s][k] = __builtin_bit_cast(half8, WkvT4[(((size_t)(w * TPW + s) * 8 + k) * 2 + 1) * 64 + lane]);
+        }
 
 #pragma unroll 1
     for (int tt = 0; tt < a.tpw; ++tt) {
@@ -427,7 +490,8 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();                                                            // (1) y planes
         if (tt + 1 < a.tpw) LN::load(xr, a.x + (row0 + NPX) * a.ldx, a.ldx, tid);
-#pragma unroll UNR
+        f32x4 dkr[NTL][2], dvr[NTL][2];
+#pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             f32x4 M[4], Lo[4];
 #pragma unroll
@@ -466,16 +530,40 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
                         dks[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[dt][et][i], vv[et][i], dks[dt], 0, 0, 0);
                         dv[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[et][dt][i], ksm[dt][i], dv[et], 0, 0, 0);
                     }
+            float mx = 0.f;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int hd = w * 32 + dt * 16 + lq * 4 + i;
-                    DK[hd * NPX + nt * 16 + lr] = ksm[dt][i] * (dks[dt][i] * a.inv_n - Tt[dt][i]);
-                    DV[hd * NPX + nt * 16 + lr] = dv[dt][i] * a.inv_n;
+                    dkr[nt][dt][i] = ksm[dt][i] * (dks[dt][i] * a.inv_n - Tt[dt][i]);
+                    dvr[nt][dt][i] = dv[dt][i] * a.inv_n;
+                    mx = fmaxf(mx, fmaxf(fabsf(dkr[nt][dt][i]), fabsf(dvr[nt][dt][i])));
                 }
+            mx = xmax32(xmax16(mx));                         // over this head's 64 dk | dv channels of pixel nt * 16 + lr
+            if (lq == 0) PM[w][nt * 16 + lr] = mx;
         }
-        __syncthreads();                                                            // (2) DK, DV ; y planes consumed
+        __syncthreads();                                                            // (2) PM ; y planes consumed
+        // dk | dv of every head -> planes [pixel][256] times the pixel's power of two (common to the heads)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            const int px = nt * 16 + lr;
+            float inv;
+            const float sc = grad_scale(fmaxf(fmaxf(PM[0][px], PM[1][px]), fmaxf(PM[2][px], PM[3][px])), inv);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                half4v kh4, kl4, vh4, vl4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float vk = dkr[nt][dt][i] * sc, vv_ = dvr[nt][dt][i] * sc;
+                    kh4[i] = (_Float16)vk; kl4[i] = (_Float16)((vk - (float)kh4[i]) * H3_SCALE);
+                    vh4[i] = (_Float16)vv_; vl4[i] = (_Float16)((vv_ - (float)vh4[i]) * H3_SCALE);
+                }
+                const int off = px * GPB + 2 * (w * 32 + dt * 16 + lq * 4);
+                *reinterpret_cast<half4v*>(&Gp[0][off]) = kh4; *reinterpret_cast<half4v*>(&Gp[1][off]) = kl4;
+                *reinterpret_cast<half4v*>(&Gp[0][off + 256]) = vh4; *reinterpret_cast<half4v*>(&Gp[1][off + 256]) = vl4;
+            }
+        }
+        __syncthreads();                                                            // (2b) dk | dv planes
         // the tile's own x and dout rows for the LayerNorm derivative below (x from L2: this workgroup read it a moment ago)
         float4 xres[LN::NPASS], dor[LN::NPASS];
 #pragma unroll
@@ -489,20 +577,25 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
             const int c = (w * TPW + s) * 16 + lq * 4;
 #pragma unroll UNR
             for (int nt = 0; nt < NTL; ++nt) {
-                const float4 yq = *reinterpret_cast<const float4*>(a.dyq + (row0 + nt * 16 + lr) * C + c);
-                f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int px = nt * 16 + lr;
+                const float4 yq = *reinterpret_cast<const float4*>(a.dyq + (row0 + px) * C + c);
+                f32x4 oM = f32x4{0.f, 0.f, 0.f, 0.f}, oL = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
-                    const float wk = WRES ? wkT[WRES ? s : 0][kk] : wkTp[((size_t)s * 32 + kk) * 64];
-                    const float wv = WRES ? wvT[WRES ? s : 0][kk] : wvTp[((size_t)s * 32 + kk) * 64];
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk, DK[(4 * kk + lq) * NPX + nt * 16 + lr], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, DV[(4 * kk + lq) * NPX + nt * 16 + lr], o1, 0, 0, 0);
+                for (int k = 0; k < 8; ++k) {
+                    const int off = px * GPB + k * 64 + lq * 16;
+                    const half8 gh = *reinterpret_cast<const half8*>(&Gp[0][off]);
+                    const half8 gl = *reinterpret_cast<const half8*>(&Gp[1][off]);
+                    oM = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgh[s][k], gh, oM, 0, 0, 0);
+                    oL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgh[s][k], gl, oL, 0, 0, 0);
+                    oL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgl[s][k], gh, oL, 0, 0, 0);
                 }
-                *reinterpret_cast<float4*>(&DY[(nt * 16 + lr) * ZP + c]) =
-                    make_float4((o0[0] + o1[0]) + yq.x, (o0[1] + o1[1]) + yq.y, (o0[2] + o1[2]) + yq.z, (o0[3] + o1[3]) + yq.w);
+                float inv;
+                (void)grad_scale(fmaxf(fmaxf(PM[0][px], PM[1][px]), fmaxf(PM[2][px], PM[3][px])), inv);
+                const f32x4 o = (oM + oL * H3_INV) * inv;
+                *reinterpret_cast<float4*>(&DY[px * ZP + c]) = make_float4(o[0] + yq.x, o[1] + yq.y, o[2] + yq.z, o[3] + yq.w);
             }
         }
-        __syncthreads();                                                            // (3) dy ; DK / DV consumed
+        __syncthreads();                                                            // (3) dy ; dk | dv planes and PM consumed
         // dx = beta dx + dout + LayerNorm'(x; g1) dy
 #pragma unroll
         for (int r = 0; r < LN::NPASS; ++r) {

@@ -300,3 +300,26 @@ def test_guided_chain_sharding_invariance(device, force):
     full, lo, hi = run(4, 0), run(2, 0), run(2, 2)
     assert bool(torch.isfinite(full).all())
     assert torch.equal(full[:2], lo) and torch.equal(full[2:], hi)
+
+
+@pytest.mark.parametrize("mults", [(1, 2, 4, 8), (2, 2, 4, 8)], ids=["paper", "wide_level1"])
+def test_forceunet_fused_linear_attention_vs_layered(device, mults):
+    """The LinearAttention sites without q | k | v tensors (forceunet_la.h: la2d forward kernels + the two-pass recomputing
+    input gradient) against the layer-by-layer path (option la_fused = 0) and the oracle's autograd.  dim_mults (2, 2, 4, 8)
+    puts a 128-channel site at 32 x 32 pixels, the second instantiation of the backward kernels."""
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(dim_mults=mults), 5)
+    x = torch.randn((4, 4, 64, 64), generator=torch.Generator().manual_seed(13))
+    xo = x.clone().requires_grad_(True)
+    y = O.force_unet_forward(sd, xo)
+    ref = torch.autograd.grad((1.1 * y[:, 0].abs() + y[:, 1]).sum(), xo)[0]
+    res = {}
+    for fused in (1, 0):
+        m = cindm_amd.ForceUnet(dim=64, dim_mults=mults, channels=4)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(device)
+        m.set_option("la_fused", fused)
+        res[fused] = m.input_grad(x.to(device), lambda_force=1.1)
+        assert rel(res[fused][0], y.detach()) < TOL and rel(res[fused][1], ref) < TOL, fused
+        out2, dx2 = m.input_grad(x.to(device), lambda_force=1.1)
+        assert torch.equal(out2, res[fused][0]) and torch.equal(dx2, res[fused][1])        # repeatable bit for bit
+    assert rel(res[1][1], res[0][1].cpu().numpy()) < TOL

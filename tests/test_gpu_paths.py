@@ -241,6 +241,7 @@ def test_workspace_recycling(device, unet8):
             m.set_option("ws_alias", v)
             m.sync_weights()
             size[v] = L.cindm_unet1d_workspace_bytes(m._h, 768)
+            size[v, 256] = L.cindm_unet1d_workspace_bytes(m._h, 256)
             out[v] = (d.sample(batch_size=37, n_composed=0, compose_n_bodies=2, seed=2, t_stop=988),
                       d.sample(batch_size=5, n_composed=2, compose_start_step=16, compose_mode="mean-inside", seed=2, t_stop=994))
     finally:
@@ -251,7 +252,7 @@ def test_workspace_recycling(device, unet8):
         assert torch.equal(a, b)
     m.set_option("ws_alias", 1)
     m.sync_weights()
-    assert L.cindm_unet1d_workspace_bytes(m._h, 768) == size[2] and L.cindm_unet1d_workspace_bytes(m._h, 256) > size[2]     # automatic above 320 rows
+    assert L.cindm_unet1d_workspace_bytes(m._h, 768) == size[2] and L.cindm_unet1d_workspace_bytes(m._h, 256) == size[0, 256] > size[2, 256]     # automatic above 320 rows
     x = torch.randn((19, 24, 8), generator=torch.Generator().manual_seed(5)).to(device)
     t = torch.full((19,), 611, device=device)
     y1 = m(x, t)
