@@ -39,7 +39,15 @@ struct FuLaArgs {
     float* dx; float beta;              // pass B: dx = beta * dx + dout + LayerNorm'(...)
     int HW, tpw;                        // pixels per image ; NPX-pixel tiles per workgroup (NPX = 64 at C = 64, 32 at C = 128)
     float inv_n;
+#ifdef FU_LA_PROF
+    unsigned long long* prof;            // tools/micro/la_bwd.hip only
+#endif
 };
+#ifdef FU_LA_PROF
+#define FU_LA_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tt == 1) a.prof[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FU_LA_MARK(i) do { } while (0)
+#endif
 
 // max over groups of LPR consecutive lanes (as rowgroup_sum)
 template <int LPR>
@@ -110,8 +118,8 @@ __global__ __launch_bounds__(256) void fu_la_dctx_merge_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int C, int NPX>
-__global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
+template <int C, int NPX, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void fu_la_bwd_a_kernel(const FuLaArgs a) {
     using LN = LnTile<C, NPX>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4, KC4 = C / 4;
     constexpr int QP = 33;                                   // pitch of the per-wave [pixel][32] fp32 tiles
@@ -196,8 +204,10 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
 #pragma unroll 1
     for (int tt = 0; tt < a.tpw; ++tt) {
         const size_t row0 = row00 + (size_t)tt * NPX;
+        FU_LA_MARK(0);
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();                                                            // (1) y planes
+        FU_LA_MARK(1);
         if (tt + 1 < a.tpw) LN::load(xr, a.x + (row0 + NPX) * a.ldx, a.ldx, tid);
         // dout rows of this thread (LayerNorm' below), requested early
         float4 dor[LN::NPASS];
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
                 for (int i = 0; i < 4; ++i) QS[w][(nt * 16 + lr) * QP + dt * 16 + lq * 4 + i] = q[dt][i];
         }
         __syncthreads();                                                            // (2) att planes ; y planes consumed
+        FU_LA_MARK(2);
         // z = Wo att + bo -> Z[pixel][channel]
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             }
         }
         __syncthreads();                                                            // (3) Z ; att planes consumed
+        FU_LA_MARK(3);
         // dz = LayerNorm'(z; g2) dout, in place: dz = r (t - mean(t) - zhat mean(t zhat)), t = g2 dout
 #pragma unroll
         for (int r = 0; r < LN::NPASS; ++r) {
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             *reinterpret_cast<half4v*>(DZ1 + n * YPB + 8 * lcol) = lo;
         }
         __syncthreads();                                                            // (4) dz planes
+        FU_LA_MARK(4);
         // datt (rows e of head w, cols pixels) = Wo^T dz ; dqs = ctx datt ; dq ; dctx += qs datt^T
         f32x4 dq[NTL][2];
 #pragma unroll
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             if (lq == 0) PM[w][nt * 16 + lr] = mxq;
         }
         __syncthreads();                                                            // (5) dz planes consumed ; QS / DA / PM complete
+        FU_LA_MARK(5);
         // dq of every head -> planes [pixel][128] (pitch APB, over the dz planes) times the pixel's power of two (common to the heads)
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
@@ -388,6 +402,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             dctx[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, dctx[1][1], 0, 0, 0);
         }
         __syncthreads();                                                            // (6) dq planes
+        FU_LA_MARK(6);
         // dyq (rows c of this wave's channel tiles, cols pixels) = Wq^T dq over the 128 head channels
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
@@ -412,6 +427,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
             }
         }
         __syncthreads();                                                            // (7) dq planes and PM consumed: the next tile rewrites Yp / Ap
+        FU_LA_MARK(7);
     }
     float* rec = a.dctx_part + (((size_t)img * wpi + wg) * 4 + w) * 1024;
 #pragma unroll
@@ -423,8 +439,8 @@ __global__ __launch_bounds__(256) void fu_la_bwd_a_kernel(const FuLaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int C, int NPX>
-__global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
+template <int C, int NPX, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void fu_la_bwd_b_kernel(const FuLaArgs a) {
     using LN = LnTile<C, NPX>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];       // y planes -> dy (fp32 [pixel][ZP])
@@ -487,8 +503,10 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
 #pragma unroll 1
     for (int tt = 0; tt < a.tpw; ++tt) {
         const size_t row0 = row00 + (size_t)tt * NPX;
+        FU_LA_MARK(32);
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();                                                            // (1) y planes
+        FU_LA_MARK(33);
         if (tt + 1 < a.tpw) LN::load(xr, a.x + (row0 + NPX) * a.ldx, a.ldx, tid);
         f32x4 dkr[NTL][2], dvr[NTL][2];
 #pragma unroll
@@ -543,6 +561,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
             if (lq == 0) PM[w][nt * 16 + lr] = mx;
         }
         __syncthreads();                                                            // (2) PM ; y planes consumed
+        FU_LA_MARK(34);
         // dk | dv of every head -> planes [pixel][256] times the pixel's power of two (common to the heads)
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
@@ -564,6 +583,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
             }
         }
         __syncthreads();                                                            // (2b) dk | dv planes
+        FU_LA_MARK(35);
         // the tile's own x and dout rows for the LayerNorm derivative below (x from L2: this workgroup read it a moment ago)
         float4 xres[LN::NPASS], dor[LN::NPASS];
 #pragma unroll
@@ -596,6 +616,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
             }
         }
         __syncthreads();                                                            // (3) dy ; dk | dv planes and PM consumed
+        FU_LA_MARK(36);
         // dx = beta dx + dout + LayerNorm'(x; g1) dy
 #pragma unroll
         for (int r = 0; r < LN::NPASS; ++r) {
@@ -615,6 +636,7 @@ __global__ __launch_bounds__(256) void fu_la_bwd_b_kernel(const FuLaArgs a) {
             *op = o;
         }
         __syncthreads();                                                            // (4) dy consumed: the next tile rewrites Yp
+        FU_LA_MARK(37);
     }
 }
 
