@@ -504,10 +504,25 @@ __global__ __launch_bounds__(256, MINB) void fu_la_bwd_b_kernel(const FuLaArgs a
     for (int tt = 0; tt < a.tpw; ++tt) {
         const size_t row0 = row00 + (size_t)tt * NPX;
         FU_LA_MARK(32);
+        constexpr bool EARLY_YQ = C == 64;                   // (C = 128: the dy loop stays rolled -- a register array could not be indexed)
+        float4 xres[LN::NPASS];                              // the tile's own rows, for the LayerNorm derivative at the end
+#pragma unroll
+        for (int r = 0; r < LN::NPASS; ++r) xres[r] = xr[r];
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();                                                            // (1) y planes
         FU_LA_MARK(33);
         if (tt + 1 < a.tpw) LN::load(xr, a.x + (row0 + NPX) * a.ldx, a.ldx, tid);
+        // this tile's dout rows and its dyq fragments are requested HERE, a whole k | v phase before
+        // their first use -- requested where they are used, their HBM latency was most of the dy phase (9.9k of 28k cycles per tile)
+        float4 dor[LN::NPASS], yqr[EARLY_YQ ? TPW * NTL : 1];
+#pragma unroll
+        for (int r = 0; r < LN::NPASS; ++r) dor[r] = *reinterpret_cast<const float4*>(a.dout + (row0 + r * LN::RPP + lrow) * C + 4 * lcol);
+        if constexpr (EARLY_YQ) {
+#pragma unroll
+            for (int s = 0; s < TPW; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) yqr[s * NTL + nt] = *reinterpret_cast<const float4*>(a.dyq + (row0 + nt * 16 + lr) * C + (w * TPW + s) * 16 + lq * 4);
+        }
         f32x4 dkr[NTL][2], dvr[NTL][2];
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
@@ -584,13 +599,7 @@ __global__ __launch_bounds__(256, MINB) void fu_la_bwd_b_kernel(const FuLaArgs a
         }
         __syncthreads();                                                            // (2b) dk | dv planes
         FU_LA_MARK(35);
-        // the tile's own x and dout rows for the LayerNorm derivative below (x from L2: this workgroup read it a moment ago)
-        float4 xres[LN::NPASS], dor[LN::NPASS];
-#pragma unroll
-        for (int r = 0; r < LN::NPASS; ++r) {
-            xres[r] = *reinterpret_cast<const float4*>(a.x + (row0 + r * LN::RPP + lrow) * a.ldx + 4 * lcol);
-            dor[r] = *reinterpret_cast<const float4*>(a.dout + (row0 + r * LN::RPP + lrow) * C + 4 * lcol);
-        }
+
         // dy (rows c of this wave's channel tiles, cols pixels) = dyq + Wk^T dk + Wv^T dv -> DY[pixel][channel]
 #pragma unroll
         for (int s = 0; s < TPW; ++s) {
@@ -598,7 +607,8 @@ __global__ __launch_bounds__(256, MINB) void fu_la_bwd_b_kernel(const FuLaArgs a
 #pragma unroll UNR
             for (int nt = 0; nt < NTL; ++nt) {
                 const int px = nt * 16 + lr;
-                const float4 yq = *reinterpret_cast<const float4*>(a.dyq + (row0 + px) * C + c);
+                float4 yq;
+                if constexpr (EARLY_YQ) yq = yqr[s * NTL + nt]; else yq = *reinterpret_cast<const float4*>(a.dyq + (row0 + px) * C + c);
                 f32x4 oM = f32x4{0.f, 0.f, 0.f, 0.f}, oL = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
