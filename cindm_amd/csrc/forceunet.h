@@ -52,25 +52,40 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
     const int pi = lane & 15, py = 2 * w + (pi >> 3), px = pi & 7;          // this lane's A row = pixel (py, px) of the tile
     const int nq_total = a.CoutP / (16 * NB);
     const int kcs = a.CinP / 4;
+    // one staged element: halo pixel hp, channel quad c4 of the 16-channel chunk at c0
+    auto fetch = [&](int i, int c0) {
+        const int hp = i / (CK / 4), c4 = i - hp * (CK / 4);
+        const int hy = hp / TW, hx = hp - hy * TW;
+        const int y = ty0 + hy - HALO / 2, x = tx0 + hx - HALO / 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = c0 + c4 * 4;
+        if constexpr (UNSHUF == 1) {
+            const int pp = c / a.Csrc, cs = c - pp * a.Csrc;             // Csrc is a multiple of 16: a float4 stays in one pixel
+            v = *reinterpret_cast<const float4*>(a.x + (((size_t)img * 2 * a.H + 2 * y + (pp >> 1)) * (2 * a.Wd) + 2 * x + (pp & 1)) * a.Csrc + cs);
+        } else
+        if (y >= 0 && y < a.H && x >= 0 && x < a.Wd && c < a.Cin) {
+            const float* p = a.x + ((size_t)img * HW + (size_t)y * a.Wd + x) * a.Cin + c;
+            if (c + 3 < a.Cin) v = *reinterpret_cast<const float4*>(p);
+            else { v.x = p[0]; if (c + 1 < a.Cin) v.y = p[1]; if (c + 2 < a.Cin) v.z = p[2]; }
+        }
+        return v;
+    };
+    auto put = [&](int i, const float4 v) {
+        const int hp = i / (CK / 4), c4 = i - hp * (CK / 4);
+        float* d = &As[hp * CKP + c4 * 4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    };
+    // 1x1: a chunk is exactly one float4 per thread -- the next chunk's is requested while this one multiplies (issued in the
+    // staging loop itself, its HBM latency was most of a chunk's time)
+    float4 ahead = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (KS == 1) ahead = fetch(tid, 0);
     for (int c0 = 0; c0 < a.CinP; c0 += CK) {
         __syncthreads();
-        for (int i = tid; i < NPIX * (CK / 4); i += 256) {
-            const int hp = i / (CK / 4), c4 = i - hp * (CK / 4);
-            const int hy = hp / TW, hx = hp - hy * TW;
-            const int y = ty0 + hy - HALO / 2, x = tx0 + hx - HALO / 2;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int c = c0 + c4 * 4;
-            if constexpr (UNSHUF == 1) {
-                const int pp = c / a.Csrc, cs = c - pp * a.Csrc;             // Csrc is a multiple of 16: a float4 stays in one pixel
-                v = *reinterpret_cast<const float4*>(a.x + (((size_t)img * 2 * a.H + 2 * y + (pp >> 1)) * (2 * a.Wd) + 2 * x + (pp & 1)) * a.Csrc + cs);
-            } else
-            if (y >= 0 && y < a.H && x >= 0 && x < a.Wd && c < a.Cin) {
-                const float* p = a.x + ((size_t)img * HW + (size_t)y * a.Wd + x) * a.Cin + c;
-                if (c + 3 < a.Cin) v = *reinterpret_cast<const float4*>(p);
-                else { v.x = p[0]; if (c + 1 < a.Cin) v.y = p[1]; if (c + 2 < a.Cin) v.z = p[2]; }
-            }
-            float* d = &As[hp * CKP + c4 * 4];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if constexpr (KS == 1) {
+            put(tid, ahead);
+            if (c0 + CK < a.CinP) ahead = fetch(tid, c0 + CK);
+        } else {
+            for (int i = tid; i < NPIX * (CK / 4); i += 256) put(i, fetch(i, c0));
         }
         __syncthreads();
         const int nk = min(CK / 4, (a.Cin - c0 + 3) >> 2);
