@@ -1484,16 +1484,21 @@ struct Level0Args {
 
 // one 16-channel x (NT*16)-position tile of a k-tap convolution: A = this wave's weight fragments [tap][k32][plane],
 // B = activation planes at row (position * stride + tap + row0)
+// lvl_wload() requests a layer's fragments; lvl_conv() multiplies with them.  A workgroup of these kernels is alone on its CU:
+// nothing hides an L2 round trip (0.5 - 0.8 us) unless the NEXT layer's fragments are requested before the current layer's
+// epilogue (GroupNorm, Mish, fp16 split, barrier) -- level0_down_kernel issued them after the barrier until round 3.
+template <int N>
+__device__ __forceinline__ void lvl_wload(const float4* __restrict__ Wt, int lane, float4 (&wr)[N][2]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { wr[i][0] = Wt[(i * 2 + 0) * 64 + lane]; wr[i][1] = Wt[(i * 2 + 1) * 64 + lane]; }
+}
 template <int NT, int TAPS, int KS, int PITCHB>
-__device__ __forceinline__ void lvl_conv(const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
+__device__ __forceinline__ void lvl_conv(const float4 (&wr)[TAPS * KS][2], const unsigned char* Xh, const unsigned char* Xl,
                                          int stride, int row0, int maxrow, int lane, f32x4 (&out)[NT]) {
     const int lr = lane & 15, lq = lane >> 4;
     f32x4 M[NT], Lo[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { M[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float4 wr[TAPS * KS][2];
-#pragma unroll
-    for (int i = 0; i < TAPS * KS; ++i) { wr[i][0] = Wt[(i * 2 + 0) * 64 + lane]; wr[i][1] = Wt[(i * 2 + 1) * 64 + lane]; }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
@@ -1617,15 +1622,23 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     const float4* Wd4 = reinterpret_cast<const float4*>(a.Wd) + (size_t)w * (3 * 2 * 2 * 64);
     auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + cl); };
     const float4 tb0 = ld4(a.tb0 + (size_t)t_now * a.tb_ld), tb1 = ld4(a.tb1 + (size_t)t_now * a.tb_ld);
+    // every per-channel vector of the level, once (requested where they are used, each cost an L2 round trip inside an epilogue)
+    float4 pbc[4], pga[4], pbe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pbc[i] = ld4(a.bc[i]); pga[i] = ld4(a.gam[i]); pbe[i] = ld4(a.bet[i]); }
+    const float4 pbr = ld4(a.br), pbo = ld4(a.bo), pbd = ld4(a.bd);
+    float4 w5a[5][2], w1[1][2], w10[10][2];
+    lvl_wload<5>(Wc0, lane, w5a); lvl_wload<1>(Wr4, lane, w1);
     __syncthreads();
 
     // ---- block 0 : y = Mish(GN(conv(x))) + tb0 ; h1 = Mish(GN(conv(y))) + (Wr x + br) ----
     f32x4 v[NT], r1[NT];
-    lvl_conv<NT, 5, 1, XPB>(Wc0, X0[0], X0[1], 1, 0, ROWS - 1, lane, v);
-    lvl_conv<NT, 1, 1, XPB>(Wr4, X0[0], X0[1], 1, 2, ROWS - 1, lane, r1);
-    lvl_gn_mish<NT>(v, ld4(a.bc[0]), ld4(a.gam[0]), ld4(a.bet[0]), L, lane);
+    lvl_conv<NT, 5, 1, XPB>(w5a, X0[0], X0[1], 1, 0, ROWS - 1, lane, v);
+    lvl_conv<NT, 1, 1, XPB>(w1, X0[0], X0[1], 1, 2, ROWS - 1, lane, r1);
+    lvl_wload<10>(Wc1, lane, w10);
+    lvl_gn_mish<NT>(v, pbc[0], pga[0], pbe[0], L, lane);
     {
-        const float4 br = ld4(a.br);
+        const float4 br = pbr;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             v[nt][0] += tb0.x; v[nt][1] += tb0.y; v[nt][2] += tb0.z; v[nt][3] += tb0.w;
@@ -1634,8 +1647,9 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     }
     lvl_to_planes<NT, PPB>(v, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
-    lvl_conv<NT, 5, 2, PPB>(Wc1, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
-    lvl_gn_mish<NT>(v, ld4(a.bc[1]), ld4(a.gam[1]), ld4(a.bet[1]), L, lane);
+    lvl_conv<NT, 5, 2, PPB>(w10, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
+    lvl_wload<10>(Wc2, lane, w10);
+    lvl_gn_mish<NT>(v, pbc[1], pga[1], pbe[1], L, lane);
     f32x4 h1[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) h1[nt] = v[nt] + r1[nt];
@@ -1643,14 +1657,28 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     lvl_to_planes<NT, PPB>(h1, P[1][0], P[1][1], c0, 2, L, lane);
     __syncthreads();
     // ---- block 1 (identity residual) ----
-    lvl_conv<NT, 5, 2, PPB>(Wc2, P[1][0], P[1][1], 1, 0, ROWS - 1, lane, v);
-    lvl_gn_mish<NT>(v, ld4(a.bc[2]), ld4(a.gam[2]), ld4(a.bet[2]), L, lane);
+    lvl_conv<NT, 5, 2, PPB>(w10, P[1][0], P[1][1], 1, 0, ROWS - 1, lane, v);
+    lvl_wload<10>(Wc3, lane, w10);
+    lvl_gn_mish<NT>(v, pbc[2], pga[2], pbe[2], L, lane);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { v[nt][0] += tb1.x; v[nt][1] += tb1.y; v[nt][2] += tb1.z; v[nt][3] += tb1.w; }
     lvl_to_planes<NT, PPB>(v, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
-    lvl_conv<NT, 5, 2, PPB>(Wc3, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
-    lvl_gn_mish<NT>(v, ld4(a.bc[3]), ld4(a.gam[3]), ld4(a.bet[3]), L, lane);
+    lvl_conv<NT, 5, 2, PPB>(w10, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
+    // the attention's q | k | v fragments of this wave's head (tiles 2w, 2w+1 of q, k, v), requested two barriers ahead
+    half8 wh[2][6], wl[2][6];
+    {
+        const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int tile = (s >> 1) * 8 + 2 * w + (s & 1);
+                wh[k][s] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 0) * 64 + lane]);
+                wl[k][s] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 1) * 64 + lane]);
+            }
+    }
+    lvl_gn_mish<NT>(v, pbc[3], pga[3], pbe[3], L, lane);
     f32x4 h2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) h2[nt] = v[nt] + h1[nt];
@@ -1686,7 +1714,6 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     __syncthreads();
     f32x4 qa[2][NT], ka[NT][2], va[NT][2];
     {
-        const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
         f32x4 qM[2][NT], qL[2][NT], kM[NT][2], kL[NT][2], vM[NT][2], vL[NT][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1695,15 +1722,6 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
                 qM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; qL[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 kM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; kL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 vM[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; vL[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        half8 wh[2][6], wl[2][6];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int tile = (s >> 1) * 8 + 2 * w + (s & 1);
-                wh[k][s] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 0) * 64 + lane]);
-                wl[k][s] = __builtin_bit_cast(half8, Wq4[(((size_t)tile * 2 + k) * 2 + 1) * 64 + lane]);
             }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -1734,6 +1752,9 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
                 va[j][i] = vM[j][i] + vL[j][i] * H3_INV;
             }
     }
+    float4 wo4[4][2], wd6[6][2];                             // out projection and Downsample1d fragments: in flight during the core
+    lvl_wload<4>(reinterpret_cast<const float4*>(a.Wo) + (size_t)w * (4 * 2 * 64), lane, wo4);
+    lvl_wload<6>(Wd4, lane, wd6);
     f32x4 att[2][NT];
     attn_site_core<NT>(qa, ka, va, att, 1, NP, NP, L, lq, lr);
 #pragma unroll
@@ -1750,9 +1771,8 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     __syncthreads();
     f32x4 h3[NT];
     {
-        const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo) + (size_t)w * (4 * 2 * 64);
-        lvl_conv<NT, 1, 4, APB>(Wo4, Ap[0], Ap[1], 1, 0, NP - 1, lane, h3);
-        const float4 bo = ld4(a.bo);
+        lvl_conv<NT, 1, 4, APB>(wo4, Ap[0], Ap[1], 1, 0, NP - 1, lane, h3);
+        const float4 bo = pbo;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             h3[nt][0] += bo.x; h3[nt][1] += bo.y; h3[nt][2] += bo.z; h3[nt][3] += bo.w;
@@ -1765,8 +1785,8 @@ __global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
     // ---- Downsample1d: out[n'] = sum_tap W[tap] h3[2 n' + tap - 1] + bd ----
     {
         f32x4 d[1];
-        lvl_conv<1, 3, 2, PPB>(Wd4, P[0][0], P[0][1], 2, 1, ROWS - 1, lane, d);
-        const float4 bd = ld4(a.bd);
+        lvl_conv<1, 3, 2, PPB>(wd6, P[0][0], P[0][1], 2, 1, ROWS - 1, lane, d);
+        const float4 bd = pbd;
         d[0][0] += bd.x; d[0][1] += bd.y; d[0][2] += bd.z; d[0][3] += bd.w;
         lvl_store<1>(d, a.down + (size_t)b * (L / 2) * C, c0, L / 2, lane);
     }
