@@ -1930,7 +1930,14 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
 #pragma unroll
         for (int i = 0; i < 17; ++i) PV[i][tid] = src[i][tid];
     }
-    // ---- stage x: sample tile nt at rows nt*RS + 2 + position; everything else zero ----
+    // ---- stage x: sample tile nt at rows nt*RS + 2 + position; everything else zero.  The rows are requested BEFORE the zero
+    // fill and its barrier (after them, their round trip opened every launch) ----
+    float4 xin[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        xin[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nt < s_here && (tid >> 4) < L) xin[nt] = *reinterpret_cast<const float4*>(a.x + ((size_t)(s0 + nt) * L + (tid >> 4)) * CI + 4 * (tid & 15));
+    }
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(R)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -1940,7 +1947,7 @@ __global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
         for (int pass = 0; pass < NT; ++pass) {
             const int nt = pass, p = tid >> 4;                           // 16 positions per pass = one sample tile
             if (nt < s_here && p < L) {
-                const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(s0 + nt) * L + p) * CI + 4 * c4);
+                const float4 v = xin[nt];
                 half4v hi, lo;
                 hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
                 lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
@@ -2288,6 +2295,15 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         for (int i = 0; i < 13; ++i) PV[i][c] = src[i][c];
         PV[13][c] = c < a.F ? a.bf[c] : 0.f;
     }
+    float4 xin[4];                                                       // cat(x, skip) rows, requested before the zero fill and its barrier
+    if ((tid >> 4) < L) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = tid >> 4, cf = (tid & 15) + 16 * q;            // float4 index over the 256 channels
+            const float* src = cf < 32 ? a.x + ((size_t)b * L + p) * 128 + 4 * cf : a.skip + ((size_t)b * L + p) * 128 + 4 * (cf - 32);
+            xin[q] = *reinterpret_cast<const float4*>(src);
+        }
+    }
     for (int i = tid; i < 2 * ROWS1 * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2297,9 +2313,8 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         if (p < L) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cf = c4 + 16 * q;                              // float4 index over the 256 channels
-                const float* src = cf < 32 ? a.x + ((size_t)b * L + p) * 128 + 4 * cf : a.skip + ((size_t)b * L + p) * 128 + 4 * (cf - 32);
-                const float4 v = *reinterpret_cast<const float4*>(src);
+                const int cf = c4 + 16 * q;
+                const float4 v = xin[q];
                 half4v hi, lo;
                 hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
                 lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
@@ -2574,6 +2589,11 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) PV[i][tid] = src[i][tid];
     }
+    float4 xin[4];                                                       // the input rows, requested before the zero fill and its barrier
+    if ((tid >> 4) < L) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xin[q] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + (tid >> 4)) * CI + 4 * ((tid & 15) + 16 * q));
+    }
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -2583,7 +2603,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cf = c4 + 16 * q;
-                const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + p) * CI + 4 * cf);
+                const float4 v = xin[q];
                 half4v hi, lo;
                 hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
                 lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
