@@ -1395,6 +1395,18 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             for (int pl = 0; pl < 2; ++pl)
                 wo[t][k][pl] = (t < TPW) ? Wo4[(((size_t)(w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // the first output tile's bias and residual rows, requested before the core (requested in the epilogue, their L2 round trip
+    // was exposed once per launch; the later tiles' loads overlap the earlier tiles' products)
+    float4 eb0 = make_float4(0.f, 0.f, 0.f, 0.f), ex0[NT];
+    {
+        const int c = (w * TPW) * 16 + lq * 4;
+        eb0 = *reinterpret_cast<const float4*>(a.bo + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
+            ex0[nt] = (n < nend && pn < L) ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     // ---- core ----
     f32x4 att[2][NT];
     attn_site_core<NT>(qa, ka, va, att, a.dbg == 3 ? 0 : s_here, nend, slot, L, lq, lr);
@@ -1442,14 +1454,14 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             }
         }
         const int c = ct * 16 + lq * 4;
-        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+        const float4 b = t == 0 ? eb0 : *reinterpret_cast<const float4*>(a.bo + c);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 z = zM[nt] + zL[nt] * H3_INV;
             const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
             if (n < nend && pn < L) {
                 const size_t row = row0 + sn * L + pn;
-                const float4 xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+                const float4 xv = t == 0 ? ex0[nt] : *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
                 float4 o;
                 o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
                 *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;

@@ -1184,6 +1184,19 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             va[0][i][r] = (Part[0][16 + i * 4 + r][lane] + Part[1][16 + i * 4 + r][lane]) + (Part[2][16 + i * 4 + r][lane] + Part[3][16 + i * 4 + r][lane]);
         }
 
+    // the epilogue's bias and residual rows, requested before the core and the exchange (requested in the epilogue, their L2
+    // round trip was the tail of the launch)
+    float4 eb[TPW], ex[TPW];
+    {
+        const int n = lr, sn = n / slot, pn = n - sn * slot;
+        const bool ok = n < nend && pn < L;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int c = (hd * CT4 + w * TPW + t) * 16 + lq * 4;
+            eb[t] = *reinterpret_cast<const float4*>(a.bo + c);
+            ex[t] = ok ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     // ---- core: wave w owns sample w of the group ----
     f32x4 att[2][1];
     attn_site_core_range<1>(qa, ka, va, att, w, min(w + 1, s_here), nend, slot, L, lq, lr);
@@ -1256,12 +1269,12 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             zL = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, zL, 0, 0, 0);
         }
         const int c = ct * 16 + lq * 4;
-        const float4 b = *reinterpret_cast<const float4*>(a.bo + c);
+        const float4 b = eb[t];
         const f32x4 z = zM + zL * H3_INV;
         const int n = lr, sn = n / slot, pn = n - sn * slot;
         if (n < nend && pn < L) {
             const size_t row = row0 + sn * L + pn;
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+            const float4 xv = ex[t];
             float4 o;
             o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
             *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
