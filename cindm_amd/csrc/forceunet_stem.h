@@ -13,10 +13,10 @@
 //     T[y][x'][b*4 + ci] = sum_a sum_co g[y + a - 3][x'][co] W[co][ci][6 - a][6 - b] ;  dx[y][x][ci] = sum_b T[y][x + b - 3][b*4 + ci]
 // turned into a SCATTER over the staged gradient rows: a workgroup walks down a 16-row strip one gradient row at a time,
 // multiplies the row by all 7 vertical taps (84 MFMAs per 16 pixels) and adds tap a's product into the accumulator of output
-// row r + 3 - a; seven output rows are in flight in the MFMA accumulators (rotating, the row loop is unrolled by 7), the
-// weights never leave the wave.  Only ONE gradient row is staged at a time, with a power-of-two scale from the maxima of the
-// rows around it (exact; depends on nothing outside the image: a design's gradient stays independent of its batch) -- no pass
-// over the tensor for a maximum is needed.  HBM: g is read 22 / 16 times instead of 10 / 4.
+// row r + 3 - a; seven output rows are in flight in registers (rotating, the row loop is unrolled by 7), the weights never leave
+// the wave.  Only ONE gradient row is staged at a time, so its power-of-two scale is the row's own (exact; depends on nothing
+// outside the image: a design's gradient stays independent of its batch) and no pass over the tensor for a maximum is
+// needed.  HBM: g is read 22 / 16 times instead of 10 / 4.
 #pragma once
 #include "forceunet_la.h"
 #include <type_traits>
@@ -122,12 +122,11 @@ __device__ __forceinline__ float pow2_of_exp(int se) { return __builtin_bit_cast
 
 // W: [tap a (7)][kk (2: channels 0..31 | 32..63)][nb (2)][plane (2)][lane (64)][8 halfs]; lane (lr = n in tile, lq), half j:
 // A[n = nb*16 + lr][co = kk*32 + lq*8 + j] = W[co][ci = n & 3][6 - a][6 - (n >> 2)], zero for n >= 28.  64-pixel-wide images.
-// Wave w = (column block nb = w & 1 of T, pixel blocks 2 (w >> 1), 2 (w >> 1) + 1): its 112 weight registers stay in VGPRs, its
-// 7 rows x 2 pixel blocks x (main, low) accumulators are the MFMAs' own C / D operands (AGPRs) -- no VALU per product.  That
-// needs ONE scale for everything an accumulator adds up: a gradient row is staged with the smallest scale (largest magnitude)
-// among itself and the six rows before it -- exactly the rows it can share an accumulator with -- and when that window
-// minimum changes the live accumulators are multiplied by the ratio (a power of two: exact, and by construction everything
-// they hold came from rows inside the window, so nothing overflows).
+// Wave w = (column block nb = w & 1 of T, pixel blocks 2 (w >> 1), 2 (w >> 1) + 1): its 112 weight registers stay in VGPRs.  Each
+// gradient row is staged with ITS OWN power-of-two scale; a tap's product (6 MFMAs from a zero accumulator) is multiplied by
+// the row's inverse scale and added to the fp32 accumulator of the output row it feeds (8 VALU per 6 MFMAs).  A variant that
+// accumulated in the MFMAs' own accumulators (one scale per 7-row window, accumulators rescaled when it moved) was no faster
+// and lost bits of a small row that follows a much larger one within six rows (`tools/micro/stem_bwd.hip --check`).
 __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Args a) {
     constexpr int WD = 64, RO = 16, NR = RO + 6, PB = 144, TP = 33;
     __shared__ __attribute__((aligned(16))) unsigned char Gp[2][2][WD * PB];       // [buffer][plane][pixel][64 halfs + pad]
@@ -146,15 +145,9 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
             wh[ta][kk] = __builtin_bit_cast(half8, W4[((((ta * 2 + kk) * 2 + nb) * 2 + 0) * 64) + lane]);
             wl[ta][kk] = __builtin_bit_cast(half8, W4[((((ta * 2 + kk) * 2 + nb) * 2 + 1) * 64) + lane]);
         }
-    f32x4 aM[7][2], aL[7][2];
+    f32x4 acc[7][2];                                         // the seven output rows in flight x this wave's two pixel blocks
 #pragma unroll
-    for (int s = 0; s < 7; ++s)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) { aM[s][p] = f32x4{0.f, 0.f, 0.f, 0.f}; aL[s][p] = aM[s][p]; }
-    int hist[7];                                             // scale exponents of the last seven staged rows (253 = an all-zero row)
-#pragma unroll
-    for (int s = 0; s < 7; ++s) hist[s] = 253;
-    int ref = 253;                                           // the window minimum = the scale of everything the accumulators hold
+    for (int s = 0; s < 7; ++s) { acc[s][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][1] = acc[s][0]; }
     // staging role of a thread: pixels p0 + 16 j (j < 4), channel quad c4.  Rows outside the image are staged as zeros, so
     // that every row of the strip runs the same instruction stream.
     const int p0 = tid >> 4, c4 = tid & 15;
@@ -179,7 +172,7 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
     };
     auto red_exp = [&](int q) {
         const float mx = fmaxf(fmaxf(red[q][0], red[q][1]), fmaxf(red[q][2], red[q][3]));
-        return mx == 0.f ? 253 : scale_exp_of(mx);
+        return scale_exp_of(mx);
     };
     auto store_row = [&](int q, float sc) {
 #pragma unroll
@@ -193,13 +186,6 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
             *reinterpret_cast<half4v*>(&Gp[q][0][off]) = hi;
             *reinterpret_cast<half4v*>(&Gp[q][1][off]) = lo;
         }
-    };
-    auto rescale = [&](int d) {                              // accumulators *= 2^d
-        const float f = pow2_of_exp(min(max(127 + d, 1), 254));
-#pragma unroll
-        for (int s = 0; s < 7; ++s)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) { aM[s][p] *= f; aL[s][p] *= f; }
     };
     const int ox = tid >> 2, oc = tid & 3;                  // output role: pixel ox, channel oc
     auto row_sum = [&](int q, int oy) {                      // dx row oy of the strip from the T row in Ts[q]
@@ -218,9 +204,9 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
     load_row(0);
     row_max(0);
     __syncthreads();
-    hist[0] = red_exp(0);
-    ref = hist[0] == 253 ? 253 : max(hist[0] - 1, 1);
-    store_row(0, pow2_of_exp(ref == 253 ? 127 : ref));
+    int se = red_exp(0);
+    float inv_cur = pow2_of_exp(254 - se);                   // inverse scale of the row the planes hold
+    store_row(0, pow2_of_exp(se));
     load_row(1);
     row_max(1);
     __syncthreads();
@@ -236,23 +222,16 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
             const int rr = it * 7 + j, buf = rr & 1;
             if (rr < NR) {                                   // (uniform)
                 FU_STEM_MARK(0);
-                // (A) the scale of row rr + 1: the accumulators' scale `ref` is kept while it stays within [window minimum - 4,
-                // window minimum + 1] -- nothing overflows (|value| < 2^15) and at most four of fp16's low binades go unused --
-                // and re-centred one below the minimum otherwise (the accumulators follow AFTER this row's products, below)
-                hist[(j + 1) % 7] = red_exp(buf ^ 1);
-                int nref = hist[0];
-#pragma unroll
-                for (int s = 1; s < 7; ++s) nref = min(nref, hist[s]);
-                if (nref == 253) nref = ref;
-                else if (ref != 253 && ref >= nref - 4 && ref <= nref + 1) nref = ref;
-                else nref = max(nref - 1, 1);
-                store_row(buf ^ 1, pow2_of_exp(nref == 253 ? 127 : nref));
+                // (A) row rr + 1 with the scale of its own maximum
+                se = red_exp(buf ^ 1);
+                const float inv_next = pow2_of_exp(254 - se);
+                store_row(buf ^ 1, pow2_of_exp(se));
                 load_row(rr + 2);                            // (B)
                 FU_STEM_MARK(1);
                 row_sum(buf ^ 1, rr - 7);                    // (C)
                 FU_STEM_MARK(2);
-                // (D) tap a of row rr feeds output row rr - a, whose accumulators are slot (rr - a) mod 7; tap 0 OPENS a slot (zero C
-                // operand).  Slots of rows outside the strip are fed like the others and never written out.
+                // (D) tap a of row rr feeds output row rr - a, whose accumulator is slot (rr - a) mod 7; tap 0 OPENS a slot.  Slots of
+                // rows outside the strip are fed like the others and never written out.
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int boff = ((pb0 + p) * 16 + lr) * PB + lq * 16;
@@ -261,12 +240,14 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
 #pragma unroll
                     for (int ta = 0; ta < 7; ++ta) {
                         const int slot = (j - ta + 7) % 7;
-                        aM[slot][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][0], gh0, ta == 0 ? zero4 : aM[slot][p], 0, 0, 0);
-                        aL[slot][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][0], gl0, ta == 0 ? zero4 : aL[slot][p], 0, 0, 0);
-                        aL[slot][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ta][0], gh0, aL[slot][p], 0, 0, 0);
-                        aM[slot][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][1], gh1, aM[slot][p], 0, 0, 0);
-                        aL[slot][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][1], gl1, aL[slot][p], 0, 0, 0);
-                        aL[slot][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ta][1], gh1, aL[slot][p], 0, 0, 0);
+                        f32x4 M = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][0], gh0, zero4, 0, 0, 0);
+                        f32x4 Lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][0], gl0, zero4, 0, 0, 0);
+                        Lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ta][0], gh0, Lo, 0, 0, 0);
+                        M = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][1], gh1, M, 0, 0, 0);
+                        Lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ta][1], gl1, Lo, 0, 0, 0);
+                        Lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ta][1], gh1, Lo, 0, 0, 0);
+                        const f32x4 pr = (M + Lo * H3_INV) * inv_cur;
+                        acc[slot][p] = ta == 0 ? pr : acc[slot][p] + pr;
                     }
                 }
                 FU_STEM_MARK(3);
@@ -274,15 +255,12 @@ __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Ar
                 // (F) output row rr - 6 has its last contribution (tap 6 of this row)
                 {
                     const int sd = (j + 1) % 7;
-                    const float inv = pow2_of_exp(ref == 253 ? 127 : 254 - ref);
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const f32x4 t = (aM[sd][p] + aL[sd][p] * H3_INV) * inv;
+                    for (int p = 0; p < 2; ++p)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) Ts[buf][((pb0 + p) * 16 + lr) * TP + nb * 16 + lq * 4 + i] = t[i];
-                    }
+                        for (int i = 0; i < 4; ++i) Ts[buf][((pb0 + p) * 16 + lr) * TP + nb * 16 + lq * 4 + i] = acc[sd][p][i];
                 }
-                if (nref != ref) { if (ref != 253) rescale(nref - ref); ref = nref; }      // (uniform, rare)
+                inv_cur = inv_next;
                 FU_STEM_MARK(4);
                 __syncthreads();
                 FU_STEM_MARK(5);

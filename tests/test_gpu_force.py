@@ -323,3 +323,19 @@ def test_forceunet_fused_linear_attention_vs_layered(device, mults):
         out2, dx2 = m.input_grad(x.to(device), lambda_force=1.1)
         assert torch.equal(out2, res[fused][0]) and torch.equal(dx2, res[fused][1])        # repeatable bit for bit
     assert rel(res[1][1], res[0][1].cpu().numpy()) < TOL
+
+
+def test_stem_input_gradient_adversarial_row_scales(tmp_path):
+    """fu_stem_bwd_h3_kernel stages one gradient row at a time with the row's own power-of-two scale.  Ordinary gradients never
+    stress that: tools/micro/stem_bwd.hip --check drives the kernel directly with rows whose magnitudes differ by up to 2^60
+    (and a band of exactly-zero rows) and compares every output row with a double-precision evaluation on the host."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = str(tmp_path / "stem_bwd.bin")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "micro", "stem_bwd.hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", src, "-o", exe], check=True)
+    r = subprocess.run([exe, "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -25,8 +25,9 @@ elif wl == "cfg2-ddim250":
     run = lambda n: d.ddim_sample((B, 24, 8), None, seed=1, step_range=(0, n), init_img=torch.zeros((B, 24, 8), device=dev))
     first = 2
 else:
-    kw = w.get("compose_kw", dict(n_composed=0))
-    run = lambda n: d.sample(batch_size=B, cond=None, compose_n_bodies=2, seed=1, t_stop=1000 - n, **kw)
+    kw = dict(n_composed=0, compose_n_bodies=2)
+    kw.update(w.get("compose_kw", {}))
+    run = lambda n: d.sample(batch_size=B, cond=None, seed=1, t_stop=1000 - n, **kw)
     first = 2
 run(first)
 torch.cuda.synchronize()
