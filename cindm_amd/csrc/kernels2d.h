@@ -1101,6 +1101,61 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void conv1x1_wide_kernel(const Co
     }
 }
 
+// tail_identity_kernel<C>: the ResnetBlock tail without a res_conv -- out = x + SiLU(GroupNorm(y1)) (+ LayerNorm partials when an
+// attention follows) -- as a plain element-wise pass.  Through conv1x1_wide_kernel's identity mode the x tile went global ->
+// registers -> LDS -> barrier -> registers and the y1 rows were requested only in the epilogue: two HBM round trips in series
+// per 64-pixel workgroup (3.2 TB/s at 64 x 64, 128 images).  Here a thread owns channel quad (tid % (C/4)) of rows tid / (C/4) +
+// k * (256 / (C/4)), requests all its x and y1 quads at once, and writes the same expression in the same order (bit-identical
+// output).  Workgroup = 64 rows of one image; the LayerNorm partial of a pixel's 16 channels is a quad reduction.
+template <int C>
+__global__ __launch_bounds__(256) void tail_identity_kernel(const Conv2dArgs a) {
+    constexpr int F4 = C / 4, RPP = 256 / F4, NPASS = 64 / RPP;
+    __shared__ float tabE[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const int img = (int)(row0 / (a.Hout * a.Wout));
+    const int c4 = tid % F4, r0 = tid / F4, col = c4 * 4;
+    const Src& s0 = a.src[0];
+    float4 xv[NPASS], yv[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const size_t prow = row0 + r0 + p * RPP;
+        xv[p] = *reinterpret_cast<const float4*>(s0.p + prow * s0.ld + col);
+        yv[p] = *reinterpret_cast<const float4*>(a.e_y + prow * a.e_ld + col);
+    }
+    if (w == 1) {
+        float m, r;
+        merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
+        if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
+    }
+    const float4 eg = *reinterpret_cast<const float4*>(a.e_gamma + col), eb = *reinterpret_cast<const float4*>(a.e_beta + col);
+    __syncthreads();
+    const int g = col >> (31 - __builtin_clz(a.e_gw));
+    const float em = tabE[2 * g], er = tabE[2 * g + 1];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const size_t prow = row0 + r0 + p * RPP;
+        const float4 y = yv[p];
+        float4 v = make_float4(xv[p].x + 0.f, xv[p].y + 0.f, xv[p].z + 0.f, xv[p].w + 0.f);       // (the GEMM path adds a zero bias)
+        v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
+        v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
+        *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
+        if (a.ln_out) {
+            // LayerNorm partial over 16 channels = the four lanes of a quad, summed (a0 + a1) + (a2 + a3) as the GEMM path does
+            float sm = (v.x + v.y) + (v.z + v.w);
+            sm += dpp_get<0xB1>(sm); sm += dpp_get<0x4E>(sm);
+            const float mean = sm * (1.0f / 16.0f);
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            m2 += dpp_get<0xB1>(m2); m2 += dpp_get<0x4E>(m2);
+            if ((c4 & 3) == 0) {
+                float* o = a.ln_out + (prow * (C / 16) + (c4 >> 2)) * 2;
+                o[0] = mean; o[1] = m2;
+            }
+        }
+    }
+}
+
 // conv1x1_tail_h3_kernel<KT>: the ResnetBlock tails that carry a real GEMM -- out = res_conv(cat(x0, x1)) + bias +
 // SiLU(GN(y1)) (+ LayerNorm partials), KT = 128 or 192 input channels -- on the split-fp16 products.  On the fp32 MFMA
 // (conv1x1_wide_kernel) these launches were co-bound by the matrix pipe (8.6 GFLOP = 55 us at the fp32 peak for 536 MB

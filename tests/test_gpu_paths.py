@@ -79,8 +79,8 @@ def test_unet1d_paths_chain_and_ragged(gold_dir, device, opts):
     assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
 
 
-@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}, {"tail_h3": 0}],
-                         ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0", "tail_h3_0"])
+@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}, {"tail_h3": 0}, {"tail_ew": 0}],
+                         ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0", "tail_h3_0", "tail_ew_0"])
 def test_unet2d_paths_golden(gold_dir, device, opts):
     from test_gpu_parity_2d import build_unet2d
     g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
@@ -90,6 +90,25 @@ def test_unet2d_paths_golden(gold_dir, device, opts):
     x = torch.from_numpy(g["x"]).to(device)
     for t in (0, 500, 999):
         assert rel(m(x, torch.full((2,), t, device=device)), g[f"eps_t{t}"]) < TOL_FWD, (opts, t)
+
+
+def test_unet2d_identity_tail_paths_bitwise(device):
+    """The ResnetBlock tail without a res_conv as an element-wise pass (tail_identity_kernel, option tail_ew = 1) writes the same
+    expression in the same order as the 1x1 kernel's identity mode it replaces: outputs and every block tap (incl. the ones whose
+    LayerNorm partials feed an attention) are bit-identical."""
+    from test_gpu_parity_2d import build_unet2d
+    m, _ = build_unet2d(device)
+    x = torch.randn((4, 21, 64, 64), generator=torch.Generator().manual_seed(11)).to(device)
+    t = torch.full((4,), 700, device=device)
+    names = ["downs.0.0", "downs.0.1", "downs.0.2", "downs.1.0", "downs.1.2", "mid_block1", "mid_attn", "mid_block2", "ups.1.1", "ups.1.2", "final_res_block"]
+    res = {}
+    for v in (1, 0):
+        m.set_option("tail_ew", v)
+        y = m(x, t).clone()
+        res[v] = [y] + [m.tap(n, 4).clone() for n in names]
+    m.set_option("tail_ew", 1)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("conv_ws", [1, 2, 3], ids=["all", "plain_only", "groupnorm_only"])
