@@ -38,6 +38,7 @@ if [ "$what" = 2d ] || [ "$what" = all ]; then
 fi
 if [ "$what" = force ] || [ "$what" = all ]; then
     pmc force 0 python3 /root/repo/tools/bench_force.py 64 2 3
+    cp $out/pmc_traffic_force.json profiles/r03_pmc_traffic_force.json        # the guided bench line adds the surrogate's bytes (hash-checked)
     ktrace force python3 /root/repo/tools/bench_force.py 64 2 10
     python bench.py --workload cfg5g --steps 1 --warmup 1 > $out/bench_cfg5g.json 2> $out/bench_cfg5g.err; cut -c1-200 $out/bench_cfg5g.json
 fi
