@@ -351,6 +351,75 @@ __global__ void fu_gn_silu_bwd_apply_kernel(const float* __restrict__ x, const f
     }
 }
 
+// GroupNorm + SiLU derivative in ONE pass (option gn_bwd_fused): workgroup = (image, group), 512 threads; the group's slice of the
+// convolution output x and of the upstream gradient dy (HW pixels x C / 8 channels each) is read ONCE into registers -- E float4 per
+// thread and tensor (16 at 64 x 64 / 64 channels) --, replaced in place by (z, dz), the two sums cross the workgroup in a fixed
+// order, and dx leaves from the registers.  Memory-side bytes: x + dy + dx instead of 2 (x + dy) + dx; one launch instead of two.
+// A slice is 4 C / 8 bytes per pixel at a pitch of 4 C: the eight groups of an image are placed on ONE XCD (consecutive
+// workgroup ids go round-robin over the XCDs) and start together, so the cache lines they share are fetched from HBM once.
+template <int E>
+__global__ __launch_bounds__(512) void fu_gn_silu_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    const float* __restrict__ stats, const float* __restrict__ gam,
+                                                                    const float* __restrict__ bet, float* __restrict__ dx, float beta,
+                                                                    int HW, int C, int NI, unsigned* __restrict__ pmax) {
+    __shared__ float red[2][8];
+    __shared__ float wm[8];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int img, g;
+    if ((NI & 7) == 0) { const int id = blockIdx.x, k = id >> 3; g = k & 7; img = (k >> 3) * 8 + (id & 7); }
+    else { img = blockIdx.x >> 3; g = blockIdx.x & 7; }
+    const int QP = C >> 5;                                    // float4 per pixel of one group's slice (C / 8 channels)
+    const int q = tid % QP;                                   // (512 is a multiple of QP: a thread keeps its channel quad)
+    const int cq = g * (C >> 3) + 4 * q;
+    const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
+    const float4 ga = *reinterpret_cast<const float4*>(gam + cq), be = *reinterpret_cast<const float4*>(bet + cq);
+    const size_t base = (size_t)img * HW * C + cq;
+    float4 a[E], b[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = (tid + 512 * k) / QP;
+        a[k] = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+        b[k] = *reinterpret_cast<const float4*>(dy + base + (size_t)p * C);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        float z, dz;
+        fu_gn_dz(a[k].x, b[k].x, m, r, ga.x, be.x, z, dz); a[k].x = z; b[k].x = dz; s1 += dz; s2 += dz * z;
+        fu_gn_dz(a[k].y, b[k].y, m, r, ga.y, be.y, z, dz); a[k].y = z; b[k].y = dz; s1 += dz; s2 += dz * z;
+        fu_gn_dz(a[k].z, b[k].z, m, r, ga.z, be.z, z, dz); a[k].z = z; b[k].z = dz; s1 += dz; s2 += dz * z;
+        fu_gn_dz(a[k].w, b[k].w, m, r, ga.w, be.w, z, dz); a[k].w = z; b[k].w = dz; s1 += dz; s2 += dz * z;
+    }
+    for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    const float n = (float)HW * (float)(C / 8);
+    const float a1 = (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) + ((red[0][4] + red[0][5]) + (red[0][6] + red[0][7]))) / n;
+    const float a2 = (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + ((red[1][4] + red[1][5]) + (red[1][6] + red[1][7]))) / n;
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = (tid + 512 * k) / QP;
+        float4 v = make_float4(r * (b[k].x - a1 - a[k].x * a2), r * (b[k].y - a1 - a[k].y * a2), r * (b[k].z - a1 - a[k].z * a2), r * (b[k].w - a1 - a[k].w * a2));
+        float4* o = reinterpret_cast<float4*>(dx + base + (size_t)p * C);
+        if (beta != 0.f) { const float4 e = *o; v.x += beta * e.x; v.y += beta * e.y; v.z += beta * e.z; v.w += beta * e.w; }
+        *o = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (pmax) {
+        if (!(mx <= 3.0e38f)) mx = 3.0e38f;
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) wm[w] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float t = wm[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) t = fmaxf(t, wm[i]);
+            pmax[(size_t)img * 8 + g] = __builtin_bit_cast(unsigned, t);
+        }
+    }
+}
+
 // amax[img] = max over the image's `per` workgroup maxima (bit patterns of non-negative floats order like the floats)
 __global__ __launch_bounds__(256) void fu_amax_reduce_kernel(const unsigned* __restrict__ pmax, unsigned* __restrict__ amax, int per) {
     __shared__ unsigned wm[4];
