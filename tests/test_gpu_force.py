@@ -117,10 +117,10 @@ def test_guided_chain_fused_equals_loop(device, force):
     assert not torch.equal(fused, plain)
 
 
-@pytest.mark.parametrize("opt", ["h3", "h3_bwd"])
+@pytest.mark.parametrize("opt", ["h3", "h3_bwd", "gn_bwd_fused"])
 def test_forceunet_fp32_convolution_paths(device, force, opt):
-    """The exact fp32-MFMA convolutions behind set_option("h3", 0) (forward) / ("h3_bwd", 0) (input gradient) against the
-    oracle's autograd, and the default split-fp16 path against them."""
+    """The exact fp32-MFMA convolutions behind set_option("h3", 0) (forward) / ("h3_bwd", 0) (input gradient), and the two-pass
+    GroupNorm derivative behind ("gn_bwd_fused", 0), against the oracle's autograd, and the default path against them."""
     m, sd = force
     m32 = cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
     m32.load_state_dict(sd, strict=True)
