@@ -181,6 +181,7 @@ static const OptDef kUnet1dOpts[] = {
     {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
+    {"level_occ2", 3, nullptr},        // above 320 rows: level0_down (bit 0) / level1_down (bit 1) capped at 256 registers, two workgroups per CU
     {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled: 0 never, 1 above 320 rows, 2 always
     {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
     {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
@@ -1346,7 +1347,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
-                    if (L > 16) KLAUNCH(E, level0_down_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    if (L > 16 && E.rows > 320 && (h->O("level_occ2") & 1)) KLAUNCH(E, (level0_down_kernel<2, 2>), dim3((unsigned)E.rows), dim3(256), 0, l);
+                    else if (L > 16) KLAUNCH(E, level0_down_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
                     else KLAUNCH(E, level0_down_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, l);
                 }
                 E.prof_end();
@@ -1392,7 +1394,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 const dim3 grid((unsigned)((E.rows + S - 1) / S));
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
-                    if (S == 1) KLAUNCH(E, level1_down_kernel<1>, grid, dim3(256), 0, l);
+                    if (S == 1 && E.rows > 320 && (h->O("level_occ2") & 2)) KLAUNCH(E, (level1_down_kernel<1, 2>), grid, dim3(256), 0, l);
+                    else if (S == 1) KLAUNCH(E, level1_down_kernel<1>, grid, dim3(256), 0, l);
                     else KLAUNCH(E, level1_down_kernel<2>, grid, dim3(256), 0, l);
                 }
                 E.prof_end();

@@ -1586,8 +1586,9 @@ __device__ __forceinline__ void lvl_store(const f32x4 (&v)[NT], float* dst, int 
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void level0_down_kernel(const Level0Args a) {
+// MINB = 2 (more rows than CUs: configs 3 / 4): registers capped at 256 so that two workgroups share a CU (52 KB of LDS each)
+template <int NT, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args a) {
     constexpr int C = 64, NP = NT * 16, ROWS = NP + 4;               // two halo positions on each side
     constexpr int XPB = 2 * 32 + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char X0[2][ROWS * XPB];          // input, F padded to 32 channels
@@ -1910,8 +1911,8 @@ __device__ __forceinline__ void lvlm_gn_mish(f32x4& v, const float4 bias, const 
     for (int i = 0; i < 4; ++i) v[i] = mish_f((v[i] - mean) * rstd * gg[i] + be[i]);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void level1_down_kernel(const Level1Args a) {
+template <int NT, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args a) {
     constexpr int C = 128, CI = 64, RS = 20, ROWS = NT * RS, NP = NT * 16;
     constexpr int XPB = 2 * CI + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
     constexpr int RBYTES = (2 * ROWS * XPB > 2 * NP * APB) ? 2 * ROWS * XPB : 2 * NP * APB;
