@@ -324,3 +324,45 @@ def test_bench_refuses_world_size_mismatch():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_drops_pmc_fields_measured_on_another_library(tmp_path, monkeypatch):
+    """The PMC-derived fields of the bench line come from committed files stamped with the source hash of the library they were
+    measured on: a file from another library must yield (None, reason), a matching one its numbers; the surrogate's per-call
+    bytes are the sum over the gradient calls in the trace minus the diffusion U-Net's share of the kernels both networks use."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from cindm_amd import _ffi
+    have = _ffi.lib().cindm_source_hash().decode()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    step = {"bytes_per_step": 1000, "steps_traced": 2, "source_hash": have,
+            "kernels": {"void cindm::dconv2_kernel<3, 4, 0, false, 4>(cindm::Dconv2Args)": {"launches": 3, "hbm_bytes_per_launch": 40},
+                        "void cindm::dconv_kernel<3, 2, 0, true>(cindm::DconvArgs)": {"launches": 1, "hbm_bytes_per_launch": 80},
+                        "cindm::dconv_epoch_kernel(int*)": {"launches": 5, "hbm_bytes_per_launch": 9999}}}
+    (prof / "ok.json").write_text(json.dumps(step))
+    (prof / "stale.json").write_text(json.dumps(dict(step, source_hash="0" * 64)))
+    v, note = bench.pmc_step_traffic("ok.json")
+    assert v == 1000 and have[:12] in note
+    v, note = bench.pmc_step_traffic("stale.json")
+    assert v is None and "dropped" in note
+    v, note = bench.pmc_step_traffic("absent.json")
+    assert v is None and "not present" in note
+    assert bench.pmc_traffic("ok.json", ("dconv_kernel<", "dconv2_kernel<")) == (3 * 40 + 80) // 4       # the epoch kernel is not a convolution
+    # surrogate: 2 gradient calls; shared kernels carry 1 U-Net forward's share (per forward = (4 * 10 + 2 * 5) / 2 in the config-5 file)
+    force = {"source_hash": have, "kernels": {
+        "cindm::fu_stem_bwd_h3_kernel(cindm::FuStemBwdH3Args)": {"launches": 2, "hbm_bytes_per_launch": 100},
+        "void cindm::conv2d_ws_kernel<0, 0>(cindm::Conv2dArgs)": {"launches": 10, "hbm_bytes_per_launch": 30},
+        "void cindm::conv2d_ws_kernel<0, 4>(cindm::Conv2dArgs)": {"launches": 3, "hbm_bytes_per_launch": 7777},        # U-Net only
+        "cindm::conv2d_stem7_h3_kernel(cindm::Conv2dArgs)": {"launches": 1, "hbm_bytes_per_launch": 5555}}}           # one U-Net forward
+    cfg5 = {"source_hash": have, "kernels": {
+        "cindm::conv2d_stem7_h3_kernel(cindm::Conv2dArgs)": {"launches": 2, "hbm_bytes_per_launch": 1},
+        "void cindm::conv2d_ws_kernel<0, 0>(cindm::Conv2dArgs)": {"launches": 4, "hbm_bytes_per_launch": 10},
+        "void cindm::la2d_context_kernel<64>(cindm::La2dArgs)": {"launches": 2, "hbm_bytes_per_launch": 5}}}
+    (prof / "force.json").write_text(json.dumps(force))
+    (prof / "r03_pmc_traffic_cfg5.json").write_text(json.dumps(cfg5))
+    v, note = bench.pmc_surrogate_traffic("force.json")
+    assert v == int((2 * 100 + 10 * 30 - 25.0 * 1) / 2) and "2 gradient calls" in note
