@@ -16,6 +16,11 @@ Inputs (weights, state) are resident in HBM when the timed region starts.
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank samples its own designs
 (weak scaling, no communication inside the loop) and the final designs are all-gathered over RCCL.
 Prints ONE JSON line on rank 0, with `roofline`, `cpu_baseline` and `rel_err` for every workload.
+
+The default run (cfg2, one GPU) also times EVERY other BASELINE configuration after the headline's timed region -- a few chains
+each of cfg3, cfg4, cfg2-ddim250 and cfg5 and a step-bounded sample of cfg5g, each with its own rel_err against the oracle, its
+roofline fraction and a bounded CPU baseline -- and nests the compact records under "workloads" in the same line
+(--no-extra-workloads skips them; they add about a minute).
 """
 import argparse
 import json
@@ -109,6 +114,7 @@ def spawn_ranks_if_needed(args):
 
 
 FLOP_PER_IMAGE_2D = 10.467e9       # per Unet evaluation of one 64x64 image
+PMC_CFG5_FILE = "r04_pmc_traffic_cfg5.json"
 
 
 def pmc_surrogate_traffic(fname):
@@ -137,7 +143,7 @@ def pmc_surrogate_traffic(fname):
     # bytes in the config-5 passes times the U-Net forwards in this trace (one stem launch each)
     shared = ("conv2d_ws_kernel<0, 0>", "la2d_context_kernel", "la2d_apply_out_kernel")
     try:
-        k5 = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg5.json")))["kernels"]
+        k5 = json.load(open(os.path.join(ROOT, "profiles", PMC_CFG5_FILE)))["kernels"]
         f5 = sum(v["launches"] for k, v in k5.items() if "conv2d_stem7" in k)
         per_fwd = sum(v["launches"] * v["hbm_bytes_per_launch"] for k, v in k5.items() if any(u in k for u in shared)) / max(f5, 1)
         tot -= per_fwd * sum(v["launches"] for k, v in ks.items() if "conv2d_stem7" in k)
@@ -160,57 +166,99 @@ def pmc_traffic(fname, substr):
     return int(b / n) if n else None
 
 
-def cpu_baseline_2d(sd, budget_s=20.0):
-    """The oracle's 2-D reverse step (torch-CPU port of the reference) on a bounded sample: steps of 4 designs x 2
-    boundaries, extrapolated to 1000 steps."""
+PMC_PREFIX = "r04_pmc_traffic_"        # profiles/<prefix><workload>.json, written by tools/r4_measure.sh (hash-checked)
+
+
+def timed_cpu_steps(step_once, budget_s, reps=3, max_steps=100):
+    """Best of `reps` repetitions of a block of CPU reverse steps (a baseline that moves 2x with the host's load needs a
+    minimum, not a mean): `step_once(k)` advances the CPU chain by its k-th step; every repetition continues the chain.
+    Returns (best seconds per step, steps taken in total, per-repetition ms per step)."""
+    per = []
+    k = 0
+    for r in range(reps):
+        n, t0 = 0, time.time()
+        while True:
+            step_once(k)
+            k += 1; n += 1
+            if time.time() - t0 > budget_s / reps or k >= max_steps * (r + 1) // reps:
+                break
+        per.append((time.time() - t0) / n)
+    return min(per), k, [round(v * 1e3, 1) for v in per]
+
+
+def thread_sweep(step_fn, hint=None):
+    """One CPU step per thread count; returns (fastest count, {count: seconds}).  With `hint` (the count another workload's
+    sweep on this host chose) nothing is swept."""
+    model, phys = cpu_info()
+    default_threads = torch.get_num_threads()
+    if hint:
+        return int(hint), {}
+    sweep = {}
+    for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)}):
+        torch.set_num_threads(nt)
+        step_fn()
+        t0 = time.time()
+        step_fn()
+        sweep[nt] = time.time() - t0
+    return min(sweep, key=sweep.get), sweep
+
+
+def cpu_baseline_2d(sd, budget_s=20.0, threads_hint=None, guided_sd=None, Bc=4):
+    """The oracle's 2-D reverse step (torch-CPU port of the reference) on a bounded sample: steps of Bc designs x 2
+    boundaries, extrapolated to 1000 steps; `guided_sd`: under the airfoil design objective (the ForceUnet surrogate's
+    forward + autograd per step, inference/inverse_design_2d.py:208-214).  Also returns what the rel_err leg replays:
+    (x0, [(t, noise)], final CPU state, design_fn or None)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cindm_oracle as O
     od = O.Diffusion2D(sd, image_size=64, frames=6)
-    Bc, nb = 4, 2
+    nb = 2
     g = torch.Generator().manual_seed(0)
-    x = torch.randn((Bc * nb, 21, 64, 64), generator=g)
-    nz = O.sample_noise_2d(torch.randn((Bc, 1, 18, 64, 64), generator=g), torch.randn((Bc, nb, 3, 64, 64), generator=g)).reshape(Bc * nb, 21, 64, 64)
+    x0 = torch.randn((Bc * nb, 21, 64, 64), generator=g)
     shape = (Bc, nb, 21, 64, 64)
+    draw = lambda: O.sample_noise_2d(torch.randn((Bc, 1, 18, 64, 64), generator=g), torch.randn((Bc, nb, 3, 64, 64), generator=g)).reshape(Bc * nb, 21, 64, 64)
+    fn, guid = None, "standard"
+    if guided_sd is not None:
+        def fn(z):
+            with torch.enable_grad():       # (the oracle takes the objective's gradient with autograd, as the reference's design_fn does)
+                return O.airfoil_design_grad(guided_sd, z, Bc, nb, 6, p_min=-37.7, p_max=57.6).detach()
+        guid = "standard-alpha"
     cpu_model, phys = cpu_info()
     default_threads = torch.get_num_threads()
-    sweep = {}
+    nz0 = draw()
+    step = lambda x, t, nz: O.p_sample_2d(od, shape, x, t, nz, fn, guid)[0]
     with torch.no_grad():
-        O.p_sample_2d(od, shape, x, 500, nz)
-        # the reference's best CPU number: one step per thread count, the fastest runs the timed sample
-        for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)}):
-            torch.set_num_threads(nt)
-            t0 = time.time()
-            O.p_sample_2d(od, shape, x, 500, nz)
-            sweep[nt] = time.time() - t0
-        best = min(sweep, key=sweep.get)
+        best, sweep = thread_sweep(lambda: step(x0, 500, nz0), threads_hint)
         torch.set_num_threads(best)
-        n, t0 = 0, time.time()
-        while True:
-            x, _ = O.p_sample_2d(od, shape, x, 500 - n, nz)
-            n += 1
-            if time.time() - t0 > budget_s or n >= 50:
-                break
-        dt = (time.time() - t0) / n
+        state = {"x": x0.clone()}
+        tape = []
+
+        def once(k):
+            nz = draw()
+            tape.append((500 - k, nz))
+            state["x"] = step(state["x"], 500 - k, nz)
+
+        dt, n, per = timed_cpu_steps(once, budget_s, max_steps=30)
         torch.set_num_threads(default_threads)
     out = {"value": Bc / (dt * TIMESTEPS), "unit": "samples/s", "cores": best, "kind": "port",
-           "sample": f"{n} reverse steps of {Bc} designs x {nb} boundaries ({dt * 1e3:.0f} ms/step), extrapolated x{TIMESTEPS}",
-           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())}}
+           "sample": f"{n} reverse steps of {Bc} designs x {nb} boundaries" + (" under the force objective" if fn else "")
+                     + f" (best of 3 repetitions: {dt * 1e3:.0f} ms/step), extrapolated x{TIMESTEPS}",
+           "ms_per_step_per_repetition": per,
+           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())} if sweep
+                                       else f"not swept: {best} threads, the count the headline workload's sweep chose on this host"}
     out.update({"cpu_model": cpu_model, "physical_cores": phys})
-    return out
+    return out, (x0, tape, state["x"], Bc)
 
 
-def main_cfg5(args):
+def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=0):
     """BASELINE configs[4]: airfoil 2-D, Unet(dim=64, dim_mults=(1,2), channels=21) on 64x64, 2-boundary composition,
-    batch 64 designs per GPU (128 images per reverse step), 1000 DDPM steps per design."""
+    batch 64 designs per GPU (128 images per reverse step), 1000 DDPM steps per design (t_stop > 0: a step-bounded sample of
+    the chain, 1000 - t_stop steps, extrapolated -- every reverse step costs the same).  Returns the bench line (rank 0)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    import torch.distributed as dist
     import cindm_amd
     from cindm_amd import dist as cdist
     from cindm_amd.synthetic import synthetic_init_
@@ -220,17 +268,19 @@ def main_cfg5(args):
     B, nb = (args.batch or 64), 2
     total = B * world
     stream = torch.cuda.Stream(device=dev)
-    # --workload cfg5g: the same chain under the airfoil design objective (inference/inverse_design_2d.py:208-214): every
+    # cfg5g: the same chain under the airfoil design objective (inference/inverse_design_2d.py:208-214): every
     # reverse step also runs the ForceUnet surrogate forward + input gradient over 6 frames x B x nb images and shifts the
     # state by eta_t * gradient ("standard-alpha"), all inside the captured step
-    guided = args.workload == "cfg5g"
+    guided = wl == "cfg5g"
     design_kw = {}
+    force = None
     if guided:
         force = synthetic_init_(cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4), seed=7).to(dev)
         design_kw = dict(design_fn=cindm_amd.ForceObjective(force, B, nb, 6, p_min=-37.7, p_max=57.6), design_guidance="standard-alpha")
+    nsteps = TIMESTEPS - t_stop
 
-    def one_chain(i):
-        local = diffusion.sample(batch_size=B, num_boundaries=nb, seed=1234 + i, sample_offset=rank * B, **design_kw)
+    def one_chain(i, stop=t_stop):
+        local = diffusion.sample(batch_size=B, num_boundaries=nb, seed=1234 + i, sample_offset=rank * B, t_stop=stop, **design_kw)
         return cdist.all_gather_designs(local, total) if distributed else local
 
     def fence():
@@ -238,13 +288,14 @@ def main_cfg5(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    line = None
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):
-            out = one_chain(i)
+        for i in range(warmup):
+            out = one_chain(i, stop=max(t_stop, TIMESTEPS - 8) if t_stop else 0)     # (a bounded sample warms up on a few steps)
         fence()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = one_chain(args.warmup + i)
+        for i in range(steps):
+            out = one_chain(warmup + i)
         fence()
         elapsed = time.perf_counter() - t0
         if distributed:
@@ -258,7 +309,7 @@ def main_cfg5(args):
             x[:, :, 21:] = 0
             model.profile(x, 500)
             acc = {}
-            reps = 5
+            reps = 5 if not t_stop else 2
             for _ in range(reps):
                 for k, (n, ms, fl) in model.profile(x, 500).items():
                     a = acc.setdefault(k, [0, 0.0, 0.0])
@@ -267,8 +318,8 @@ def main_cfg5(args):
             tot_ms = sum(v[1] for v in acc.values())
             achieved = k3[2] / (k3[1] * 1e-3) / 1e12
             h3 = os.environ.get("CINDM_MFMA") != "f32"
-            step_s = elapsed / args.steps / TIMESTEPS
-            pmc_file = "r03_pmc_traffic_cfg5.json"
+            step_s = elapsed / steps / nsteps
+            pmc_file = PMC_PREFIX + "cfg5.json"
             pmc, pmc_note = pmc_step_traffic(pmc_file)
             if h3:
                 # the 3x3 convolutions evaluate every fp32 product as 3 fp16 MFMA products: price the pipe actually
@@ -284,14 +335,14 @@ def main_cfg5(args):
             roof.update({"traffic": pmc_traffic(pmc_file, "conv2d_ws_kernel<0, 0" if h3 else "conv2d_tile_kernel<0") if pmc else None,
                          "pmc_provenance": pmc_note,
                          "launches_per_forward": k3[0] // reps, "avg_launch_us": round(k3[1] / k3[0] * 1e3, 2),
-                         "timing": "HIP events around every launch on the launch stream (cindm_unet2d_profile), 5 forwards",
+                         "timing": f"HIP events around every launch on the launch stream (cindm_unet2d_profile), {reps} forwards",
                          "share_of_forward_time": round(k3[1] / tot_ms, 3),
                          "forward_ms_sum_of_kernels": round(tot_ms / reps, 3),
                          "per_kind_us": {k: round(v[1] / reps * 1e3, 1) for k, v in acc.items()}})
             if pmc and guided:
                 # a guided step = the diffusion U-Net's bytes + one design-gradient call of the surrogate (its own PMC passes:
                 # the trace of tools/bench_force.py, one fu_stem_bwd launch per gradient call)
-                sur, sur_note = pmc_surrogate_traffic("r03_pmc_traffic_force.json")
+                sur, sur_note = pmc_surrogate_traffic(PMC_PREFIX + "force.json")
                 roof["pmc_provenance"] += "; " + sur_note
                 roof["hbm_bytes_per_step_diffusion_unet"] = pmc
                 roof["hbm_bytes_per_surrogate_gradient_call"] = sur
@@ -300,30 +351,67 @@ def main_cfg5(args):
                 roof["hbm_bytes_per_step"] = pmc
                 roof["hbm_gbps_whole_step"] = round(pmc / step_s / 1e9, 1)
                 roof["frac_of_hbm_peak"] = round(pmc / step_s / 1e9 / PEAK_HBM_GBPS, 4)
-    if rank == 0:
-        value = total * args.steps / elapsed
-        flop_design = nb * FLOP_PER_IMAGE_2D * TIMESTEPS
-        line = {
-            "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
-            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"airfoil 2-D: Unet dim=64 mults (1,2) channels=21 on 64x64, {nb}-boundary composition, "
-                                   f"batch {B} designs/GPU ({B * nb} images per reverse step), {TIMESTEPS} DDPM steps (BASELINE configs[4])"
-                                   + (f"; force-guided (standard-alpha): ForceUnet dim=64 mults (1,2,4,8) forward + input gradient on "
-                                      f"{6 * B * nb} images per step inside the captured step" if guided else ""),
-                       "designs_per_step": total, "unet_evals_per_design": TIMESTEPS * nb,
-                       "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
-            "model_tflops": round(value * flop_design / 1e12, 2),
-            "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
-            "roofline": roof,
-        }
-        if guided:
-            line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r03_force_kernel_stats*.txt"
-        if not args.no_cpu_baseline and world == 1 and not guided:
-            line["cpu_baseline"] = cpu_baseline_2d(cpu_state_dict(model))
+        if rank == 0:
+            # designs per second of COMPLETE chains: a bounded sample of nsteps steps is a fraction nsteps / 1000 of a chain
+            value = total * steps / elapsed * (nsteps / TIMESTEPS)
+            flop_design = nb * FLOP_PER_IMAGE_2D * TIMESTEPS
+            line = {
+                "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
+                "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(elapsed / steps * 1e3 * (TIMESTEPS / nsteps), 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"airfoil 2-D: Unet dim=64 mults (1,2) channels=21 on 64x64, {nb}-boundary composition, "
+                                       f"batch {B} designs/GPU ({B * nb} images per reverse step), {TIMESTEPS} DDPM steps (BASELINE configs[4])"
+                                       + (f"; force-guided (standard-alpha): ForceUnet dim=64 mults (1,2,4,8) forward + input gradient on "
+                                          f"{6 * B * nb} images per step inside the captured step" if guided else ""),
+                           "designs_per_step": total, "unet_evals_per_design": TIMESTEPS * nb,
+                           "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
+                "us_per_reverse_step": round(elapsed / (steps * nsteps) * 1e6, 1),
+                "model_tflops": round(value * flop_design / 1e12, 2),
+                "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
+                "roofline": roof,
+            }
+            if t_stop:
+                line["config"]["sampled"] = (f"step-bounded sample: {steps} x the first {nsteps} reverse steps of the chain (t = 999 .. {t_stop}); "
+                                             f"value and ms_per_step are extrapolated x{TIMESTEPS / nsteps:g} (every reverse step is the same work)")
+            if guided:
+                line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r04_force_kernel_stats*.txt"
+            if not args.no_cpu_baseline and world == 1:
+                # cpu_baseline + rel_err: the oracle's reverse steps on a few designs, then the same steps, inputs and explicit noise
+                # through the HIP path.  Guided: 1 design (the surrogate's autograd on the CPU is ~4 s per design and step).
+                from cindm_amd.diffusion2d import NoiseTape2D        # noqa: F401  (the explicit-noise convention of p_sample)
+                gsd = cpu_state_dict(force) if guided else None
+                Bc = 1 if guided else 4
+                cb, (x0, tape, xc, Bc) = cpu_baseline_2d(cpu_state_dict(model), budget_s=cpu_budget_s, threads_hint=threads_hint,
+                                                         guided_sd=gsd, Bc=Bc)
+                line["cpu_baseline"] = cb
+                kw = {}
+                if guided:
+                    kw = dict(design_fn=cindm_amd.ForceObjective(force, Bc, nb, 6, p_min=-37.7, p_max=57.6), design_guidance="standard-alpha")
+                xg = x0.to(dev)
+                for t, nz in tape:
+                    xg, _ = diffusion.p_sample((Bc, nb, 21, 64, 64), xg, t, None, noise=nz.to(dev), **kw)
+                torch.cuda.synchronize(dev)
+                line["rel_err"] = float((xg.cpu() - xc).abs().max() / xc.abs().max())
+                line["rel_err_note"] = (f"max-abs / max-abs of the state after the cpu_baseline leg's {len(tape)} reverse steps of {Bc} designs x {nb} "
+                                        "boundaries (same weights, inputs and explicit noise on both sides, free-running); tolerance 1e-4")
+    return line
+
+
+def main_cfg5(args):
+    """bench.py --workload cfg5 | cfg5g as the headline."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    line = measure_2d(args, args.workload, args.steps, args.warmup, 20.0)
+    if line is not None:
         print(json.dumps(line), flush=True)
-    if distributed:
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 
@@ -376,10 +464,10 @@ def build_1d(workload, B, dev):
     return w
 
 
-def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0):
+def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0, threads_hint=None):
     """cpu_baseline + rel_err of a 1-D workload: the oracle's reverse steps (t = 500 downwards) on the host cores for
-    ~budget_s, the fastest thread count of a short sweep, extrapolated to the chain length; then the same steps on the
-    same inputs and explicit noise through the HIP path."""
+    ~budget_s -- the fastest thread count of a short sweep, best of three repetitions -- extrapolated to the chain length;
+    then the same steps on the same inputs and explicit noise through the HIP path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cindm_oracle as O
     d = w["diffusion"]
@@ -407,33 +495,29 @@ def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0):
         gpu_step = lambda x, t, nz: d.p_sample_compose_outside(x, None, t, noise=nz, **kw)[0]
     model, phys = cpu_info()
     default_threads = torch.get_num_threads()
-    sweep = {}
     with torch.no_grad():
         nz = torch.randn((B, L, F), generator=g)
-        for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)}):
-            torch.set_num_threads(nt)
-            cpu_step(x0, t_first, nz)
-            t0 = time.time()
-            cpu_step(x0, t_first, nz)
-            sweep[nt] = time.time() - t0
-        best = min(sweep, key=sweep.get)
+        best, sweep = thread_sweep(lambda: cpu_step(x0, t_first, nz), threads_hint)
         torch.set_num_threads(best)
-        x, noises, n, t0 = x0.clone(), [], 0, time.time()
-        while True:
+        state = {"x": x0.clone()}
+        noises = []
+
+        def once(k):
             nzk = torch.randn((B, L, F), generator=g)
             noises.append(nzk)
-            x = cpu_step(x, t_first - n, nzk)
-            n += 1
-            if time.time() - t0 > budget_s or n >= 100:
-                break
-        dt = (time.time() - t0) / n
+            state["x"] = cpu_step(state["x"], t_first - k, nzk)
+
+        dt, n, per = timed_cpu_steps(once, budget_s)
+        x = state["x"]
         torch.set_num_threads(default_threads)
     S = w["steps_per_design"]
     out = {"value": B / (dt * S), "unit": "samples/s", "cores": best, "kind": "port",
-           "sample": f"{n} reverse steps of batch {B} ({dt * 1e3:.1f} ms/step), extrapolated x{S}"
+           "sample": f"{n} reverse steps of batch {B} (best of 3 repetitions: {dt * 1e3:.1f} ms/step), extrapolated x{S}"
                      + (" (a DDIM step costs the same U-Net evaluation)" if workload == "cfg2-ddim250" else ""),
+           "ms_per_step_per_repetition": per,
            "cpu_model": model, "physical_cores": phys,
-           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())}}
+           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())} if sweep
+                                       else f"not swept: {best} threads, the count the headline workload's sweep chose on this host"}
     xg = x0.to(dev)
     for k, nzk in enumerate(noises):
         xg = gpu_step(xg, t_first - k, nzk.to(dev))
@@ -459,36 +543,17 @@ def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0):
     return out, rel, extra
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2 / cfg3, 128 for cfg4, 64 for cfg5)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg2-ddim250", "cfg5", "cfg5g"), default="cfg2",
-                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] (time composition, 3 windows -> "
-                         "56 steps); cfg4 = configs[3] (4-body composition, script path, 128 designs per GPU); cfg2-ddim250 = cfg2 with the "
-                         "scripts' default 250 DDIM steps; cfg5 = configs[4] (2-D airfoil); cfg5g = cfg5 under the ForceUnet design objective")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    spawn_ranks_if_needed(args)
-    if args.workload in ("cfg5", "cfg5g"):
-        return main_cfg5(args)
-    wl = args.workload
-    args.batch = args.batch or (128 if wl == "cfg4" else BATCH)
-
+def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
+    """One 1-D workload: warm-up chains, `steps` timed chains between barriers, the roofline leg, the CPU leg.  Returns the
+    bench line on rank 0 (None elsewhere)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
+    import torch.distributed as dist
     from cindm_amd import dist as cdist
-    B = args.batch
+    B = args.batch or (128 if wl == "cfg4" else BATCH)
     total = B * world
     w = build_1d(wl, B, dev)
     model, diffusion = w["pair"], w["diffusion"]
@@ -505,12 +570,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):
+        for i in range(warmup):
             out = one_chain(i)
         fence()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = one_chain(args.warmup + i)
+        for i in range(steps):
+            out = one_chain(warmup + i)
         fence()
         elapsed = time.perf_counter() - t0
         if distributed:
@@ -543,12 +608,13 @@ def main():
             kname = "conv_gemm_kernel<5,32,48,*> (fp32 MFMA)" if f32_path else \
                 "dconv2_kernel<L,K0,K1,RES,KB> / dconv_kernel (the deep-level k=5 convolutions of a forward, two per launch where a whole " \
                 "ResidualTemporalBlock fits; fp32 products as 3 fp16 MFMAs, fp32 accumulate)"
-            step_s = elapsed / (args.steps * S)
-            pmc_file = f"r03_pmc_traffic_{wl}.json"
+            step_s = elapsed / (steps * S)
+            pmc_file = PMC_PREFIX + f"{wl}.json"
             pmc, pmc_note = pmc_step_traffic(pmc_file)
             roof = {"bound": "latency",
-                    "bound_note": f"neither roofline binds: the reverse step is a chain of {step_launches} dependent launches; per launch ~2 us "
-                                  "dispatch gap + ~2 us prologue + ~3 us epilogue around ~3 us of weight streaming / MFMA work",
+                    "bound_note": f"neither roofline binds: the reverse step is a chain of {step_launches} dependent launches; the per-launch phase "
+                                  "clocks (profiles/r04_phase_table_*.txt) split each into dispatch, first loads, weight streaming / MFMA, "
+                                  "reductions, exchanges between workgroups and the store drain",
                     "kernel": kname,
                     # priced against the pipe that EXECUTES: every fp32 product is 3 fp16 MFMAs (f32 path: the fp32 MFMA itself)
                     "achieved": round(achieved if f32_path else 3 * achieved, 2),
@@ -569,31 +635,110 @@ def main():
                 roof["frac_of_hbm_peak"] = round(pmc / step_s / 1e9 / PEAK_HBM_GBPS, 4)
             roof["pmc_provenance"] = pmc_note
 
-    if rank == 0:
-        chains = args.steps
-        value = total * chains / elapsed
-        flop_design = S * (w["evals"][0] * FLOP_PER_EVAL + w["evals"][1] * FLOP_PER_EVAL_F4)
-        line = {
-            "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
-            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / chains * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w["text"], "designs_per_step": total, "unet_evals_per_design": S * sum(w["evals"]),
-                       "reverse_steps_per_design": S,
-                       "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
-            "us_per_reverse_step": round(elapsed / (chains * S) * 1e6, 1),
-            "sample_steps_per_s": round(value * S, 1),
-            "model_tflops": round(value * flop_design / 1e12, 2),
-            "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], line["rel_err"], extra = cpu_baseline_1d(wl, w, B, dev)
-            line.update(extra)
-            line["rel_err_note"] = "max-abs / max-abs of the state after the cpu_baseline leg's reverse steps (same weights, inputs and explicit " \
-                                   "noise on both sides, free-running); tolerance 1e-4"
+        line = None
+        if rank == 0:
+            chains = steps
+            value = total * chains / elapsed
+            flop_design = S * (w["evals"][0] * FLOP_PER_EVAL + w["evals"][1] * FLOP_PER_EVAL_F4)
+            line = {
+                "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
+                "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(elapsed / chains * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": w["text"], "designs_per_step": total, "unet_evals_per_design": S * sum(w["evals"]),
+                           "reverse_steps_per_design": S,
+                           "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
+                "us_per_reverse_step": round(elapsed / (chains * S) * 1e6, 1),
+                "sample_steps_per_s": round(value * S, 1),
+                "model_tflops": round(value * flop_design / 1e12, 2),
+                "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
+                "exchange_timeouts_recovered": int(model.recovered) + (int(w["single"].recovered) if w["single"] is not None else 0),
+                "roofline": roof,
+            }
+            if not args.no_cpu_baseline and world == 1:
+                line["cpu_baseline"], line["rel_err"], extra = cpu_baseline_1d(wl, w, B, dev, budget_s=cpu_budget_s, threads_hint=threads_hint)
+                line.update(extra)
+                line["rel_err_note"] = "max-abs / max-abs of the state after the cpu_baseline leg's reverse steps (same weights, inputs and explicit " \
+                                       "noise on both sides, free-running); tolerance 1e-4"
+    return line
+
+
+def compact(line):
+    """The record of a workload nested under the headline line's "workloads"."""
+    r = line.get("roofline") or {}
+    cb = line.get("cpu_baseline") or {}
+    out = {"value": line["value"], "unit": line["unit"], "chains_timed": line["steps"], "designs_per_chain": line["config"]["designs_per_step"],
+           "us_per_reverse_step": line.get("us_per_reverse_step"), "ms_per_chain": line["ms_per_step"],
+           "rel_err": line.get("rel_err"),
+           "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_forward", "traffic")},
+           "hbm_bytes_per_step": r.get("hbm_bytes_per_step"), "frac_of_hbm_peak": r.get("frac_of_hbm_peak"),
+           "pmc_provenance": r.get("pmc_provenance"),
+           "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
+           "workload": line["config"]["workload"]}
+    for k in ("rel_err_ddim_teacher_forced", "launches_per_reverse_step", "exchange_timeouts_recovered"):
+        if k in line:
+            out[k] = line[k]
+        elif k in r:
+            out[k] = r[k]
+    if "sampled" in line["config"]:
+        out["sampled"] = line["config"]["sampled"]
+    return out
+
+
+# what the default run measures after the headline: (workload, timed chains, warm-up chains, CPU-leg budget in seconds, t_stop)
+EXTRA_WORKLOADS = (("cfg3", 2, 1, 4.0, 0), ("cfg4", 3, 1, 4.0, 0), ("cfg2-ddim250", 3, 1, 3.0, 0), ("cfg5", 1, 1, 4.0, 0),
+                   ("cfg5g", 1, 1, 8.0, 980))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2 / cfg3, 128 for cfg4, 64 for cfg5)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg2-ddim250", "cfg5", "cfg5g"), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] (time composition, 3 windows -> "
+                         "56 steps); cfg4 = configs[3] (4-body composition, script path, 128 designs per GPU); cfg2-ddim250 = cfg2 with the "
+                         "scripts' default 250 DDIM steps; cfg5 = configs[4] (2-D airfoil); cfg5g = cfg5 under the ForceUnet design objective")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="the default run (cfg2, one GPU) also times cfg3, cfg4, cfg2-ddim250, cfg5 and a step-bounded cfg5g after the headline "
+                         "and nests them under \"workloads\"; this skips them")
+    args = ap.parse_args()
+    spawn_ranks_if_needed(args)
+    if args.workload in ("cfg5", "cfg5g"):
+        return main_cfg5(args)
+    wl = args.workload
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    line = measure_1d(args, wl, args.steps, args.warmup, 20.0)
+    if line is not None and wl == "cfg2" and world == 1 and not args.no_extra_workloads and not args.batch:
+        # every other BASELINE configuration, driver-timed in the same run; each builds its own models and frees them
+        hint = (line.get("cpu_baseline") or {}).get("cores")
+        extra = {}
+        t_extra = time.time()
+        for name, st, wu, budget, t_stop in EXTRA_WORKLOADS:
+            try:
+                sub = measure_2d(args, name, st, wu, budget, threads_hint=hint, t_stop=t_stop) if name.startswith("cfg5") else \
+                    measure_1d(args, name, st, wu, budget, threads_hint=hint)
+                extra[name] = compact(sub)
+            except Exception as e:      # a failing extra workload must not take the headline down: it is reported, not hidden
+                extra[name] = {"error": f"{type(e).__name__}: {e}"}
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        line["workloads"] = extra
+        line["workloads_seconds"] = round(time.time() - t_extra, 1)
+    if line is not None:
         print(json.dumps(line), flush=True)
-    if distributed:
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -10,6 +10,7 @@ import os
 from . import build as _build
 
 _lib = None
+ABI_VERSION = 2          # == CINDM_ABI_VERSION of include/cindm_hip.h (tests/test_host_logic.py keeps the two in step)
 
 
 class CindmError(RuntimeError):
@@ -66,6 +67,11 @@ SIGNATURES = {
     "cindm_last_error": (C.c_char_p, []),
     "cindm_source_hash": (C.c_char_p, []),
     "cindm_unet1d_status": (C.c_int, [_vp, _vp]),
+    "cindm_unet1d_poll": (C.c_int, [_vp, _vp]),
+    "cindm_unet1d_recovered": (C.c_int, [_vp]),
+    "cindm_unet1d_phase_prof_enable": (C.c_int, [_vp, _i32]),
+    "cindm_unet1d_phase_prof_read": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "cindm_unet1d_phase_prof_name": (C.c_char_p, [_vp, _i32]),
     "cindm_unet1d_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "cindm_unet1d_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "cindm_unet2d_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
@@ -119,6 +125,7 @@ SIGNATURES = {
                                     _vp, _sz, _vp]),
     "cindm_ddpm2d_sample": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _u64, _i64, _i32, _i32, _vp, _sz, _vp,
                                       _i32]),
+    "cindm_ddpm2d_predict": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cindm_fill_noise2d": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _u64, _i64, _i32, _vp]),
     "cindm_forceunet_create": (C.c_int, [C.POINTER(ForceUnetDesc), C.POINTER(_vp)]),
     "cindm_forceunet_destroy": (None, [_vp]),
@@ -169,8 +176,8 @@ def lib():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if L.cindm_abi_version() != 1:
-        raise CindmError("libcindm_hip.so ABI version mismatch")
+    if L.cindm_abi_version() != ABI_VERSION:
+        raise CindmError(f"libcindm_hip.so ABI version {L.cindm_abi_version()}, this binding is written for {ABI_VERSION}")
     have, want = L.cindm_source_hash().decode(), _build.source_hash()
     if have != want:
         raise CindmError(f"libcindm_hip.so was built from other sources (library {have[:12]}, tree {want[:12]}); "

@@ -9,7 +9,13 @@ SRC = os.path.join(HERE, "csrc", "cindm_hip.hip")
 CSRC = os.path.join(HERE, "csrc")
 DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))] + \
        [os.path.join(os.path.dirname(HERE), "include", "cindm_hip.h")]
-LIB = os.path.join(HERE, "libcindm_hip.so")
+# CINDM_LIB_VARIANT=prof selects the PROFILING build of the same sources (-DCINDM_PHASE_PROF: in-kernel phase clocks,
+# csrc/kernels.h PhaseBuf) -> libcindm_hip_prof.so; tools/phase_table.py runs on it.  The production library has no trace of it.
+VARIANT = os.environ.get("CINDM_LIB_VARIANT", "")
+if VARIANT not in ("", "prof"):
+    raise RuntimeError(f"unknown CINDM_LIB_VARIANT {VARIANT!r} (only 'prof')")
+EXTRA_FLAGS = ["-DCINDM_PHASE_PROF"] if VARIANT == "prof" else []
+LIB = os.path.join(HERE, "libcindm_hip_prof.so" if VARIANT == "prof" else "libcindm_hip.so")
 
 
 HASH_FILE = LIB + ".srchash"
@@ -85,8 +91,8 @@ def build(force=False, verbose=False):
     # as distinct ops) and the step identities between compose modes stay bitwise; MFMA builtins are unaffected
     tmp = f"{LIB}.tmp{os.getpid()}"          # per-process name + atomic replace: concurrent builders cannot corrupt the library
     sh = source_hash()
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f'-DCINDM_SRC_HASH="{sh}"',
-           "-shared", "-fPIC", "-o", tmp, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f'-DCINDM_SRC_HASH="{sh}"'] + EXTRA_FLAGS + \
+          ["-shared", "-fPIC", "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:
@@ -102,4 +108,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--prof" in sys.argv and VARIANT != "prof":
+        # the variant is fixed at import: re-run this module with it selected
+        sys.exit(subprocess.run([sys.executable, "-m", "cindm_amd.build"] + [a for a in sys.argv[1:] if a != "--prof"],
+                                env=dict(os.environ, CINDM_LIB_VARIANT="prof"), cwd=os.path.dirname(HERE)).returncode)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -94,6 +94,16 @@ struct cindm_unet1d {
     int generation = 0;                    // bumped by every (re)pack: captured graphs that embed this handle's pointers check it
     bool force_f32 = false;                // calibration forward overflowed on the split-fp16 kernels: fp32 MFMA kernels in use
     bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
+    // Exchange-free mode (run-time option "no_exchange", or forced for the re-run of a chain whose exchange timed out): the
+    // kernels that hand data between WORKGROUPS inside a launch (dconv / dconv2 at C = 512 and the y0 all-gather, attn1d_head)
+    // are not emitted; their per-layer / one-workgroup counterparts run instead.  Nothing in that mode can time out.
+    int no_xchg_force = 0;
+    int recovered = 0;                     // chains / forwards re-run in exchange-free mode after a time-out (cindm_unet1d_recovered)
+    bool NX() const { return no_xchg_force || O("no_exchange"); }
+    int plan_nx = -1;                      // the mode h->launches / pf_table were planned for
+    // phase clocks (profiling builds): [slot][PH_MAXWG][PH_MAXWAVE][PH_NST] uint64, armed by cindm_unet1d_phase_prof_enable
+    unsigned long long* ph_buf = nullptr; int ph_on = 0;
+    std::vector<std::string> ph_names;     // kernel of each launch slot of the last emitted forward
     // kernel-path options (cindm_unet1d_set_option; defaults = the fast path, overridable by CINDM_* at create)
     std::map<std::string, int> opt;
     int O(const char* k) const { auto it = opt.find(k); return it == opt.end() ? 0 : it->second; }
@@ -189,6 +199,7 @@ static const OptDef kUnet1dOpts[] = {
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
     {"fuse_update", 1, "CINDM_FUSE_UPDATE"},   // plain single-model steps: the reverse-step update inside ups_last_kernel (no update launch)
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
+    {"no_exchange", 0, "CINDM_NO_EXCHANGE"},   // 1: only kernels without an in-launch exchange between workgroups (run-time option: does not un-finalize)
     {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
@@ -208,7 +219,11 @@ extern "C" int cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t
     REQUIRE(h && key, "null argument");
     auto it = h->opt.find(key);
     if (it == h->opt.end()) return fail(std::string("unknown option: ") + key);
-    if (it->second != value) { it->second = value; h->finalized = false; }
+    if (it->second != value) {
+        it->second = value;
+        // "no_exchange" only selects among kernels whose operands are all packed already: the handle stays finalized
+        if (std::strcmp(key, "no_exchange") != 0) h->finalized = false;
+    }
     return 0;
 }
 
@@ -249,6 +264,7 @@ extern "C" void cindm_unet1d_destroy(cindm_unet1d* h) {
     if (h->blob) (void)hipFree(h->blob);
     if (h->ttable) (void)hipFree(h->ttable);
     if (h->epoch_dev) (void)hipFree(h->epoch_dev);
+    if (h->ph_buf) (void)hipFree(h->ph_buf);
     delete h;
 }
 
@@ -651,6 +667,16 @@ struct Emitter {
         }
         pf_step(pf, r);
     }
+    // phase clocks (profiling builds): the record slot of the launch being emitted
+    int ph_slot = 0;
+    PhaseBuf ph_next(const std::string& name) {
+        PhaseBuf b{nullptr, 0};
+        if (dry || !h || !h->ph_on || !h->ph_buf || ph_slot >= 32) return b;
+        b.buf = h->ph_buf; b.slot = ph_slot++;
+        if ((int)h->ph_names.size() <= b.slot) h->ph_names.resize(b.slot + 1);
+        h->ph_names[b.slot] = name;
+        return b;
+    }
     bool epoch_bumped = false;                // dconv pair exchanges: the per-forward epoch has been advanced
     std::vector<std::pair<size_t, size_t>>* xregions = nullptr;      // dry run: (offset, bytes) of the exchange regions
 
@@ -868,7 +894,7 @@ static bool dconv_applicable(cindm_unet1d* h, const std::string& p, const Ten& x
     if (!h->O("dconv") || !h->use_h3 || !h->use_local_gn) return false;
     const int L = x0.L, gw = cout / 8;
     if ((L != 3 && L != 6) || cout % 32 || (gw != 16 && gw != 32 && gw != 64)) return false;
-    if (gw == 64 && (!h->O("dconv_pair") || (cout / 32) % 2)) return false;
+    if (gw == 64 && (!h->O("dconv_pair") || (cout / 32) % 2 || h->NX())) return false;
     if (x0.C % 128 || (x1 && (x1->C % 128 || x1->L != L))) return false;
     if (x0.ld != x0.C || (x1 && x1->ld != x1->C)) return false;      // (every tensor that reaches a block has an fp32 copy)
     auto w0 = h->packed.find(p + ".blocks.0.block.0"), w1 = h->packed.find(p + ".blocks.1.block.0");
@@ -930,6 +956,8 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
         d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
         d.xchg_a = xa; d.xchg_b = xb; d.epoch = h->ep(); d.err_flag = h->epoch_dev + 1;
         d.stress = h->O("stress"); d.dbg = h->O("dbg") >= 30 ? h->O("dbg") - 30 : 0;
+        d.ph = E.ph_next("dconv2<" + std::to_string(L) + "," + std::to_string(k0) + "," + std::to_string(k1) + "," + (identity ? "false" : "true") + "," +
+                         std::to_string(kb) + "> " + p);
         const dim3 grid((unsigned)NT, (unsigned)tiles);
         const double cin = (double)x0.C + (x1 ? (double)x1->C : 0.0);
         E.prof_begin(4, 2.0 * Bp * L * cout * cin * (5.0 + (identity ? 0.0 : 1.0)) + 2.0 * Bp * L * cout * (double)cout * 5.0);
@@ -962,7 +990,7 @@ static Ten emit_rtb_dconv(Emitter& E, const std::string& p, const Ten& x0, const
     const Packed& w0 = h->packed.at(p + ".blocks.0.block.0");
     const Packed& w1 = h->packed.at(p + ".blocks.1.block.0");
     const bool identity = !h->packed.count(p + ".residual_conv");
-    if (h->O("dconv2") && dconv2_instantiated(L, x0.C / 128, x1 ? x1->C / 128 : 0, !identity, cout / 128) &&
+    if (h->O("dconv2") && !h->NX() && dconv2_instantiated(L, x0.C / 128, x1 ? x1->C / 128 : 0, !identity, cout / 128) &&
         w0.CinP / 128 == x0.C / 128 + (x1 ? x1->C / 128 : 0))
         return emit_rtb_dconv2(E, p, x0, x1, cout);
     Ten y0; y0.L = L; y0.C = cout; y0.ld = cout; E.planes(y0);
@@ -1110,7 +1138,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
     const Packed& wo = h->packed.at(p + ".fn.fn.to_out");
     GemmArgs a;
     auto site = h->packed.find(p + ".fn.fn.to_qkv#site");
-    if (site != h->packed.end() && site->second.h3 && h->O("attn_head") && (C == 512 || (C == 256 && (L <= 4 || h->O("attn_head") > 1))) && L <= 16 && x.ld == C) {
+    if (site != h->packed.end() && site->second.h3 && h->O("attn_head") && !h->NX() && (C == 512 || (C == 256 && (L <= 4 || h->O("attn_head") > 1))) && L <= 16 && x.ld == C) {
         // (at C = 256 with two samples per group the site kernel is faster: 10.6 vs 12.2 us, measured; attn_head = 2 forces this path)
         // heads split over workgroups (attn1d_head_kernel): grid (4 heads, sample groups)
         Ten out = E.ten(L, C);
@@ -1129,6 +1157,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             s.L = L; s.S = S; s.slot = slot; s.Bp = Bp;
             s.xchg = xg; s.epoch = h->ep(); s.err_flag = h->epoch_dev + 1;
             s.stress = h->O("stress");
+            s.ph = E.ph_next("attn1d_head<" + std::to_string(C) + "> " + p);
             const dim3 grid(4, (unsigned)groups);
             E.prof_begin(5, 2.0 * Bp * L * 1024.0 * C + (double)Bp * 4 * (2.0 * 32 * 32 * L * 2));
             for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
@@ -1270,6 +1299,7 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
             d.pf = pf;
             d.x = x.p; d.ld = x.ld; d.W = reinterpret_cast<const uint4*>(E.W(w)); d.bias = E.B(w); d.nch = w.CinP / 128;
             d.Bp = Bp; d.N = x.C; d.NT = NT; d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
+            d.ph = E.ph_next(std::string("dresample<") + (up ? "up" : "down") + "> " + p);
             const dim3 grid((unsigned)NT, (unsigned)tiles);
             E.prof_begin(up ? 3 : 2, 2.0 * Bp * Lout * x.C * (double)x.C * (up ? 2.0 : 3.0));
             if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }
@@ -1345,6 +1375,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wo = E.W(h->packed.at("downs.0.2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at("downs.0.2.fn.fn.to_out"));
                 l.Wd = E.W(h->packed.at("downs.0.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.0.3.conv"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
+                l.ph = E.ph_next("level0_down downs.0");
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
                     if (L > 16 && E.rows > 320 && (h->O("level_occ2") & 1)) KLAUNCH(E, (level0_down_kernel<2, 2>), dim3((unsigned)E.rows), dim3(256), 0, l);
@@ -1390,6 +1421,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wd = E.W(h->packed.at("downs.1.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.1.3.conv"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L; l.Bp = (int)E.rows;
                 l.dbg = h->O("dbg4");
+                l.ph = E.ph_next("level1_down downs.1");
                 const int S = lvl1 == 1 ? 1 : 2;
                 const dim3 grid((unsigned)((E.rows + S - 1) / S));
                 E.prof_begin(5, 0.0);
@@ -1455,6 +1487,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wu = E.W(h->packed.at(p + ".3.conv#lvl")); l.bu = E.B(h->packed.at(p + ".3.conv"));
                 l.Wf = E.W(h->packed.at("final_conv.1#lvl")); l.bf = E.B(h->packed.at("final_conv.1"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
+                l.ph = E.ph_next("ups_last " + p + " + final_conv");
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
                     KLAUNCH(E, ups_last_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
@@ -1494,6 +1527,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wo = E.W(h->packed.at(p + ".2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at(p + ".2.fn.fn.to_out"));
                 l.Wu = E.W(h->packed.at(p + ".3.conv#lvl")); l.bu = E.B(h->packed.at(p + ".3.conv"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L;
+                l.ph = E.ph_next("ups_tail128 " + p);
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
                     KLAUNCH(E, ups_tail128_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
@@ -1529,6 +1563,19 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
         E.launch(1, a);
     }
     return 0;
+}
+
+// count the launches of one forward and collect what each of them streams (L2 warm-up table), for the kernel paths the
+// handle's options select NOW (the exchange-free mode is a run-time switch: re-planned when it flips)
+static void unet1d_plan(cindm_unet1d* h) {
+    h->pf_table.clear();
+    std::vector<cindm_unet1d::WReg> regs;
+    Emitter D{h, nullptr, true, nullptr, 0, 1, nullptr, 0};
+    D.pf_out = &regs;
+    emit_forward(D, nullptr, nullptr);
+    h->launches = D.launches;
+    h->pf_table = regs;
+    h->plan_nx = h->NX() ? 1 : 0;
 }
 
 static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
@@ -1645,16 +1692,9 @@ static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
     if (E.err != hipSuccess) return fail(std::string("finalize launch: ") + hipGetErrorString(E.err));
     HIPCHK(hipStreamSynchronize(stream));
     (void)hipFree(sin_d); (void)hipFree(y1); (void)hipFree(temb);
-    // count launches of one forward; collect what each of them streams (L2 warm-up table)
-    h->pf_table.clear();
-    std::vector<cindm_unet1d::WReg> regs;
-    Emitter D{h, nullptr, true, nullptr, 0, 1, nullptr, 0};
-    D.pf_out = &regs;
-    emit_forward(D, nullptr, nullptr);
-    h->launches = D.launches;
-    h->pf_table = regs;
     h->generation = ++g_generation;
     h->finalized = true;
+    unet1d_plan(h);
     return 0;
 }
 
@@ -1705,11 +1745,22 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     return 0;
 }
 
-extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t rows) {
+// (the larger of the two kernel selections: a chain whose exchange timed out is re-run in exchange-free mode on the SAME
+// caller-provided workspace)
+extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h_, int64_t rows) {
+    cindm_unet1d* h = const_cast<cindm_unet1d*>(h_);
     if (!h || !h->finalized || rows <= 0) return 0;
-    Emitter D{const_cast<cindm_unet1d*>(h), nullptr, true, nullptr, 0, rows, nullptr, 0};
-    emit_forward(D, nullptr, nullptr);
-    return D.ws_off + 256;
+    size_t need = 0;
+    const int keep = h->no_xchg_force;
+    for (int nx = 0; nx < 2; ++nx) {
+        h->no_xchg_force = nx;
+        if (nx == 0 && h->O("no_exchange")) continue;
+        Emitter D{h, nullptr, true, nullptr, 0, rows, nullptr, 0};
+        emit_forward(D, nullptr, nullptr);
+        need = std::max(need, D.ws_off);
+    }
+    h->no_xchg_force = keep;
+    return need + 256;
 }
 
 extern "C" int cindm_unet1d_launches_per_forward(const cindm_unet1d* h) { return h ? h->launches : 0; }
@@ -1718,6 +1769,7 @@ extern "C" int cindm_unet1d_launches_per_forward(const cindm_unet1d* h) { return
 // time a (workspace, rows) pair is seen (caller-owned memory arrives uninitialised).  Must run outside stream capture;
 // the sample loops call it before they capture their step.
 static int unet1d_prepare_ws(cindm_unet1d* h, void* ws, int64_t rows, hipStream_t stream) {
+    if ((h->NX() ? 1 : 0) != h->plan_nx) { unet1d_plan(h); h->seen_ws = nullptr; }     // the exchange-free switch flipped: other launches, other regions
     if (h->seen_ws == ws && h->seen_rows == rows) return 0;
     std::vector<std::pair<size_t, size_t>> regions;
     Emitter D{h, nullptr, true, nullptr, 0, rows, nullptr, 0};
@@ -1749,6 +1801,55 @@ static int unet1d_check_flag(cindm_unet1d* h, hipStream_t stream) {
 extern "C" int cindm_unet1d_status(cindm_unet1d* h, void* stream) {
     REQUIRE(h, "null handle");
     return unet1d_check_flag(h, (hipStream_t)stream);
+}
+
+// 0 healthy, 1 timed out (flag cleared), < 0 error
+static int unet1d_poll_flag(cindm_unet1d* h, hipStream_t stream) {
+    if (!h || !h->epoch_dev) return 0;
+    int v[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(v, h->epoch_dev, sizeof(v), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (!v[1]) return 0;
+    HIPCHK(hipMemsetAsync(h->epoch_dev + 1, 0, sizeof(int), stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 1;
+}
+
+extern "C" int cindm_unet1d_poll(cindm_unet1d* h, void* stream) {
+    REQUIRE(h, "null handle");
+    return unet1d_poll_flag(h, (hipStream_t)stream);
+}
+
+extern "C" int cindm_unet1d_recovered(const cindm_unet1d* h) { return h ? h->recovered : 0; }
+
+// ---- phase clocks (profiling builds) -----------------------------------------------------------------------------------
+static constexpr size_t kPhSlots = 32;
+static constexpr size_t kPhWordsPerSlot = (size_t)PH_MAXWG * PH_MAXWAVE * PH_NST;
+extern "C" int cindm_unet1d_phase_prof_enable(cindm_unet1d* h, int32_t on) {
+    REQUIRE(h, "null handle");
+#ifndef CINDM_PHASE_PROF
+    (void)on;
+    return fail("not a profiling build: the phase clocks exist only in libcindm_hip_prof.so (python -m cindm_amd.build --prof)");
+#else
+    if (on && !h->ph_buf) HIPCHK(hipMalloc((void**)&h->ph_buf, kPhSlots * kPhWordsPerSlot * sizeof(unsigned long long)));
+    if (on) HIPCHK(hipMemset(h->ph_buf, 0, kPhSlots * kPhWordsPerSlot * sizeof(unsigned long long)));
+    h->ph_on = on ? 1 : 0;
+    h->ph_names.clear();
+    h->generation = ++g_generation;          // captured steps embed the record pointers: never replay an older capture
+    return 0;
+#endif
+}
+extern "C" int cindm_unet1d_phase_prof_read(cindm_unet1d* h, unsigned long long* dst, int64_t dst_cap, void* stream) {
+    REQUIRE(h && dst, "null argument");
+    REQUIRE(h->ph_buf, "phase clocks are not enabled");
+    const size_t n = h->ph_names.size() * kPhWordsPerSlot;
+    REQUIRE((int64_t)n <= dst_cap, "phase clocks: destination too small");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpy(dst, h->ph_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return (int)h->ph_names.size();
+}
+extern "C" const char* cindm_unet1d_phase_prof_name(const cindm_unet1d* h, int32_t slot) {
+    return (h && slot >= 0 && slot < (int)h->ph_names.size()) ? h->ph_names[slot].c_str() : "";
 }
 
 extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, const int32_t* t_dev,
@@ -1847,6 +1948,7 @@ struct cindm_ddpm1d {
     // descriptor, tensor / workspace pointers, batch): a loop with the same key replays it without a new capture
     std::vector<unsigned char> gkey; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     int last_step_launches = 0, last_step_fused = 0;     // what the last emitted reverse step consisted of (cindm_ddpm1d_last_step_info)
+    float* xT = nullptr; size_t xT_cap = 0;              // the chain's initial state, kept for the exchange-free re-run after a time-out
     hipGraph_t graph1 = nullptr; hipGraphExec_t gexec1 = nullptr;      // ping-pong loops: the one-step graph that ends an odd count
     void drop_graph() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -1889,6 +1991,7 @@ extern "C" void cindm_ddpm1d_destroy(cindm_ddpm1d* h) {
     h->drop_graph();
     if (h->own) (void)hipStreamDestroy(h->own);
     if (h->ddim_buf) (void)hipFree(h->ddim_buf);
+    if (h->xT) (void)hipFree(h->xT);
     delete h;
 }
 
@@ -2150,15 +2253,17 @@ template <typename StepFn>
 static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, hipStream_t stream, int nsteps, int use_graph, StepFn step,
                         cindm_unet1d* pair, cindm_unet1d* uncond, bool pingpong = false) {
     // a chain is only handed back after the exchange flags of its U-Nets have been read: a timed-out partner (not
-    // co-resident under foreign load) would otherwise return designs computed from garbage statistics
+    // co-resident under foreign load) would otherwise return designs computed from garbage statistics.  Returns 1 for a
+    // time-out (run_chain_with_recovery re-runs the chain on the exchange-free kernels), -1 for an error.
     auto finish = [&]() -> int {
         if (pingpong) {          // the slot an eager forward reads may hold an older epoch than the loop's last step used: bump next time
             pair->epoch_prebumped = false;
             if (uncond) uncond->epoch_prebumped = false;
         }
-        if (unet1d_check_flag(pair, stream) != 0) return -1;
-        if (uncond && unet1d_check_flag(uncond, stream) != 0) return -1;
-        return 0;
+        const int r0 = unet1d_poll_flag(pair, stream);
+        const int r1 = uncond ? unet1d_poll_flag(uncond, stream) : 0;
+        if (r0 < 0 || r1 < 0) return -1;
+        return (r0 == 1 || r1 == 1) ? 1 : 0;
     };
     if (!use_graph) {
         for (int i = 0; i < nsteps; ++i) if (step(i & 1) != 0) return -1;
@@ -2200,9 +2305,42 @@ static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, 
     return finish();
 }
 
+// A chain (one sample-loop call) with its recovery: `body` runs the loop and returns replay_steps' code.  When an in-kernel
+// exchange between workgroups timed out (1) -- foreign load on the device kept a partner workgroup from becoming resident
+// within the spin bound; the chain's state is garbage from that step on -- the state is restored to the chain's x_T and the
+// chain is re-run ONCE with both U-Nets in exchange-free mode (per-layer kernels, nothing to time out); the handles go back
+// to the fast kernels afterwards.  The counter-based noise is a function of (seed, sample, step), tapes are read-only: the
+// re-run draws what the first run drew.
+template <typename Body>
+static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, float* x, size_t n_floats,
+                                   hipStream_t stream, Body body) {
+    const bool guard = !pair->NX();           // (already exchange-free: nothing can time out, nothing to keep)
+    if (guard) {
+        if (h->xT_cap < n_floats) {
+            if (h->xT) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(h->xT); h->xT = nullptr; h->xT_cap = 0; }
+            HIPCHK(hipMalloc((void**)&h->xT, n_floats * sizeof(float)));
+            h->xT_cap = n_floats;
+        }
+        HIPCHK(hipMemcpyAsync(h->xT, x, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    int rc = body();
+    if (rc != 1) return rc;
+    if (!guard) return fail("an in-kernel exchange timed out in exchange-free mode (internal error)");
+    HIPCHK(hipMemcpyAsync(x, h->xT, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    pair->no_xchg_force = 1; ++pair->recovered;
+    if (uncond) { uncond->no_xchg_force = 1; ++uncond->recovered; }
+    h->drop_graph();
+    rc = body();
+    pair->no_xchg_force = 0;
+    if (uncond) uncond->no_xchg_force = 0;
+    h->drop_graph();
+    if (rc == 1) return fail("an in-kernel exchange timed out again during the exchange-free re-run (internal error)");
+    return rc;
+}
+
 static void key_common(KeyBuilder& K, int kind, const cindm_unet1d* pair, const cindm_unet1d* uncond, const cindm_compose_desc* c, const StepIO& io,
                        int64_t B, const void* ws, size_t ws_bytes) {
-    K(kind)(pair)(pair->generation)(uncond)(uncond ? uncond->generation : 0)(*c)(B)(ws)(ws_bytes);
+    K(kind)(pair)(pair->generation)(uncond)(uncond ? uncond->generation : 0)(*c)(B)(ws)(ws_bytes)(pair->NX())(uncond ? uncond->NX() : false);
     K(io.x)(io.cond)(io.x_out)(io.noise)(io.noise_t_stride)(io.add_noise)(io.inp_cond)(io.inp_steps)(io.inp_noise)(io.inp_noise_t_stride);
     K(io.ddim_tab)(io.ddim_tnext)(io.iso)(io.iso_steps)(io.recur_t_stride);
 }
@@ -2230,18 +2368,21 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1;
-    if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
     io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
-    start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
-    KeyBuilder K;
-    key_common(K, 0, pair, uncond, c, io, B, ws, ws_bytes);
     // the step state lives in two slots and the step's own update advances it (no step_counter_kernel launch)
     const bool pp = pair->O("pingpong") != 0;
-    K(pp);
     io.pingpong = pp ? 1 : 0;
-    return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph,
-                        [&](int q) { StepIO it = io; it.parity = q; return run_step(h, pair, uncond, c, it, 0, h->t_dev, B, ws, ws_bytes, stream); },
-                        pair, c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr, pp);
+    cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
+    return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
+        if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
+        start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
+        KeyBuilder K;
+        key_common(K, 0, pair, uncond, c, io, B, ws, ws_bytes);
+        K(pp);
+        return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph,
+                            [&](int q) { StepIO it = io; it.parity = q; return run_step(h, pair, uncond, c, it, 0, h->t_dev, B, ws, ws_bytes, stream); },
+                            pair, un, pp);
+    });
 }
 
 extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -2281,14 +2422,17 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
-    if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
     io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
-    start_loop(h, pair, uncond, c, (int)times[0], stream, seed, sample_offset);
-    KeyBuilder K;
-    key_common(K, 1, pair, uncond, c, io, B, ws, ws_bytes);
-    return replay_steps(h, K.k, stream, n_steps, use_graph,
-                        [&](int) { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); },
-                        pair, c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr);
+    cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
+    return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
+        if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
+        start_loop(h, pair, uncond, c, (int)times[0], stream, seed, sample_offset);
+        KeyBuilder K;
+        key_common(K, 1, pair, uncond, c, io, B, ws, ws_bytes);
+        return replay_steps(h, K.k, stream, n_steps, use_graph,
+                            [&](int) { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); },
+                            pair, un);
+    });
 }
 
 extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, const cindm_compose_desc* c,
@@ -2320,9 +2464,7 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dz = dz; io.iso = initial_state_overwrite; io.iso_steps = initial_state_overwrite ? overwrite_steps : 0;
     io.recur_t_stride = (int64_t)(R > 0 ? R : 1) * B * Ltot * F;
-    if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
     io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
-    start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
     // one reverse step (:1286-1370): R x [p_mean_variance, mean - grad, overwrite, relaxation]; the last iteration's
     // relaxation is never used by the reference, its pred + sigma z is the step's result
     auto step = [&](int) -> int {
@@ -2337,10 +2479,15 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
         }
         return 0;
     };
-    KeyBuilder K;
-    key_common(K, 2, pair, uncond, c, io, B, ws, ws_bytes);
-    K(*dz)(recur_noise_steps)(R);
-    return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph, step, pair, c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr);
+    cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
+    return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
+        if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
+        start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
+        KeyBuilder K;
+        key_common(K, 2, pair, uncond, c, io, B, ws, ws_bytes);
+        K(*dz)(recur_noise_steps)(R);
+        return replay_steps(h, K.k, stream, t_start - t_end + 1, use_graph, step, pair, un);
+    });
 }
 
 extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint64_t seed, int64_t sample_offset,

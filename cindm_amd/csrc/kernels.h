@@ -88,6 +88,33 @@ __device__ __forceinline__ void stress_delay(int stress, unsigned site) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
 }
 
+// In-kernel phase clocks -- profiling builds only (-DCINDM_PHASE_PROF: `python -m cindm_amd.build --prof` ->
+// libcindm_hip_prof.so; the production library contains none of this).  Every wave keeps up to PH_NST stamps of the
+// 100 MHz constant clock (s_memrealtime: the same time base on every CU, so records of different workgroups -- and of
+// consecutive launches -- line up) in registers and lane 0 writes them at the end of the kernel:
+// buf[((slot * PH_MAXWG + workgroup) * PH_MAXWAVE + wave) * PH_NST + i].  sched_barrier pins a mark between the phases it
+// separates; the cost of the instrumentation is the difference between the profiling and the production build of the same
+// launch (tools/phase_table.py reports both).
+constexpr int PH_MAXWG = 1024, PH_MAXWAVE = 8, PH_NST = 16;
+struct PhaseBuf { unsigned long long* buf; int slot; };
+#ifdef CINDM_PHASE_PROF
+#define PH_DECL unsigned long long ph_[cindm::PH_NST] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
+#define PH(i) do { __builtin_amdgcn_sched_barrier(0); ph_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PH_FLUSH(pb) do { \
+        if ((pb).buf && (threadIdx.x & 63) == 0) { \
+            const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+            if (wg_ < (unsigned)cindm::PH_MAXWG) { \
+                unsigned long long* o_ = (pb).buf + ((((size_t)(pb).slot * cindm::PH_MAXWG + wg_) * cindm::PH_MAXWAVE + (threadIdx.x >> 6)) * cindm::PH_NST); \
+                _Pragma("unroll") for (int i_ = 0; i_ < cindm::PH_NST; ++i_) o_[i_] = ph_[i_]; \
+            } \
+        } \
+    } while (0)
+#else
+#define PH_DECL do { } while (0)
+#define PH(i) do { } while (0)
+#define PH_FLUSH(pb) do { } while (0)
+#endif
+
 struct Pf { const char* base[2]; unsigned bytes[2]; unsigned stride[2]; int* sink; };
 struct PfRegs { unsigned v[2][2]; };
 __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
@@ -1491,7 +1518,7 @@ struct Level0Args {
     const float* Wd; const float* bd;      // Downsample1d (k = 3, stride 2, pad 1)
     const int* t_ptr; int t_imm;
     int L;
-    Pf pf;                                 // L2 warm-up for the next launch
+    Pf pf; PhaseBuf ph;                                 // L2 warm-up for the next launch
 };
 
 // one 16-channel x (NT*16)-position tile of a k-tap convolution: A = this wave's weight fragments [tap][k32][plane],
@@ -1589,6 +1616,8 @@ __device__ __forceinline__ void lvl_store(const f32x4 (&v)[NT], float* dst, int 
 // MINB = 2 (more rows than CUs: configs 3 / 4): registers capped at 256 so that two workgroups share a CU (52 KB of LDS each)
 template <int NT, int MINB = 1>
 __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args a) {
+    PH_DECL;
+    PH(0);        // phase clocks (profiling builds, kernels.h PhaseBuf): mark k follows the k-th workgroup barrier, the last one the final stores
     constexpr int C = 64, NP = NT * 16, ROWS = NP + 4;               // two halo positions on each side
     constexpr int XPB = 2 * 32 + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char X0[2][ROWS * XPB];          // input, F padded to 32 channels
@@ -1643,6 +1672,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     float4 w5a[5][2], w1[1][2], w10[10][2];
     lvl_wload<5>(Wc0, lane, w5a); lvl_wload<1>(Wr4, lane, w1);
     __syncthreads();
+    PH(1);
 
     // ---- block 0 : y = Mish(GN(conv(x))) + tb0 ; h1 = Mish(GN(conv(y))) + (Wr x + br) ----
     f32x4 v[NT], r1[NT];
@@ -1660,6 +1690,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     }
     lvl_to_planes<NT, PPB>(v, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
+    PH(2);
     lvl_conv<NT, 5, 2, PPB>(w10, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
     lvl_wload<10>(Wc2, lane, w10);
     lvl_gn_mish<NT>(v, pbc[1], pga[1], pbe[1], L, lane);
@@ -1669,6 +1700,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     if (a.h1) lvl_store<NT>(h1, a.h1 + (size_t)b * L * C, c0, L, lane);
     lvl_to_planes<NT, PPB>(h1, P[1][0], P[1][1], c0, 2, L, lane);
     __syncthreads();
+    PH(3);
     // ---- block 1 (identity residual) ----
     lvl_conv<NT, 5, 2, PPB>(w10, P[1][0], P[1][1], 1, 0, ROWS - 1, lane, v);
     lvl_wload<10>(Wc3, lane, w10);
@@ -1677,6 +1709,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     for (int nt = 0; nt < NT; ++nt) { v[nt][0] += tb1.x; v[nt][1] += tb1.y; v[nt][2] += tb1.z; v[nt][3] += tb1.w; }
     lvl_to_planes<NT, PPB>(v, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
+    PH(4);
     lvl_conv<NT, 5, 2, PPB>(w10, P[0][0], P[0][1], 1, 0, ROWS - 1, lane, v);
     // the attention's q | k | v fragments of this wave's head (tiles 2w, 2w+1 of q, k, v), requested two barriers ahead
     half8 wh[2][6], wl[2][6];
@@ -1700,6 +1733,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     for (int nt = 0; nt < NT; ++nt)
         *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl]) = make_float4(h2[nt][0], h2[nt][1], h2[nt][2], h2[nt][3]);
     __syncthreads();
+    PH(5);
     // ---- attention: y = LN(h2) g -> planes P[1] (rows position + 2) ; q, k, v ; core ; out projection + h2 ----
     {
         constexpr int RPP = 16;                                          // 16 lanes per row, 16 rows per pass
@@ -1725,6 +1759,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
         }
     }
     __syncthreads();
+    PH(6);
     f32x4 qa[2][NT], ka[NT][2], va[NT][2];
     {
         f32x4 qM[2][NT], qL[2][NT], kM[NT][2], kL[NT][2], vM[NT][2], vL[NT][2];
@@ -1782,6 +1817,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
             *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
         }
     __syncthreads();
+    PH(7);
     f32x4 h3[NT];
     {
         lvl_conv<NT, 1, 4, APB>(wo4, Ap[0], Ap[1], 1, 0, NP - 1, lane, h3);
@@ -1795,6 +1831,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     lvl_store<NT>(h3, a.skip + (size_t)b * L * C, c0, L, lane);
     lvl_to_planes<NT, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
+    PH(8);
     // ---- Downsample1d: out[n'] = sum_tap W[tap] h3[2 n' + tap - 1] + bd ----
     {
         f32x4 d[1];
@@ -1803,7 +1840,9 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
         d[0][0] += bd.x; d[0][1] += bd.y; d[0][2] += bd.z; d[0][3] += bd.w;
         lvl_store<1>(d, a.down + (size_t)b * (L / 2) * C, c0, L / 2, lane);
     }
+    PH(9);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1822,7 +1861,7 @@ struct Level1Args {
     const int* t_ptr; int t_imm;
     int L, Bp;
     int dbg;                               // timing ablation: return after phase dbg (wrong results)
-    Pf pf;                                 // L2 warm-up for the next launch
+    Pf pf; PhaseBuf ph;                                 // L2 warm-up for the next launch
 };
 
 // MT x NT tiles of a k-tap convolution.  The weight fragments stream through a register ring of RING taps that the
@@ -1913,6 +1952,8 @@ __device__ __forceinline__ void lvlm_gn_mish(f32x4& v, const float4 bias, const 
 
 template <int NT, int MINB = 1>
 __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args a) {
+    PH_DECL;
+    PH(0);        // phase clocks (profiling builds, kernels.h PhaseBuf): mark k follows the k-th workgroup barrier, the last one the final stores
     constexpr int C = 128, CI = 64, RS = 20, ROWS = NT * RS, NP = NT * 16;
     constexpr int XPB = 2 * CI + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
     constexpr int RBYTES = (2 * ROWS * XPB > 2 * NP * APB) ? 2 * ROWS * XPB : 2 * NP * APB;
@@ -1954,6 +1995,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(R)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    PH(1);
     {
         const int c4 = tid & 15;                                         // 16 float4 per row
 #pragma unroll
@@ -2016,6 +2058,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
         }
     };
     __syncthreads();
+    PH(2);
     if (a.dbg == 1) return;
 
     // ---- block 0 ----
@@ -2028,6 +2071,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     add4(r1, 14);
     to_planes(v, P[0][0], P[0][1]);
     __syncthreads();
+    PH(3);
     lvlm_conv<2, NT, 5, 4, PPB, 4>(ring, wbase(a.Wc[1], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
     lvlm_prefetch<2, 5, 4, 4>(ring, wbase(a.Wc[2], 5, 4), lane);
     gn_all(v, 1);
@@ -2038,6 +2082,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     if (a.h1) store(h1, a.h1, L);
     to_planes(h1, P[1][0], P[1][1]);
     __syncthreads();
+    PH(4);
     if (a.dbg == 2) return;
     // ---- block 1 ----
     lvlm_conv<2, NT, 5, 4, PPB, 4>(ring, wbase(a.Wc[2], 5, 4), P[1][0], P[1][1], RS, 1, 0, ROWS - 1, lane, v);
@@ -2046,6 +2091,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     add4(v, 13);
     to_planes(v, P[0][0], P[0][1]);
     __syncthreads();
+    PH(5);
     lvlm_conv<2, NT, 5, 4, PPB, 4>(ring, wbase(a.Wc[3], 5, 4), P[0][0], P[0][1], RS, 1, 0, ROWS - 1, lane, v);
     lvlm_prefetch<2, 1, 4, 4>(ring, wbase(a.Wo, 1, 4), lane);          // to_out fragments: in flight through the attention
     gn_all(v, 3);
@@ -2060,6 +2106,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
         for (int nt = 0; nt < NT; ++nt)
             *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl(mt)]) = make_float4(h2[mt][nt][0], h2[mt][nt][1], h2[mt][nt][2], h2[mt][nt][3]);
     __syncthreads();
+    PH(6);
     if (a.dbg == 3) return;
     // ---- attention: LayerNorm -> planes P[1] ----
     {
@@ -2085,6 +2132,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
         }
     }
     __syncthreads();
+    PH(7);
     if (a.dbg == 4) return;
     // ---- q, k, v of head w (tiles 2w, 2w+1 | 8+2w.. | 16+2w..), K = 128: ring over the four k32 steps ----
     f32x4 qa[2][NT], ka[NT][2], va[NT][2];
@@ -2147,6 +2195,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     f32x4 att[2][NT];
     attn_site_core<NT>(qa, ka, va, att, s_here, s_here * 16, 16, L, lq, lr);
     __syncthreads();                                          // every wave is done with H (the att planes alias it)
+    PH(8);
 #pragma unroll
     for (int et = 0; et < 2; ++et)
 #pragma unroll
@@ -2159,6 +2208,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
             *reinterpret_cast<half4v*>(Apl + off) = lo;
         }
     __syncthreads();
+    PH(9);
     if (a.dbg == 5) return;
     f32x4 h3[2][NT];
     lvlm_conv<2, NT, 1, 4, APB, 4>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 16, 1, 0, NP - 1, lane, h3);
@@ -2171,6 +2221,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     store(h3, a.skip, L);
     to_planes(h3, P[0][0], P[0][1]);
     __syncthreads();
+    PH(10);
     if (a.dbg == 6) return;
     // ---- Downsample1d (k = 3, stride 2, pad 1): rows nt*RS + 2*n' + tap + 1 ----
     {
@@ -2179,7 +2230,9 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
         add4(d, 16);
         store(d, a.down, L / 2);
     }
+    PH(11);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2266,11 +2319,13 @@ struct UpsLastArgs {
     const float* Wf; const float* bf;                    // final 1x1, one 16-channel tile (rows >= F are zero)
     const int* t_ptr; int t_imm;
     int L;
-    Pf pf;                                               // L2 warm-up for the next launch (the next step's first kernel)
+    Pf pf; PhaseBuf ph;                                               // L2 warm-up for the next launch (the next step's first kernel)
     int fuse_upd; ComposeArgs upd;                       // plain single-model step: x_{t-1} from this kernel's eps rows, in place
 };
 
 __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
+    PH_DECL;
+    PH(0);        // phase clocks (profiling builds, kernels.h PhaseBuf): mark k follows the k-th workgroup barrier, the last one the final stores
     constexpr int C = 64, CB = 128, CI = 256, NP1 = 16, NP2 = 32, ROWS1 = NP1 + 4, ROWS2 = NP2 + 4;
     constexpr int XPB = 2 * CI + 16, QPB = 2 * CB + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char XI[2][ROWS1 * XPB];
@@ -2321,6 +2376,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    PH(1);
     {
         const int p = tid >> 4, c4 = tid & 15;                           // 16 positions x 16 float4, four channel quarters
         if (p < L) {
@@ -2356,6 +2412,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    PH(2);
 
     // ---- block 0 (256 -> 128, residual_conv): the wave's two 16-channel tiles one after the other ----
     f32x4 vb[2][1], rb[2][1], h1b[2][1];
@@ -2378,6 +2435,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     }
     q_planes(vb, Q[0][0], Q[0][1]);
     __syncthreads();
+    PH(3);
     {
         f32x4 t[1][1];
         lvlm_conv<1, 1, 5, 4, QPB, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), Q[0][0], Q[0][1], 0, 1, 0, ROWS1 - 1, lane, t); vb[0][0] = t[0][0];
@@ -2393,6 +2451,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     }
     q_planes(h1b, Q[1][0], Q[1][1]);
     __syncthreads();
+    PH(4);
     // ---- block 1 (128 -> 64, residual_conv) ----
     f32x4 v1[1][1], r1[1][1], h2[1];
     lvlm_conv<1, 1, 5, 4, QPB, 8>(ring, wtile(a.Wc[2], w, 5, 4), Q[1][0], Q[1][1], 0, 1, 0, ROWS1 - 1, lane, v1);
@@ -2403,6 +2462,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     add4(r1[0][0], pv4(10));
     lvl_to_planes<1, PPB>(v1[0], P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
+    PH(5);
     lvlm_conv<1, 1, 5, 2, PPB, 8>(ring, wbase(a.Wc[3], 5, 2), P[0][0], P[0][1], 0, 1, 0, ROWS2 - 1, lane, v1);
     lvlm_prefetch<1, 1, 4, 8>(ring, wbase(a.Wo, 1, 4), lane);           // to_out fragments: in flight through the attention
     lvl_gn_mish<1>(v1[0], pv4(3), pv4(4), pv4(5), L, lane);
@@ -2410,6 +2470,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     if (a.h2) lvl_store<1>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
     *reinterpret_cast<float4*>(&H[lr * HP + cl]) = make_float4(h2[0][0], h2[0][1], h2[0][2], h2[0][3]);
     __syncthreads();
+    PH(6);
     // ---- attention site (C = 64, one 16-position tile) ----
     {
         const int lrow = tid >> 4, lcol = tid & 15;
@@ -2431,6 +2492,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         *reinterpret_cast<half4v*>(&P[1][1][(n + 2) * PPB + 8 * lcol]) = lo;
     }
     __syncthreads();
+    PH(7);
     f32x4 qa[2][1], ka[1][2], va[1][2];
     {
         const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
@@ -2483,6 +2545,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         *reinterpret_cast<half4v*>(Apl + off) = lo;
     }
     __syncthreads();
+    PH(8);
     f32x4 h3[1];
     lvlm_conv<1, 1, 1, 4, APB, 8>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 0, 1, 0, NP1 - 1, lane, v1);
     lvlm_prefetch<1, 4, 2, 8>(ring, wbase(a.Wu, 4, 2), lane);
@@ -2492,6 +2555,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     if (a.h3) lvl_store<1>(h3, a.h3 + (size_t)b * L * C, c0, L, lane);
     lvl_to_planes<1, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
+    PH(9);
     // ---- Upsample1d: ConvTranspose1d(k = 4, stride 2, pad 1), L -> 2L positions (two tiles) ----
     f32x4 u[1][2];
     lvlm_conv<1, 2, 4, 2, PPB, 8, 1>(ring, wbase(a.Wu, 4, 2), P[0][0], P[0][1], 0, 0, 0, ROWS2 - 1, lane, u);
@@ -2500,6 +2564,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     if (a.up) lvl_store<2>(u[0], a.up + (size_t)b * L2 * C, c0, L2, lane);
     lvl_to_planes<2, PPB>(u[0], P[1][0], P[1][1], c0, 2, L2, lane);
     __syncthreads();
+    PH(10);
     // ---- final Conv1dBlock(64 -> 64, k5) and Conv1d(64 -> F, 1) ----
     f32x4 y[1][2];
     lvlm_conv<1, 2, 5, 2, PPB, 8>(ring, wbase(a.Wc[4], 5, 2), P[1][0], P[1][1], 16, 1, 0, ROWS2 - 1, lane, y);
@@ -2509,6 +2574,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     lvl_gn_mish<2>(y[0], zero4, pv4(7), pv4(8), L2, lane);
     lvl_to_planes<2, PPB>(y[0], P[0][0], P[0][1], c0, 2, L2, lane);
     __syncthreads();
+    PH(11);
     if (w == 0) {
         // Plain single-model step (UpsLastArgs::upd): the lanes that hold the prediction of 4 state elements also apply the
         // reverse-step update to them, in place -- no compose_update_kernel launch.  The state values and the noise of those
@@ -2554,7 +2620,9 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         }
         if (a.fuse_upd && blockIdx.x == 0 && lane == 0) compose_advance(u, tu);
     }
+    PH(12);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2573,10 +2641,12 @@ struct UpsTailArgs {
     const float* Wu; const float* bu;
     const int* t_ptr; int t_imm;
     int L;
-    Pf pf;                                 // L2 warm-up for the next launch
+    Pf pf; PhaseBuf ph;                                 // L2 warm-up for the next launch
 };
 
 __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
+    PH_DECL;
+    PH(0);        // phase clocks (profiling builds, kernels.h PhaseBuf): mark k follows the k-th workgroup barrier, the last one the final stores
     constexpr int C = 128, CI = 256, NP = 16, ROWS = NP + 4;
     constexpr int XPB = 2 * CI + 16, PPB = 2 * C + 16, APB = 2 * 128 + 16, HP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char XI[2][ROWS * XPB];
@@ -2610,6 +2680,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    PH(1);
     {
         const int p = tid >> 4, c4 = tid & 15;
         if (p < L) {
@@ -2648,6 +2719,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
             if (lr < nvalid) *reinterpret_cast<float4*>(dst + ((size_t)b * nvalid + lr) * C + cl(mt)) = make_float4(v[mt][0], v[mt][1], v[mt][2], v[mt][3]);
     };
     __syncthreads();
+    PH(2);
 
     // ---- ResidualTemporalBlock(256 -> 128): the wave's two 16-channel tiles one after the other ----
     f32x4 v[2], r[2], h2[2];
@@ -2669,6 +2741,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     }
     planes(v, P[0][0], P[0][1], L);
     __syncthreads();
+    PH(3);
     {
         f32x4 t[1][1];
         lvlm_conv<1, 1, 5, 4, PPB, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), P[0][0], P[0][1], 0, 1, 0, ROWS - 1, lane, t); v[0] = t[0][0];
@@ -2684,6 +2757,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     }
     if (a.h2) store(h2, a.h2, L);
     __syncthreads();
+    PH(4);
     // ---- attention site (C = 128) ----
     {
         const int lrow = tid >> 5, lcol = tid & 31;                      // 32 lanes per row, 8 rows per pass
@@ -2708,6 +2782,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
         }
     }
     __syncthreads();
+    PH(5);
     f32x4 qa[2][1], ka[1][2], va[1][2];
     {
         const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
@@ -2756,6 +2831,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     f32x4 att[2][1];
     attn_site_core<1>(qa, ka, va, att, 1, NP, NP, L, lq, lr);
     __syncthreads();                                          // every wave is done with H (the att planes alias it)
+    PH(6);
 #pragma unroll
     for (int et = 0; et < 2; ++et) {
         half4v hi, lo;
@@ -2766,6 +2842,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
         *reinterpret_cast<half4v*>(Apl + off) = lo;
     }
     __syncthreads();
+    PH(7);
     f32x4 h3[2];
     {
         f32x4 t[1][1];
@@ -2779,6 +2856,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     if (a.h3) store(h3, a.h3, L);
     planes(h3, P[0][0], P[0][1], L);
     __syncthreads();
+    PH(8);
     // ---- Upsample1d: ConvTranspose1d(k = 4, stride 2, pad 1), L -> 2L <= 16 positions (one tile) ----
     {
         f32x4 u[2];
@@ -2789,7 +2867,9 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
         add4(u[0], pv4(9, 0)); add4(u[1], pv4(9, 1));
         store(u, a.up, L2);
     }
+    PH(9);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 // ---------------------------------------------------------------------------------------------

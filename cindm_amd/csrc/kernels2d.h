@@ -2081,6 +2081,10 @@ struct Update2dArgs {
     const float* noise_bound; int64_t nb_t_stride;      // [B*nb, HW, 3]
     uint64_t seed; int64_t sample_off;
     int* t_dec; unsigned* done;
+    // model_predictions (:727-754): eps_out = the (shared) prediction; predict = 1: with use_avg bit 1 the prediction stays
+    // un-shared AND x_start / mean are not shared either (that is p_mean_variance's job); rederive: eps_out =
+    // predict_noise_from_start(x, t, x_start) = (sqrt_recip x - x_start) / sqrt_recipm1 (:738-739)
+    float* eps_out; int predict, rederive;
 };
 // counter-based noise of the 2-D path: element index = pix * CP + c (float4-aligned groups); state channels keyed by
 // the design (shared over its boundary copies), boundary channels keyed by the image
@@ -2108,14 +2112,16 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
         // shared prediction of the state channels: mean (or sum) over the boundary copies
         // use_avg bit 1 = share_noise False (p_mean_variance :757-773): the prediction is NOT shared; the clamped x_start of the
         // state channels is (x0s), and then the posterior mean computed from it (ms)
-        const bool late = (a.use_avg & 2) != 0, avg = (a.use_avg & 1) != 0;
+        const bool nopred = (a.use_avg & 2) != 0, avg = (a.use_avg & 1) != 0;
+        const bool late = nopred && !a.predict;
         float es[4] = {0.f, 0.f, 0.f, 0.f}, x0s[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f};
         if (c0 < Cs) {
             const float inv = (float)a.nb;
             for (int k = 0; k < a.nb; ++k) {
                 const size_t o = (((size_t)(b * a.nb + k) * a.HW) + pix) * a.CP + c0;
                 const float4 e = *reinterpret_cast<const float4*>(a.eps + o);
-                if (!late) { es[0] += e.x; es[1] += e.y; es[2] += e.z; es[3] += e.w; continue; }
+                if (!nopred) { es[0] += e.x; es[1] += e.y; es[2] += e.z; es[3] += e.w; continue; }
+                if (!late) continue;
                 const float4 x4 = *reinterpret_cast<const float4*>(a.x + o);
                 const float ev[4] = {e.x, e.y, e.z, e.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
@@ -2125,7 +2131,7 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
                     x0s[j] += x0;
                 }
             }
-            if (!late && avg) { es[0] /= inv; es[1] /= inv; es[2] /= inv; es[3] /= inv; }
+            if (!nopred && avg) { es[0] /= inv; es[1] /= inv; es[2] /= inv; es[3] /= inv; }
             if (late) {
                 if (avg) { x0s[0] /= inv; x0s[1] /= inv; x0s[2] /= inv; x0s[3] /= inv; }
                 for (int k = 0; k < a.nb; ++k) {
@@ -2164,11 +2170,11 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
                     noise2d_bound4(a.seed, (a.sample_off + b) * a.nb + k, (uint32_t)t, (uint32_t)pix, G, g, zb);
                 }
             }
-            float r0[4], rm[4], rx[4];
+            float r0[4], rm[4], rx[4], re[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + j;
-                const float e = (c < Cs && !late) ? es[j] : ev[j];
+                const float e = (c < Cs && !nopred) ? es[j] : ev[j];
                 float x0 = __fsub_rn(__fmul_rn(ra, xv[j]), __fmul_rn(rb, e));
                 if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
                 float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[j]));
@@ -2177,7 +2183,9 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
                 const bool real = c < a.C;
                 r0[j] = real ? x0 : 0.f; rm[j] = real ? mean : 0.f;
                 rx[j] = real ? (noisy ? mean + sigma * z : mean) : 0.f;
+                re[j] = real ? (a.rederive ? __fsub_rn(__fmul_rn(ra, xv[j]), x0) / rb : e) : 0.f;
             }
+            if (a.eps_out) *reinterpret_cast<float4*>(a.eps_out + o) = make_float4(re[0], re[1], re[2], re[3]);
             if (a.x0_out) *reinterpret_cast<float4*>(a.x0_out + o) = make_float4(r0[0], r0[1], r0[2], r0[3]);
             if (a.mean_out) *reinterpret_cast<float4*>(a.mean_out + o) = make_float4(rm[0], rm[1], rm[2], rm[3]);
             if (a.x_out) *reinterpret_cast<float4*>(a.x_out + o) = make_float4(rx[0], rx[1], rx[2], rx[3]);

@@ -26,6 +26,14 @@
 
 namespace cindm {
 
+// Bound of the hand-over spins.  A chain whose flag is already up (an earlier launch timed out: everything computed since
+// is garbage and the chain will be re-run) only waits briefly: a chain of launches that all wait the full bound would
+// turn one lost partner into minutes.  (~1 us per spin iteration: 2^20 ~ 1 s.)
+__device__ __forceinline__ int spin_bound(const int* err_flag, bool forced_short, int full_log2 = 20) {
+    const int seen = err_flag ? __builtin_nontemporal_load(err_flag) : 0;
+    return (forced_short || seen) ? (1 << 8) : (1 << full_log2);
+}
+
 struct DSrc {
     const float* f32;        // fp32 [rows = sample * L + position, ld], or null
     const uint4* planes;     // tiled planes: hi plane [tile][C/32][4][48 rows][8 halfs]; lo plane at + pstride
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     if (a.gw == 64 && a.dbg != 5) {
         // the group's other 32 columns belong to the workgroup nt ^ 1 of the same m-tile: swap (mean, M2) halves
         stress_delay(a.stress, 1u);
+        const int spin_cap = spin_bound(a.err_flag, a.dbg == 9);
         const int sbase = ((mt * a.NT + nt) * 16) * 2, pbase = ((mt * a.NT + (nt ^ 1)) * 16) * 2;
 #pragma unroll
         for (int js = 0; js < NSAMP; ++js) {
@@ -348,9 +357,10 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
                 g1 = __hip_atomic_load(a.xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
                 if (__all(ok)) break;
-                if (++spins > (a.dbg == 9 ? (1 << 8) : (1 << 20))) { if (lane == 0) atomicExch(a.err_flag, 1); break; }     // never hang the GPU
+                if (++spins > spin_cap) { if (lane == 0) atomicExch(a.err_flag, 1); break; }     // never hang the GPU
                 __builtin_amdgcn_s_sleep(2);
             }
+            asm volatile("" ::: "memory");      // (granules carry their own tag: nothing is read behind them; kept for uniformity)
             const float mp = __builtin_bit_cast(float, (unsigned)g0), M2p = __builtin_bit_cast(float, (unsigned)g1);
             const float m = 0.5f * (mean[js] + mp);
             const float d0 = mean[js] - m, d1 = mp - m;
@@ -440,6 +450,7 @@ struct Dconv2Args {
     float* out_f32; int ldo; uint4* out_planes; size_t out_pstride;
     unsigned long long* xchg_a; unsigned long long* xchg_b; const int* epoch; int* err_flag;     // gw == 64 pair exchanges
     Pf pf; int stress; int dbg;
+    PhaseBuf ph;                                          // phase clocks (profiling builds; kernels.h)
 };
 
 template <int L, int KPW0, int KPW1, bool RES, int KPWB>
@@ -455,6 +466,8 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     __shared__ float Red[4][TM * LDR];
     __shared__ uint4 Tile[2 * 48 * 5];
 
+    PH_DECL;
+    PH(0);                                    // phase clocks, profiling builds (kernels.h): 0 = entry
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * S;
@@ -555,6 +568,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     // ---- epilogue operands of both phases ----------------------------------------------------------------------------
     const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
     const unsigned tag = (unsigned)*a.epoch;
+    const int spin_cap = spin_bound(a.err_flag, a.dbg == 9);
     const float bias_a = a.bias_a ? a.bias_a[gn] : 0.f, bias_b = a.bias_b ? a.bias_b[gn] : 0.f;
     const float gam_a = a.gamma_a[gn], bet_a = a.beta_a[gn], gam_b = a.gamma_b[gn], bet_b = a.beta_b[gn];
     const float tbv = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : 0.f;
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         for (int q = 0; q < 6; ++q) rs[q] = a.res[(size_t)grow[q] * a.ldres + gn];
     }
     __builtin_amdgcn_sched_barrier(0);
+    PH(1);                                    // 1 = every prologue load issued (phase A's tile, first weight taps, epilogue operands)
 
     if constexpr (H > 0) {
         const uint4 z = {0u, 0u, 0u, 0u};
@@ -652,6 +667,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         store_raw(g1.f32, g1.slot, KPW1 - 1, raw1[KPW1 - 1]);
         kstep(wbase, KPW1 - 1, 0, NO, RIDE_A);
     }
+    PH(2);                                    // 2 = phase A's K loop done (staging waits + MFMAs)
     // phase B's first stage of weights: in flight during phase A's epilogue and the hand-over
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
@@ -678,7 +694,9 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     const int gwt = a.gw < TN ? a.gw : TN;
     const float cnt = (float)(L * gwt);
     // GroupNorm + Mish of the reduced tile v (dconv_kernel's, incl. the pair exchange through `xchg` when gw == 64)
-    auto gn_mish = [&](const float (&v)[6], unsigned long long* xchg, float gam, float bet, float (&y)[6]) {
+    auto gn_mish = [&](const float (&v)[6], unsigned long long* xchg, float gam, float bet, float (&y)[6], auto phb) {
+        constexpr int PHB = decltype(phb)::value;      // phase marks PHB (own statistics done, published) and PHB + 1 (partner's in)
+        (void)PHB;
         float mean[NSAMP], rstd[NSAMP];
 #pragma unroll
         for (int js = 0; js < NSAMP; ++js) {
@@ -709,6 +727,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
                 }
             }
             stress_delay(a.stress, 2u);
+            PH(PHB);
 #pragma unroll
             for (int js = 0; js < NSAMP; ++js) {
                 const int s = (S == 16) ? rq + 8 * js : rq;
@@ -719,7 +738,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
                     q1 = __hip_atomic_load(xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool ok = (unsigned)(q0 >> 32) == tag && (unsigned)(q1 >> 32) == tag;
                     if (__all(ok)) break;
-                    if (++spins > (1 << 20)) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
+                    if (++spins > spin_cap) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 const float mp = __builtin_bit_cast(float, (unsigned)q0), M2p = __builtin_bit_cast(float, (unsigned)q1);
@@ -728,6 +747,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
                 mean[js] = m;
                 rstd[js] = (rstd[js] + M2p) + cnt * (d0 * d0 + d1 * d1);
             }
+            PH(PHB + 1);
         }
         const float cnt_all = a.gw == 64 ? 2.f * cnt : cnt;
 #pragma unroll
@@ -759,7 +779,8 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     float v[6], y[6];
     stress_delay(a.stress, 3u);
     reduce_to(accM, accL, bias_a, v);
-    gn_mish(v, a.xchg_a, gam_a, bet_a, y);
+    PH(3);                                    // 3 = cross-wave reduction of phase A (LDS round trip + barrier)
+    gn_mish(v, a.xchg_a, gam_a, bet_a, y, std::integral_constant<int, 4>{});      // 4, 5 = GroupNorm statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += tbv;
     planes_to_tile(y);
@@ -778,14 +799,17 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rsrc, off, 0, 16);     // aux 16 = sc1: write-through
         }
     }
+    PH(6);                                    // 6 = Mish, time bias, planes through LDS, write-through stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
     stress_delay(a.stress, 6u);
     __syncthreads();
     if (tid == 0 && !(a.dbg == 9 && (nt & 1)))
         __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PH(7);                                    // 7 = stores drained, flag raised
     // r = Wr x + br stays in registers (Red is free again: the barrier above)
     float r2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (RES) { reduce_to(accRM, accRL, bias2, r2); __syncthreads(); }
+    PH(8);                                    // 8 = the riding 1x1's reduction (RES)
 
     // ---- hand-over: this wave's k-steps of y0 (k-step ks = the 32 channels of producer nt = ks) -----------------------
     uint4 rawb[KPWB][3][2];
@@ -795,7 +819,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     {
         stress_delay(a.stress, 7u);
         int spins = 0;
-        const int spin_max = a.dbg == 9 ? (1 << 8) : (1 << 20);
+        const int spin_max = spin_cap;
         while (true) {
             bool ok = true;
 #pragma unroll
@@ -805,6 +829,12 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             if (++spins > spin_max) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        // Compiler-level ordering of the payload loads behind the flag loads (the hardware issues VMEM in program order and the
+        // loop's exit depends on the flag values, so no fence INSTRUCTION is needed -- an agent acquire costs ~1.7 us,
+        // MI355X_MICROARCH.md -- but nothing else would stop the compiler from hoisting the raw-buffer loads above the relaxed
+        // atomic loads of the spin).
+        asm volatile("" ::: "memory");
+        PH(9);                                // 9 = the flags of this wave's producers seen
         const size_t plane_bytes = a.y0_pstride * 16;
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.y0), 0, (unsigned)(2 * plane_bytes), 0x00020000);
 #pragma unroll
@@ -822,11 +852,13 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     for (int j = 0; j < KPWB - 1; ++j) { store_raw(false, slotb, j, rawb[j]); kstep(wbase_b, j, j + 1, YES, NO); }
     store_raw(false, slotb, KPWB - 1, rawb[KPWB - 1]);
     kstep(wbase_b, KPWB - 1, 0, NO, NO);
+    PH(10);                                   // 10 = phase B's K loop done (y0 fetch waits + MFMAs)
 
     // ---- phase B epilogue: out = Mish(GN(.)) + (x | r) -------------------------------------------------------------------
     stress_delay(a.stress, 8u);
     reduce_to(accM, accL, bias_b, v);
-    gn_mish(v, a.xchg_b, gam_b, bet_b, y);
+    PH(11);                                   // 11 = cross-wave reduction of phase B
+    gn_mish(v, a.xchg_b, gam_b, bet_b, y, std::integral_constant<int, 12>{});     // 12, 13 = statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += RES ? r2[q] : rs[q];
 #pragma unroll
@@ -844,7 +876,9 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             a.out_planes[pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within] = t4;
         }
     }
+    PH(14);                                   // 14 = Mish, residual, fp32 + planes stores issued
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 
@@ -865,6 +899,7 @@ struct DresArgs {
     float* out_f32; int ldo;
     uint4* out_planes; size_t out_pstride;
     Pf pf;
+    PhaseBuf ph;
 };
 
 template <bool UP, int KPW>
@@ -875,6 +910,8 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     __shared__ uint4 Img[2][KST * 4 * RIN];
     __shared__ float Red[4][ROUT * LDR];
     __shared__ uint4 Tile[2 * ROUT * 5];
+    PH_DECL;
+    PH(0);                                    // phase clocks (profiling builds): 0 entry, 1 loads issued, 2 K loop, 3 reduce, 4 stores issued
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * S, ns = min(S, a.Bp - b0);
@@ -911,6 +948,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
     __builtin_amdgcn_sched_barrier(0);
+    PH(1);
 
     f32x4 accM[NBLK][2], accL[NBLK][2];
 #pragma unroll
@@ -963,6 +1001,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
 #pragma unroll
     for (int j = 0; j < KPW - 1; ++j) kstep(j, j + 1, YES);
     kstep(KPW - 1, 0, NO);
+    PH(2);
 
     // cross-wave K reduction; thread (n, rq) ends with column n of rows rq + 8 q (row = position * 16 + sample)
 #pragma unroll
@@ -973,6 +1012,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
             for (int rg = 0; rg < 4; ++rg)
                 Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV;
     __syncthreads();
+    PH(3);
     uint32_t* tw = reinterpret_cast<uint32_t*>(Tile);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1004,7 +1044,9 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
             a.out_planes[pl * a.out_pstride + dst] = t4;
         }
     }
+    PH(4);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 
@@ -1030,6 +1072,7 @@ struct AttnHeadArgs {
     unsigned long long* xchg; const int* epoch; int* err_flag;
     Pf pf;
     int stress;                                  // > 0: pseudo-random pauses before the hand-overs (stress_delay)
+    PhaseBuf ph;
 };
 
 template <int C>
@@ -1042,6 +1085,9 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NP * YPB];
     __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NP * APB];
     __shared__ __attribute__((aligned(16))) float Part[4][24][64];             // per-wave q|k|v partial accumulators
+    PH_DECL;
+    PH(0);        // phase clocks (profiling builds): 0 entry, 1 weight loads issued, 2 LayerNorm -> planes, 3 q|k|v K share, 4 cross-wave sum,
+                  // 5 core, 6 tile published, 7 four heads gathered, 8 att planes in LDS, 9 projection + stores issued
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int hd = blockIdx.x, grp = blockIdx.y;
@@ -1050,6 +1096,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     const int nend = s_here * slot;
     const size_t row0 = (size_t)grp * a.S * L;
     const unsigned tag = (unsigned)*a.epoch;
+    const int spin_cap = spin_bound(a.err_flag, false, 18);
     const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
     int tile[6];
 #pragma unroll
@@ -1077,6 +1124,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
                 wo[t][k][pl] = Wo4[(((size_t)(hd * CT4 + w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane];
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
+    PH(1);
 
     // ---- LayerNorm of the group's positions -> split-fp16 planes (as attn1d_site_h3_kernel) ----
     {
@@ -1132,6 +1180,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
         }
     }
     __syncthreads();
+    PH(2);
 
     // ---- this wave's K share of q, k, v of head hd ----
     f32x4 qM[2], qL[2], kM[2], kL[2], vM[2], vL[2];
@@ -1163,6 +1212,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             vL[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, vh, vL[i], 0, 0, 0);
         }
     }
+    PH(3);
     // cross-wave sum in the fixed order (w0 + w1) + (w2 + w3): every wave ends with the complete tiles
     stress_delay(a.stress, 13u);
 #pragma unroll
@@ -1184,6 +1234,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             va[0][i][r] = (Part[0][16 + i * 4 + r][lane] + Part[1][16 + i * 4 + r][lane]) + (Part[2][16 + i * 4 + r][lane] + Part[3][16 + i * 4 + r][lane]);
         }
 
+    PH(4);
     // the epilogue's bias and residual rows, requested before the core and the exchange (requested in the epilogue, their L2
     // round trip was the tail of the launch)
     float4 eb[TPW], ex[TPW];
@@ -1200,6 +1251,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     // ---- core: wave w owns sample w of the group ----
     f32x4 att[2][1];
     attn_site_core_range<1>(qa, ka, va, att, w, min(w + 1, s_here), nend, slot, L, lq, lr);
+    PH(5);
     stress_delay(a.stress, 11u);
     // publish this wave's sample columns (positions [w * slot, (w + 1) * slot)) of the head's 32 x 16 tile, and keep a
     // copy for the own projection.  Granule (hd, e, n) of group grp: value att[e][n], tag = epoch.
@@ -1224,6 +1276,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             for (int i = 0; i < 4; ++i)
                 __hip_atomic_store(gx + hd * 512 + (et * 16 + lq * 4 + i) * 16 + lr, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PH(6);
     // gather all four heads' tiles (own head included: one code path) -> att planes [position][128 channels]
     stress_delay(a.stress, 12u);
     {
@@ -1237,9 +1290,10 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
                 ok = ok && (unsigned)(gq[j] >> 32) == tag;
             }
             if (__all(ok)) break;
-            if (++spins > (1 << 18)) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
+            if (++spins > spin_cap) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
             __builtin_amdgcn_s_sleep(2);
         }
+        PH(7);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j, h2 = idx >> 9, e = (idx >> 4) & 31, n = idx & 15;
@@ -1252,6 +1306,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
         }
     }
     __syncthreads();
+    PH(8);
 
     // ---- out rows [hd * C/4, (hd + 1) * C/4): z = Wo att + bo + x ----
 #pragma unroll
@@ -1280,7 +1335,9 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
         }
     }
+    PH(9);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 }  // namespace cindm

@@ -197,11 +197,33 @@ class GaussianDiffusion1D(nn.Module):
             return int(t.reshape(-1)[0])
         return int(t)
 
-    def _check_status(self, desc, device):
-        """The exchange flags of the U-Nets a step with ``desc`` runs (CindmError on a timed-out exchange); synchronises."""
-        self.model.check_status(device)
-        if desc.mode == _ffi.COMPOSE_MULTIBODY:
-            self.model_unconditioned.check_status(device)
+    def _models(self, desc):
+        return [self.model] + ([self.model_unconditioned] if desc.mode == _ffi.COMPOSE_MULTIBODY else [])
+
+    def _timed_out(self, desc, device):
+        """True when an in-kernel exchange of the U-Nets a step with ``desc`` runs timed out since the last poll (every
+        model's flag is read and cleared); synchronises.  Raises instead when the model opted out of the recovery."""
+        hit = False
+        for m in self._models(desc):
+            hit = m.poll_status(device) or hit
+        return hit
+
+    def _rerun_exchange_free(self, fn, desc, device):
+        """``fn()`` once more with the step's U-Nets on their exchange-free kernels (TemporalUnet1D.rerun_exchange_free for
+        a step that may run two models)."""
+        ms = self._models(desc)
+        for m in ms:
+            m.exchange_free(True)
+        try:
+            out = fn()
+            if self._timed_out(desc, device):
+                raise _ffi.CindmError(self.model.TIMEOUT_TEXT)
+        finally:
+            for m in ms:
+                m.exchange_free(False)
+        for m in ms:
+            m._py_recovered = getattr(m, "_py_recovered", 0) + 1
+        return out
 
     @torch.no_grad()
     def _predict(self, x, cond, t, desc, check=True):
@@ -215,12 +237,16 @@ class GaussianDiffusion1D(nn.Module):
         B = x.shape[0]
         h, un, ws = self._prepare(desc, B, x.device)
         mean, x0, eps = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            _ffi.check(_ffi.lib().cindm_ddpm1d_predict(h, self.model._h, un, C.byref(desc), _ffi.ptr(x), _ffi.ptr(cond_d),
-                                                       int(t), None, B, _ffi.ptr(mean), _ffi.ptr(x0), _ffi.ptr(eps),
-                                                       _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
-        if check:
-            self._check_status(desc, x.device)
+
+        def launch():
+            with torch.cuda.device(x.device):
+                _ffi.check(_ffi.lib().cindm_ddpm1d_predict(h, self.model._h, un, C.byref(desc), _ffi.ptr(x), _ffi.ptr(cond_d),
+                                                           int(t), None, B, _ffi.ptr(mean), _ffi.ptr(x0), _ffi.ptr(eps),
+                                                           _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+
+        launch()
+        if check and self._timed_out(desc, x.device):
+            self._rerun_exchange_free(launch, desc, x.device)
         return mean, x0, eps
 
     def model_predictions(self, x, cond, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, **kwargs):
@@ -436,15 +462,24 @@ class GaussianDiffusion1D(nn.Module):
                                   noise_steps=None if noise is None else noise.step, seed=seed, sample_offset=sample_offset,
                                   inpaint_cond=inpaint, inpaint_noise_steps=None if noise is None else noise.cond,
                                   use_graph=use_graph)
-        for t in reversed(range(t_stop, self.num_timesteps)):
-            nz = None if noise is None else noise.step[t]
-            rn = None if (noise is None or noise.recur is None) else noise.recur[t]
-            img, _ = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, nz, rn,
-                                       check=False)
-            if inpaint is not None:
-                zc = noise.cond[t] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
-                img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
-        self._check_status(desc, device)
+        img_T = img
+
+        def chain():
+            # (the steps' predictions only feed the next step: the exchange flags are read once, after the last one)
+            img = img_T
+            for t in reversed(range(t_stop, self.num_timesteps)):
+                nz = None if noise is None else noise.step[t]
+                rn = None if (noise is None or noise.recur is None) else noise.recur[t]
+                img, _ = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite, nz, rn,
+                                           check=False)
+                if inpaint is not None:
+                    zc = noise.cond[t] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
+                    img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
+            return img
+
+        img = chain()
+        if self._timed_out(desc, device):
+            img = self._rerun_exchange_free(chain, desc, device)
         return img
 
     @torch.no_grad()
@@ -567,17 +602,25 @@ class GaussianDiffusion1D(nn.Module):
         desc = self._desc_for(shape, compose_mode, n_composed, compose_start_step, shape[1], compose_n_bodies,
                               clip=True)     # p_sample_compose_inside's own default: clip_denoised is not forwarded (:1758-1770)
         coefs = coefs.to(device)
-        for i, (t, tn) in enumerate(zip(times[:-1], times[1:])):
-            rn = None if (noise is None or noise.recur is None) else noise.recur[i]
-            eps, x_start = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite,
-                                             None, rn, ddim_return=True, check=False)
-            if tn < 0:
-                img = x_start
-                continue
-            z = noise.step[i] if noise is not None else torch.randn_like(img)
-            img = x_start * coefs[i, 0] + coefs[i, 1] * eps + coefs[i, 2] * z
-            if inpaint is not None:
-                zc = noise.cond[i] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
-                img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
-        self._check_status(desc, device)
+        img_T = img
+
+        def chain():
+            img = img_T
+            for i, (t, tn) in enumerate(zip(times[:-1], times[1:])):
+                rn = None if (noise is None or noise.recur is None) else noise.recur[i]
+                eps, x_start = self._guided_step(img, cond, t, desc, design_fn, design_guidance, initial_state_overwrite,
+                                                 None, rn, ddim_return=True, check=False)
+                if tn < 0:
+                    img = x_start
+                    continue
+                z = noise.step[i] if noise is not None else torch.randn_like(img)
+                img = x_start * coefs[i, 0] + coefs[i, 1] * eps + coefs[i, 2] * z
+                if inpaint is not None:
+                    zc = noise.cond[i] if (noise is not None and noise.cond is not None) else torch.randn_like(inpaint)
+                    img[:, :inpaint.shape[1], :] = self.q_sample(self._f32(inpaint, device), t, zc)
+            return img
+
+        img = chain()
+        if self._timed_out(desc, device):
+            img = self._rerun_exchange_free(chain, desc, device)
         return img

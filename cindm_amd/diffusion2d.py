@@ -12,6 +12,7 @@ Training, DDIM, self-conditioning and objectives other than pred_noise are outsi
 NotImplementedError.
 """
 import ctypes as C
+from collections import namedtuple
 
 import torch
 from torch import nn
@@ -19,6 +20,9 @@ from torch import nn
 from . import _ffi
 from .schedule import make_schedule
 from .unet2d import from_device_layout, to_device_layout
+
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])      # model/diffusion_2d.py:43
 
 
 class NoiseTape2D:
@@ -193,8 +197,29 @@ class GaussianDiffusion(nn.Module):
         f = lambda y: from_device_layout(y, Cc, H, W)
         return f(xd), f(x0), f(mean)
 
+    @torch.no_grad()
     def model_predictions(self, shape, x, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, share_noise=True):
-        raise NotImplementedError("use p_mean_variance / p_sample: the library fuses the prediction into the step")
+        """:727-754 (objective pred_noise).  x [B*nb, C, H, W] -> ModelPrediction(pred_noise, pred_x_start): the Unet's output
+        with its state channels shared over the boundary copies of a design (``share_noise``; mean or sum by
+        ``use_average_share``), x_start = predict_start_from_noise (clamped when ``clip_x_start``), and with
+        ``clip_x_start and rederive_pred_noise`` the noise re-derived from the clamped x_start.  One library call
+        (``cindm_ddpm2d_predict``: U-Net + one element-wise kernel)."""
+        if not x.is_cuda:
+            raise _ffi.CindmError("sampling needs ROCm device tensors; there is no CPU execution path")
+        if x_self_cond is not None:
+            raise NotImplementedError("self-conditioning is outside this build's scope")
+        B, nb, Cc, H, W = shape
+        ti = self._t_int(t)
+        cp = self.model.padded_channels
+        xd = to_device_layout(x.float(), cp)
+        eps, x0 = torch.zeros_like(xd), torch.zeros_like(xd)
+        h, ws = self._prepare(B * nb, x.device)
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().cindm_ddpm2d_predict(h, self.model._h, _ffi.ptr(xd), B, nb, int(bool(self.use_average_share)),
+                                                       int(bool(share_noise)), int(bool(clip_x_start)), int(bool(rederive_pred_noise)),
+                                                       ti, None, _ffi.ptr(eps), _ffi.ptr(x0), _ffi.ptr(ws), ws.numel(),
+                                                       _ffi.current_stream(x.device)))
+        return ModelPrediction(from_device_layout(eps, Cc, H, W), from_device_layout(x0, Cc, H, W))
 
     @torch.no_grad()
     def p_mean_variance(self, shape, x, t, x_self_cond=None, clip_denoised=True):

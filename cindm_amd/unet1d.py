@@ -70,6 +70,9 @@ class TemporalUnet1D(nn.Module):
         self._sig = None
         self._ws = None
         self._ws_rows = 0
+        # An in-kernel exchange between workgroups that timed out (foreign load on the device kept a partner workgroup from
+        # becoming resident) is recovered by re-running the work once on the exchange-free kernels; False: raise CindmError
+        self.recover_exchange_timeouts = True
         # parameters under the reference's key names, PyTorch-default initialisation
         name = C.create_string_buffer(256)
         shape = (C.c_int64 * 4)()
@@ -163,9 +166,15 @@ class TemporalUnet1D(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, x, time, cond=None):
+    def forward(self, x, time, cond=None, *, check=None):
         """x [B, horizon, transition_dim] fp32 on a ROCm device, time [B] (all equal) -> eps [B, horizon, F]
-        (model/diffusion_1d.py:610-646).  ``cond`` is ignored, as in the reference."""
+        (model/diffusion_1d.py:610-646).  ``cond`` is ignored, as in the reference.
+
+        ``check`` (build-only keyword): read the handle's exchange flag before returning -- a device-to-host copy and a
+        stream synchronise -- and recover from a timed-out exchange (``recover_exchange_timeouts``).  Default: on, except
+        while the current stream is being captured (a synchronise would invalidate the capture).  Callers that pass
+        ``check=False`` (asynchronous pipelines, graph captures) must call ``check_status()`` / ``poll_status()`` themselves
+        before they trust the results."""
         if not x.is_cuda:
             raise _ffi.CindmError("TemporalUnet1D.forward needs a ROCm device tensor; there is no CPU execution path")
         if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:
@@ -182,18 +191,62 @@ class TemporalUnet1D(nn.Module):
         x = x.contiguous().float()
         out = torch.empty_like(x)
         ws = self.workspace(x.shape[0], x.device)
-        with torch.cuda.device(x.device):
-            _ffi.check(_ffi.lib().cindm_unet1d_forward(self._h, _ffi.ptr(x), t, None, _ffi.ptr(out), x.shape[0],
-                                                       _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
-            self.check_status(x.device)
+        if check is None:
+            check = not torch.cuda.is_current_stream_capturing()
+
+        def launch():
+            with torch.cuda.device(x.device):
+                _ffi.check(_ffi.lib().cindm_unet1d_forward(self._h, _ffi.ptr(x), t, None, _ffi.ptr(out), x.shape[0],
+                                                           _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+
+        launch()
+        if check and self.poll_status(x.device):
+            self.rerun_exchange_free(launch, x.device)
         return out
+
+    TIMEOUT_TEXT = ("an in-kernel exchange between workgroups timed out (GroupNorm pair / attention head exchange): "
+                    "the results of that forward are invalid")
 
     def check_status(self, device):
         """Raises CindmError when an in-kernel exchange between workgroups of a forward issued so far timed out (its
-        results are invalid); synchronises the current stream.  ``forward`` and the sampling loops call it before they
-        hand results back."""
+        results are invalid); synchronises the current stream."""
         with torch.cuda.device(device):
             _ffi.check(_ffi.lib().cindm_unet1d_status(self._h, _ffi.current_stream(device)))
+
+    def poll_status(self, device):
+        """True when an exchange of a forward issued so far timed out (the flag is cleared); synchronises the current
+        stream.  With ``recover_exchange_timeouts = False`` a time-out raises CindmError here instead."""
+        with torch.cuda.device(device):
+            rc = _ffi.lib().cindm_unet1d_poll(self._h, _ffi.current_stream(device))
+        if rc < 0:
+            _ffi.check(rc)
+        if rc == 1 and not self.recover_exchange_timeouts:
+            raise _ffi.CindmError(self.TIMEOUT_TEXT)
+        return rc == 1
+
+    def exchange_free(self, on):
+        """Run-time switch (``cindm_unet1d_set_option("no_exchange")``; does not touch the packed weights or the workspace):
+        only kernels without an in-launch exchange between workgroups."""
+        _ffi.check(_ffi.lib().cindm_unet1d_set_option(self._h, b"no_exchange", int(bool(on))))
+
+    def rerun_exchange_free(self, fn, device):
+        """``fn()`` once more with this model on the exchange-free kernels (after a time-out); a second time-out cannot
+        happen there and raises."""
+        self.exchange_free(True)
+        try:
+            fn()
+            with torch.cuda.device(device):
+                rc = _ffi.lib().cindm_unet1d_poll(self._h, _ffi.current_stream(device))
+            if rc != 0:
+                raise _ffi.CindmError(self.TIMEOUT_TEXT if rc == 1 else _ffi.lib().cindm_last_error().decode())
+        finally:
+            self.exchange_free(False)
+        self._py_recovered = getattr(self, "_py_recovered", 0) + 1
+
+    @property
+    def recovered(self):
+        """Forwards / chains of this model that were re-run on the exchange-free kernels after a time-out."""
+        return _ffi.lib().cindm_unet1d_recovered(self._h) + getattr(self, "_py_recovered", 0)
 
     # kind 4 = the k=5 convolutions: conv_gemm_h3_kernel<5,48,*> (split-fp16 MFMA; default) or
     # conv_gemm_kernel<5,32,48,*> (fp32 MFMA; CINDM_MFMA=f32)

@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define CINDM_ABI_VERSION 1
+/* Bumped whenever an entry point's argument list changes or an entry point is added.  History: 1 = rounds 1-2; 2 = round 3's
+ * positional sum_boundary argument of cindm_airfoil_design_grad / cindm_ddpm2d_sample_force, and round 4's additions
+ * (cindm_unet1d_poll, cindm_ddpm2d_predict, cindm_unet1d_phase_prof_*, option "no_exchange", cindm_unet1d_recovered).
+ * A caller compiled against another version must not bind: compare cindm_abi_version() with this constant. */
+#define CINDM_ABI_VERSION 2
 
 typedef struct cindm_unet1d cindm_unet1d;
 typedef struct cindm_ddpm1d cindm_ddpm1d;
@@ -92,6 +96,24 @@ int  cindm_unet1d_get_option(const cindm_unet1d* h, const char* key, int32_t* va
 /* Synchronises `stream` and reports a device-side fault of earlier forwards (the bounded in-kernel exchange between
  * workgroup pairs of the C = 512 GroupNorms timing out).  0 = healthy. */
 int  cindm_unet1d_status(cindm_unet1d* h, void* stream);
+/* The same check for callers that recover: 0 = healthy, 1 = an exchange of an earlier forward on `stream` timed out (its results
+ * are invalid; the flag is cleared), < 0 = error.  Recovery = set_option("no_exchange", 1), re-issue the work, set it back: with
+ * "no_exchange" the forward runs on the kernels that exchange nothing between workgroups (per-layer conv_gemm_h3 launches with
+ * consumer-side GroupNorm at C = 512, the one-workgroup attention site kernel), which cannot time out.  "no_exchange" is a
+ * RUN-TIME option: it does not un-finalize the handle.  The sample loops (cindm_ddpm1d_sample / _sample_ddim / _sample_guided)
+ * do this by themselves: a chain whose exchange timed out (foreign load on the device kept a partner workgroup from becoming
+ * resident) is re-run ONCE from its initial state on the exchange-free kernels; cindm_unet1d_recovered() counts those re-runs. */
+int  cindm_unet1d_poll(cindm_unet1d* h, void* stream);
+int  cindm_unet1d_recovered(const cindm_unet1d* h);
+/* Profiling builds only (cindm_amd/build.py --prof: -DCINDM_PHASE_PROF -> libcindm_hip_prof.so): per-launch, per-workgroup,
+ * per-wave phase clocks (s_memrealtime, 100 MHz) of the level kernels, dconv2_kernel, dresample_kernel and attn1d_head_kernel.
+ * enable: (re)allocates the record buffer and arms it for every following forward of this handle (inside graph replays too);
+ * read: copies the records of the LAST forward/replayed step, [launch slot][workgroup < 1024][wave < 8][16 stamps] uint64,
+ * into host memory (dst_cap in uint64 words) and returns the number of launch slots used (names via cindm_unet1d_phase_prof_name).
+ * In a production build enable returns -1 ("not a profiling build"). */
+int  cindm_unet1d_phase_prof_enable(cindm_unet1d* h, int32_t on);
+int  cindm_unet1d_phase_prof_read(cindm_unet1d* h, unsigned long long* dst, int64_t dst_cap, void* stream);
+const char* cindm_unet1d_phase_prof_name(const cindm_unet1d* h, int32_t slot);
 
 size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h, int64_t rows);
 /* eps[rows,horizon,F] = TemporalUnet1D.forward(x[rows,horizon,F], time=t)   (:610-646).
@@ -346,6 +368,16 @@ int  cindm_ddpm2d_step(cindm_ddpm1d* sched, cindm_unet2d* u, float* x, int64_t B
                        const float* noise_state, const float* noise_boundary, uint64_t seed,
                        int64_t sample_offset, int32_t t, const int32_t* t_dev, float* x0_out,
                        float* mean_out, void* ws, size_t ws_bytes, void* stream);
+/* GaussianDiffusion.model_predictions (:727-754, objective pred_noise) for B designs of nb boundaries: Unet on all
+ * B*nb images; share_noise != 0: the model output's state channels are averaged (use_average_share = 1) or summed (0)
+ * over the boundaries of a design (:732-733); x_start = predict_start_from_noise(x, t, pred_noise), clamped to [-1, 1]
+ * when clip_x_start; rederive_pred_noise (with clip_x_start, :738-739): pred_noise = predict_noise_from_start(x, t,
+ * x_start) = (sqrt_recip_t x - x_start) / sqrt_recipm1_t.  Writes pred_noise_out and x_start_out, both [B*nb, H*W, CP]
+ * (either may be NULL); x is not modified. */
+int  cindm_ddpm2d_predict(cindm_ddpm1d* sched, cindm_unet2d* u, const float* x, int64_t B, int32_t nb,
+                          int32_t use_average_share, int32_t share_noise, int32_t clip_x_start,
+                          int32_t rederive_pred_noise, int32_t t, const int32_t* t_dev,
+                          float* pred_noise_out, float* x_start_out, void* ws, size_t ws_bytes, void* stream);
 /* p_sample_loop (:893-907) without design guidance: steps t_start .. t_end in place on x, one
  * captured HIP graph replayed per step when use_graph.  noise_*_steps, when given, are indexed
  * [timesteps, ...] by t. */

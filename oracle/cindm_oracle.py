@@ -1154,6 +1154,26 @@ def sample_noise_2d(state, boundary):
     return torch.cat([state.expand(-1, nb, -1, -1, -1), boundary], dim=2)
 
 
+def model_predictions_2d(d, shape, x, t, clip_x_start=False, rederive_pred_noise=False, share_noise=True):
+    """GaussianDiffusion.model_predictions, model/diffusion_2d.py:727-754 (objective pred_noise): the Unet's output with its
+    state channels shared over the boundary copies (``share_noise``, :732-733), x_start = predict_start_from_noise
+    (:735, clamped with ``clip_x_start``) and, with ``clip_x_start and rederive_pred_noise`` (:738-739), the noise
+    re-derived from the clamped x_start (predict_noise_from_start :691-695).  Returns (pred_noise, x_start)."""
+    assert d.objective == "pred_noise"
+    B, nb = shape[0], shape[1]
+    T = d.tab
+    tt = torch.full((x.shape[0],), t, dtype=torch.long)
+    eps = unet2d_forward(d.sd, x, tt)
+    if share_noise:
+        eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
+    x_start = T["sqrt_recip_alphas_cumprod"][t] * x - T["sqrt_recipm1_alphas_cumprod"][t] * eps
+    if clip_x_start:
+        x_start = x_start.clamp(-1.0, 1.0)
+        if rederive_pred_noise:
+            eps = (T["sqrt_recip_alphas_cumprod"][t] * x - x_start) / T["sqrt_recipm1_alphas_cumprod"][t]
+    return eps, x_start
+
+
 def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard", clip_denoised=True, recur_noise=None):
     """GaussianDiffusion.p_sample, model/diffusion_2d.py:788-889 (objective pred_noise, share_noise True).
     x [B*nb, C, H, W]; noise [B*nb, C, H, W] (= sample_noise(...).view) or None at t == 0; design_fn returns a GRADIENT

@@ -60,18 +60,18 @@ def _cond4(total):
     return torch.rand((total, 4, 16), generator=torch.Generator().manual_seed(4))
 
 
-def _run_case(case, dev, total, sharded):
+def _run_case(case, dev, total, sharded, gather=True):
     """One of the sharded entry points (or, sharded=False, the plain single-process call it must reproduce)."""
     from cindm_amd import dist as cdist
     import cindm_amd
     if case == "cfg3":
         d = _build(dev)
-        return cdist.sample_sharded(d, total, seed=77, **KW) if sharded else d.sample(batch_size=total, seed=77, sample_offset=0, **KW)
+        return cdist.sample_sharded(d, total, seed=77, gather=gather, **KW) if sharded else d.sample(batch_size=total, seed=77, sample_offset=0, **KW)
     if case == "cfg4":
         d = _build_cfg4(dev)
         cond = _cond4(total).to(dev)
         if sharded:
-            return cdist.sample_multibodies_sharded(d, cond, 12, 0, 4, seed=5)
+            return cdist.sample_multibodies_sharded(d, cond, 12, 0, 4, seed=5, gather=gather)
         return d.sample_compose_multibodies(cond, 12, 0, 4, seed=5)
     guided = case == "cfg5g"
     d, force = _build_2d(dev, guided)
@@ -84,11 +84,34 @@ def _run_case(case, dev, total, sharded):
 
     if sharded:
         lo, hi = cdist.shard_bounds(total, dist.get_rank(), dist.get_world_size())
-        return cdist.sample2d_sharded(d, total, seed=9, num_boundaries=nb, t_stop=996, **kw(hi - lo))
+        return cdist.sample2d_sharded(d, total, seed=9, num_boundaries=nb, t_stop=996, gather=gather, **kw(hi - lo))
     return d.sample(batch_size=total, num_boundaries=nb, seed=9, t_stop=996, **kw(total))
 
 
-def _worker(rank, world, port, total, ngpu, q, case="cfg3"):
+class _DeviceTurn:
+    """The exchange kernels of one chain want their launches' workgroups co-resident: two chains must
+    not run concurrently on ONE device.  On a one-GPU box the two ranks share cuda:0, so each takes the device for the length
+    of its chain (a file lock); the all-gather happens outside the lock.  (What happens WITHOUT this courtesy -- time-outs
+    recovered on the exchange-free kernels -- is test_two_processes_sampling_concurrently_on_one_device.)"""
+
+    def __init__(self, path, enabled):
+        self.path, self.enabled, self.f = path, enabled, None
+
+    def __enter__(self):
+        if self.enabled:
+            import fcntl
+            self.f = open(self.path, "w")
+            fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        if self.f is not None:
+            import fcntl
+            fcntl.flock(self.f, fcntl.LOCK_UN)
+            self.f.close()
+
+
+def _worker(rank, world, port, total, ngpu, q, case="cfg3", lock_path=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     nccl = ngpu >= world
     dev = torch.device("cuda", rank if nccl else 0)
@@ -98,7 +121,15 @@ def _worker(rank, world, port, total, ngpu, q, case="cfg3"):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out = _run_case(case, dev, total, True)
+        from cindm_amd import dist as cdist
+        if nccl or lock_path is None:
+            out = _run_case(case, dev, total, True)
+        else:
+            # ranks sharing one device: the local chain under the device's turn, the gather afterwards
+            with _DeviceTurn(lock_path, True):
+                local = _run_case(case, dev, total, True, gather=False)
+                torch.cuda.synchronize(dev)
+            out = cdist.all_gather_designs(local, total)
         torch.cuda.synchronize(dev)
         q.put((rank, out.cpu().numpy(), dist.get_backend()))      # by value: a shared-memory tensor handle would die with this process
     finally:
@@ -107,16 +138,17 @@ def _worker(rank, world, port, total, ngpu, q, case="cfg3"):
 
 @pytest.mark.parametrize("case,total,shape", [("cfg3", 6, (56, 8)), ("cfg3", 5, (56, 8)), ("cfg4", 5, (20, 16)),
                                               ("cfg5", 3, (2, 21, 64, 64)), ("cfg5g", 3, (2, 21, 64, 64))])
-def test_two_rank_sampler_bitwise(device, case, total, shape):
+def test_two_rank_sampler_bitwise(device, case, total, shape, tmp_path):
     """sample_sharded (time composition, config 3), sample_multibodies_sharded (config 4: pair + single-body models) and
     sample2d_sharded (config 5, plain and under the force objective) on two real sampler processes: the gathered result
-    equals the single-process call bit for bit, for even and ragged splits."""
+    equals the single-process call bit for bit, for even and ragged splits.  On a one-GPU box the ranks share cuda:0 and take
+    turns on it (_DeviceTurn): the co-residency rule of the exchange kernels is kept by the test itself."""
     ngpu = torch.cuda.device_count()
     ref = _run_case(case, device, total, False).cpu()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, ngpu, q, case)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, ngpu, q, case, str(tmp_path / "device.lock"))) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
@@ -128,3 +160,51 @@ def test_two_rank_sampler_bitwise(device, case, total, shape):
         assert backend == ("nccl" if ngpu >= 2 else "gloo")
         out = torch.from_numpy(out)
         assert torch.equal(out, ref), (case, rank, float((out - ref).abs().max()))
+
+
+def _concurrent_worker(rank, q, go, batch, t_stop):
+    """An independent sampler process on cuda:0 (no process group): waits for the start signal, runs config-2 chains."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    d = _build(dev)
+    d.sample(batch_size=batch, n_composed=0, compose_n_bodies=2, seed=3, t_stop=990)        # build, finalize, capture
+    torch.cuda.synchronize(dev)
+    q.put(("ready", rank))
+    go.wait(timeout=600)
+    outs = [d.sample(batch_size=batch, n_composed=0, compose_n_bodies=2, seed=100 + i, t_stop=t_stop).cpu().numpy() for i in range(3)]
+    q.put(("done", rank, outs, d.model.recovered))
+
+
+def test_two_processes_sampling_concurrently_on_one_device(device):
+    """Two independent processes sample on the SAME device at the same time, full-size launches (256 designs: one workgroup per
+    CU each, so the two processes' launches compete for every CU).  Co-residency of a launch's workgroups is then not given;
+    a partner that does not become resident within the spin bound raises the exchange flag and the chain is re-run on the
+    exchange-free kernels.  BOTH processes must return the single-process designs: bit-identical when nothing timed out,
+    within the parity tolerance when a chain was recovered (the exchange-free kernels sum in another order)."""
+    batch, t_stop = 256, 940
+    d = _build(device)
+    refs = [d.sample(batch_size=batch, n_composed=0, compose_n_bodies=2, seed=100 + i, t_stop=t_stop).cpu() for i in range(3)]
+    d.model.exchange_free(True)
+    refs_nx = [d.sample(batch_size=batch, n_composed=0, compose_n_bodies=2, seed=100 + i, t_stop=t_stop).cpu() for i in range(3)]
+    d.model.exchange_free(False)
+    ctx = mp.get_context("spawn")
+    q, go = ctx.Queue(), ctx.Event()
+    procs = [ctx.Process(target=_concurrent_worker, args=(r, q, go, batch, t_stop)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for _ in procs:
+        assert q.get(timeout=900)[0] == "ready"
+    go.set()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for tag, rank, outs, recovered in res:
+        assert tag == "done"
+        for i, o in enumerate(outs):
+            o = torch.from_numpy(o)
+            assert bool(torch.isfinite(o).all())
+            if torch.equal(o, refs[i]) or torch.equal(o, refs_nx[i]):
+                continue
+            pytest.fail(f"rank {rank} chain {i}: neither the fast nor the exchange-free result (recovered {recovered}, "
+                        f"max diff {float((o - refs[i]).abs().max()):.3e})")

@@ -270,3 +270,28 @@ def test_step2d_share_noise_false_golden(gold_dir, device, unet2d, avg):
         ch = d.sample(batch_size=2, num_boundaries=2, seed=4, t_stop=995)
         assert bool(torch.isfinite(ch).all()) and torch.equal(ch[:, 0, :-3], ch[:, 1, :-3])
         assert torch.equal(ch, d.sample(batch_size=2, num_boundaries=2, seed=4, t_stop=995, use_graph=False))
+
+
+@pytest.mark.parametrize("tag", ["plain", "clip", "clip_rederive", "noshare", "sum_clip_rederive"])
+def test_model_predictions_2d_golden(gold_dir, device, unet2d, tag):
+    """GaussianDiffusion.model_predictions (model/diffusion_2d.py:727-754) through cindm_ddpm2d_predict against the reference's
+    own outputs: shared / un-shared prediction, clamped x_start, re-derived noise, mean and sum sharing."""
+    from test_oracle_golden import PREDICT_2D, check_predict2d, predict2d_inputs
+    g = np.load(os.path.join(gold_dir, "predict_2d_r4.npz"))
+    clip, red, share, avg = PREDICT_2D[tag]
+    d = cindm_amd.GaussianDiffusion(unet2d[0], image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                    loss_type="l2", use_average_share=avg).to(device)
+    xs = predict2d_inputs()
+    for t in (500, 0):
+        x = xs[(tag, t)]
+        xd = x.to(device)
+        pr = d.model_predictions((1, 2, 21, 64, 64), xd, torch.full((2,), t, device=device), clip_x_start=clip,
+                                 rederive_pred_noise=red, share_noise=share)
+        assert torch.equal(xd.cpu(), x), "model_predictions must not modify its input"
+        check_predict2d(g, tag, t, x, pr.pred_noise, pr.pred_x_start, TOL_STEP)
+        if share:
+            assert torch.equal(pr.pred_noise[0, :-3], pr.pred_noise[1, :-3])
+        # the same numbers p_mean_variance builds on: x_start of the step entry (clip_denoised) equals the clipped prediction
+        if tag == "clip":
+            _, _, _, x0 = d.p_mean_variance((1, 2, 21, 64, 64), xd, t, clip_denoised=True)
+            assert torch.equal(x0, pr.pred_x_start)

@@ -39,6 +39,7 @@ PATHS_1D = [
     {"attn_head": 2},                     # ... all of them on attn1d_head_kernel
     {"l2_prefetch": 0}, {"h3_resample": 0}, {"site_pack": 0},
     {"dconv": 0, "level0": 0, "attn_head": 0},      # the round-1 per-layer path
+    {"no_exchange": 1},                   # the exchange-free selection a timed-out chain is re-run on (no in-launch hand-over between workgroups)
 ]
 IDS_1D = ["-".join(f"{k}{v}" for k, v in p.items()) for p in PATHS_1D]
 
@@ -299,26 +300,69 @@ def test_workspace_recycling(device, unet8):
         m.set_option("ws_alias", 1)
 
 
-def test_exchange_timeout_is_reported(device):
-    """A pair exchange whose partner never publishes (ablation dbg = 39: odd n-tiles of dconv_kernel skip their publish,
-    short spin bound) must surface as CindmError from forward(), from sample() and from the status call -- never as
-    silently wrong designs -- and the handle must work again afterwards."""
+def test_exchange_timeout_is_recovered(device):
+    """A pair exchange whose partner never publishes (ablation dbg = 39: odd n-tiles of the dconv kernels skip their publish,
+    short spin bound) stands in for foreign load keeping a partner workgroup off the chip.  forward(), p_sample*() and sample()
+    must RECOVER: the work is re-run once on the exchange-free kernels ("no_exchange") and the results are the ones that
+    selection gives by itself -- bit for bit -- and right against the oracle; the handle counts the recoveries and works on the
+    fast kernels again afterwards."""
     m, sd = build_unet(device)
     m.set_option("auto_range", 0)           # (the calibration forward at finalize would hit the ablation too)
-    m.set_option("dbg", 39)
     x = torch.randn((32, 24, 8), generator=torch.Generator().manual_seed(2)).to(device)
     t = torch.full((32,), 500, device=device)
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    kw = dict(compose_mode="mean", n_composed=0, single_model_step=24, compose_n_bodies=2)
+    nz = torch.randn((32, 24, 8), generator=torch.Generator().manual_seed(3)).to(device)
+    # what the exchange-free selection computes on its own
+    m.exchange_free(True)
+    ref_fwd = m(x, t).clone()
+    ref_chain = d.sample(batch_size=32, n_composed=0, compose_n_bodies=2, seed=1, t_stop=997).clone()
+    ref_step = d.p_sample_compose_outside(x, None, 500, noise=nz, **kw)[0].clone()
+    m.exchange_free(False)
+    assert m.recovered == 0
+    m.set_option("dbg", 39)
+    got = m(x, t)
+    assert m.recovered == 1 and torch.equal(got, ref_fwd)
+    ref = O.unet1d_forward(sd, x[:4].cpu(), torch.full((4,), 500, dtype=torch.long))
+    assert rel(got[:4], ref) < TOL_FWD
+    chain = d.sample(batch_size=32, n_composed=0, compose_n_bodies=2, seed=1, t_stop=997)
+    assert m.recovered == 2 and torch.equal(chain, ref_chain)
+    step = d.p_sample_compose_outside(x, None, 500, noise=nz, **kw)[0]
+    assert m.recovered == 3 and torch.equal(step, ref_step)
+    # opting out of the recovery: the time-out surfaces as CindmError -- never as silently wrong designs
+    m.recover_exchange_timeouts = False
     with pytest.raises(cindm_amd.CindmError, match="exchange"):
         m(x, t)
-    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
     with pytest.raises(cindm_amd.CindmError, match="exchange"):
-        d.sample(batch_size=32, n_composed=0, compose_n_bodies=2, seed=1, t_stop=997)
-    with pytest.raises(cindm_amd.CindmError, match="exchange"):
-        d.p_sample_compose_outside(x, None, 500, compose_mode="mean", n_composed=0, single_model_step=24, compose_n_bodies=2)
+        d.p_sample_compose_outside(x, None, 500, noise=nz, **kw)
+    m.recover_exchange_timeouts = True
     m.set_option("dbg", 0)
     m.set_option("auto_range", 1)
-    ref = O.unet1d_forward(sd, x[:4].cpu(), torch.full((4,), 500, dtype=torch.long))
-    assert rel(m(x[:4].contiguous(), t[:4]), ref) < TOL_FWD
+    n0 = m.recovered
+    fast = m(x, t)
+    assert m.recovered == n0 and rel(fast[:4], ref) < TOL_FWD and rel(fast, ref_fwd) < TOL_FWD
+
+
+def test_forward_check_opt_out(device):
+    """forward(check=False) issues the launches and returns without the device-to-host flag read (asynchronous callers poll
+    themselves); under a stream capture the check is skipped automatically -- a synchronise would invalidate the capture."""
+    m, _ = build_unet(device)
+    x = torch.randn((8, 24, 8), generator=torch.Generator().manual_seed(4)).to(device)
+    t = torch.full((8,), 300, device=device)
+    ref = m(x, t).clone()
+    out = m(x, t, check=False)
+    assert m.poll_status(device) is False and torch.equal(out, ref)
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(s):
+        m(x, 300)                                # (workspace, exchange regions and epochs set up outside the capture)
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y = m(x, 300)                        # (an int timestep: reading a timestep TENSOR is a host synchronisation)
+        g.replay()
+        torch.cuda.synchronize(device)
+        assert m.poll_status(device) is False and torch.equal(y, ref)
 
 
 @pytest.mark.parametrize("seed", [1, 7919])

@@ -27,7 +27,9 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/cindm_hip.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert L.cindm_abi_version() == 1
+    # the version the header declares, the library reports and the binding was written for are one number
+    hv = int(re.search(r"#define\s+CINDM_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "cindm_hip.h")).read()).group(1))
+    assert L.cindm_abi_version() == hv == _ffi.ABI_VERSION == 2
 
 
 def test_descriptor_structs_match_header_layout():
@@ -363,6 +365,77 @@ def test_bench_drops_pmc_fields_measured_on_another_library(tmp_path, monkeypatc
         "void cindm::conv2d_ws_kernel<0, 0>(cindm::Conv2dArgs)": {"launches": 4, "hbm_bytes_per_launch": 10},
         "void cindm::la2d_context_kernel<64>(cindm::La2dArgs)": {"launches": 2, "hbm_bytes_per_launch": 5}}}
     (prof / "force.json").write_text(json.dumps(force))
-    (prof / "r03_pmc_traffic_cfg5.json").write_text(json.dumps(cfg5))
+    (prof / bench.PMC_CFG5_FILE).write_text(json.dumps(cfg5))
     v, note = bench.pmc_surrogate_traffic("force.json")
     assert v == int((2 * 100 + 10 * 30 - 25.0 * 1) / 2) and "2 gradient calls" in note
+
+
+def test_bench_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus 8` outside torchrun starts the ranks itself: the child command must be the driver's own launch
+    line (torch.distributed.run, one node, 8 processes, rendezvous on 127.0.0.1) with bench.py's arguments passed through, and
+    bench.py must exit with the child's code -- before anything in the parent touches a GPU."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    import argparse
+    import subprocess
+    calls = []
+
+    class _Done:
+        returncode = 7
+
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: calls.append((cmd, kw)) or _Done())
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.spawn_ranks_if_needed(argparse.Namespace(gpus=8))
+    assert ex.value.code == 7 and len(calls) == 1
+    cmd = calls[0][0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    # one GPU, or already under torchrun with the right world size: nothing is spawned
+    calls.clear()
+    bench.spawn_ranks_if_needed(argparse.Namespace(gpus=1))
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    bench.spawn_ranks_if_needed(argparse.Namespace(gpus=8))
+    assert not calls
+
+
+def test_bench_line_of_an_eight_rank_world(monkeypatch):
+    """The fields the driver reads from an N-rank line, computed exactly as bench.py computes them, from a mocked world of 8
+    (no GPU here): n_gpus = 8, designs_per_step = 8 x 256 = 2048, parallelism dp8, value = ALL ranks' designs / the slowest
+    rank's time, scaling weak; the compact per-workload record keeps them."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    world, B, steps, elapsed, S = 8, bench.BATCH, 20, 7.2, bench.TIMESTEPS
+    total = B * world
+    value = total * steps / elapsed
+    line = {"metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": steps, "warmup": 5, "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "config": {"workload": "w", "designs_per_step": total, "unet_evals_per_design": S, "reverse_steps_per_design": S,
+                       "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
+            "us_per_reverse_step": round(elapsed / (steps * S) * 1e6, 1), "roofline": None}
+    assert line["n_gpus"] == 8 and line["config"]["designs_per_step"] == 2048 and line["config"]["parallelism"].startswith("dp8")
+    assert abs(line["value"] - 8 * 256 * 20 / 7.2) < 0.01
+    c = bench.compact(line)
+    assert c["value"] == line["value"] and c["designs_per_chain"] == 2048 and c["chains_timed"] == 20 and c["cpu_baseline"] is None
+    # the source computes these fields the same way (guards the formulas against edits)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for needle in ('total = B * world', 'value = total * chains / elapsed', '"n_gpus": world', '"designs_per_step": total',
+                   'f"dp{world} (design-sharded, one all-gather of final designs)"', 'dist.all_reduce(tmax, op=dist.ReduceOp.MAX)',
+                   'init_process_group("nccl"'):
+        assert needle in src, needle
+
+
+def test_bench_cpu_leg_takes_the_best_of_three_repetitions():
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    import time as _t
+    delays = iter([0.03] * 4 + [0.01] * 100)
+    dt, n, per = bench.timed_cpu_steps(lambda k: _t.sleep(next(delays)), budget_s=0.3, reps=3, max_steps=60)
+    assert len(per) == 3 and abs(dt - min(per) / 1e3) < 2e-3 and dt < 0.02 and n >= 6

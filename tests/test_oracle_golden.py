@@ -389,3 +389,40 @@ def test_pinning_report_round3(gold_dir):
     for k in ("glue.sum_b1_nb2_f2", "glue.sum_b2_nb3_f1", "glue.own_b1_nb2_f2", "guided_chain_2d", "step2d.universal-forward",
               "step2d.universal-backward", "step2d.noshare_avg", "step2d.noshare_sum", "get_item_1d"):
         assert rep[k] <= 2e-6, (k, rep[k])
+
+
+PREDICT_2D = {"plain": (False, False, True, True), "clip": (True, False, True, True), "clip_rederive": (True, True, True, True),
+              "noshare": (False, False, False, True), "sum_clip_rederive": (True, True, True, False)}
+
+
+def predict2d_inputs():
+    """The inputs of tests/golden/predict_2d_r4.npz, regenerated as oracle/make_golden_r4.py::input_for drew them."""
+    g = torch.Generator().manual_seed(404)
+    return {(tag, t): torch.randn((2, 21, 64, 64), generator=g) * (1.0 if t > 100 else 1.4) for tag in PREDICT_2D for t in (500, 0)}
+
+
+def check_predict2d(gold, tag, t, x, pred_noise, x_start, tol):
+    assert rel(x.mean(dim=(2, 3)), gold[f"{tag}.t{t}.x.cmean"]) < 1e-6, "regenerated input differs from the recorded one"
+    for name, v in (("pred_noise", pred_noise), ("x_start", x_start)):
+        v = torch.as_tensor(v).detach().cpu()
+        assert rel(v[:, :, 24:40, 8:24], gold[f"{tag}.t{t}.{name}.crop"]) < tol, (tag, t, name)
+        assert rel(v.mean(dim=(2, 3)), gold[f"{tag}.t{t}.{name}.cmean"]) < 50 * tol, (tag, t, name)
+
+
+@pytest.mark.parametrize("tag", sorted(PREDICT_2D))
+def test_model_predictions_2d(gold_dir, sd2d, tag):
+    """GaussianDiffusion.model_predictions (model/diffusion_2d.py:727-754) in every reachable argument combination."""
+    g = np.load(os.path.join(gold_dir, "predict_2d_r4.npz"))
+    clip, red, share, avg = PREDICT_2D[tag]
+    od = O.Diffusion2D(sd2d, image_size=64, frames=6, use_average_share=avg)
+    xs = predict2d_inputs()
+    for t in (500, 0):
+        pn, x0 = O.model_predictions_2d(od, (1, 2, 21, 64, 64), xs[(tag, t)].clone(), t, clip_x_start=clip, rederive_pred_noise=red, share_noise=share)
+        check_predict2d(g, tag, t, xs[(tag, t)], pn, x0, TOL)
+
+
+def test_pinning_report_round4(gold_dir):
+    with open(os.path.join(gold_dir, "PINNING_REPORT_R4.json")) as f:
+        rep = json.load(f)
+    for tag in PREDICT_2D:
+        assert rep["predict2d." + tag] <= 2e-6, (tag, rep)
