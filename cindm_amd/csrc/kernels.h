@@ -68,6 +68,23 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
     return v;
 }
 
+// The step's timestep: from device memory inside the sample loops (t_ptr, graph-replayable), an immediate otherwise.  The
+// immediate goes through an opaque SGPR move so that it is a VALUE, not a kernarg LOCATION: hipcc otherwise folds
+// `p ? *p : a.t_imm` into ONE load from a selected address -- a FLAT vector load (one address global, one constant) whose
+// first use then waits vmcnt(0), i.e. for every weight / activation load the kernel has issued behind it (level0_down_kernel
+// and the L = 6 dconv2 kernels did; round 4, found in the ISA).  With this form it is a scalar branch and an s_load.
+// The load itself goes through the CONSTANT address space (nothing in the running kernel writes the word it reads: the
+// ping-pong update writes the OTHER slot), which makes it an s_load whatever the surrounding code looks like.
+typedef const int __attribute__((address_space(4))) cindm_cint4;
+// a word that no thread of the running kernel writes before this read (exchange epoch, error flag at kernel entry): scalar load
+__device__ __forceinline__ int uniform_word(const int* p) { return *(cindm_cint4*)(const void*)p; }
+__device__ __forceinline__ int step_scalar(const int* p, int imm) {
+    imm = __builtin_amdgcn_readfirstlane(imm);          // (provably uniform for the "s" constraint)
+    asm volatile("" : "+s"(imm));
+    typedef const int __attribute__((address_space(4))) cint4;
+    return p ? *(cint4*)(const void*)p : imm;
+}
+
 // L2 warm-up of the NEXT launch's weights.  Measured (profiles/r02_*): a launch whose weights come from the Infinity
 // Cache instead of its XCD's L2 streams them at 74 instead of 117 GB/s per CU, 65 us per reverse step in total; a side
 // stream cannot do the warm-up (cross-stream graph edges cost more than they save).  So every launch touches, one dword
@@ -117,7 +134,13 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 
 struct Pf { const char* base[2]; unsigned bytes[2]; unsigned stride[2]; int* sink; };
 struct PfRegs { unsigned v[2][2]; };
+// (Every caller is a 256-thread kernel.  Round 4: the block size is a CONSTANT here.  `blockDim.x` is a 16-bit VECTOR-memory load
+// from the dispatch packet: its use made hipcc wait `vmcnt(0)` in the middle of this function -- vector loads return in order, so
+// that drained every weight / activation load the kernel had in flight at that point, a full L2 / Infinity-Cache round trip on
+// the critical path of every launch of the step.  Found with the in-replay phase clocks: the "cross-wave reduce" phase that
+// follows this call measured 1.7 - 2.4 us in dconv2_kernel's phase A against 0.45 us for the same code in phase B.)
 __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
+    constexpr int BLOCK = 256;
     const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, xcd = lin & 7, rank = lin >> 3;
     const int nshare = (int)((gridDim.x * gridDim.y * gridDim.z + 7) >> 3);
 #pragma unroll
@@ -127,7 +150,7 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
         const char* base = p.base[k] + (size_t)xcd * p.stride[k];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int li = (int)threadIdx.x + (int)blockDim.x * i;
+            const int li = (int)threadIdx.x + BLOCK * i;
             const int line = rank * per + li;
             r.v[k][i] = 0u;
             if (li < per && line < lines) r.v[k][i] = *reinterpret_cast<const unsigned*>(base + ((size_t)line << 7));
@@ -247,7 +270,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[3]
     const bool nok = gn < a.N;
     // every global read of the epilogue is issued up front (the step index and the time-bias row it addresses are a
     // dependent pair: left at their point of use they cost two exposed memory latencies per launch)
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
     const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
     float eg = 1.f, eb = 0.f;
     if (a.e_y && nok) { eg = a.e_gamma[gn]; eb = a.e_beta[gn]; }
@@ -417,7 +440,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs a) {
     const int rows_out = ns * a.Lout;
     const int rows_in = ns * a.Lin;
     const int n0 = nt * TN;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
 
     f32x4 acc[3][2];
 #pragma unroll
@@ -666,7 +689,7 @@ __global__ __launch_bounds__(256) void conv_gemm_h3_kernel(const GemmArgs a) {
     const int ns = min(a.spt, a.Bp - b0);
     const int rows_out = ns * a.Lout;
     const int rows_in = ns * a.Lin;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
 
     f32x4 accM[3][2], accL[3][2];
 #pragma unroll
@@ -1626,16 +1649,37 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     __shared__ __attribute__((aligned(16))) float H[NP * HP];                          // h2 in fp32 for the LayerNorm
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int L = a.L, b = blockIdx.x;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
     const int c0 = w * 16;                                               // this wave's channels
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
     const int cl = c0 + lq * 4;                                          // this lane's four channels
+    // ---- every request of the kernel's head in ONE round trip (round 4): the input row, the parameter vectors and the first
+    // layer's weight fragments are requested before anything waits (the row was converted and written to LDS right after its
+    // load: a full round trip from memory, and only then were the weights requested -- a second one) ----
+    const int xr = tid >> 3, xc4 = tid & 7;                              // 32 rows x 8 float4
+    const bool xok = xr < L && 4 * xc4 < a.F;
+    const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + (xok ? xr : 0)) * a.F + (xok ? 4 * xc4 : 0));
+    const float4* Wc0 = reinterpret_cast<const float4*>(a.Wc[0]) + (size_t)w * (5 * 1 * 2 * 64);
+    const float4* Wc1 = reinterpret_cast<const float4*>(a.Wc[1]) + (size_t)w * (5 * 2 * 2 * 64);
+    const float4* Wc2 = reinterpret_cast<const float4*>(a.Wc[2]) + (size_t)w * (5 * 2 * 2 * 64);
+    const float4* Wc3 = reinterpret_cast<const float4*>(a.Wc[3]) + (size_t)w * (5 * 2 * 2 * 64);
+    const float4* Wr4 = reinterpret_cast<const float4*>(a.Wr) + (size_t)w * (1 * 1 * 2 * 64);
+    const float4* Wd4 = reinterpret_cast<const float4*>(a.Wd) + (size_t)w * (3 * 2 * 2 * 64);
+    float4 w5a[5][2], w1[1][2], w10[10][2];
+    lvl_wload<5>(Wc0, lane, w5a); lvl_wload<1>(Wr4, lane, w1);
+    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + cl); };
+    const float4 tb0 = ld4(a.tb0 + (size_t)t_now * a.tb_ld), tb1 = ld4(a.tb1 + (size_t)t_now * a.tb_ld);
+    // every per-channel vector of the level, once (requested where they are used, each cost an L2 round trip inside an epilogue)
+    float4 pbc[4], pga[4], pbe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pbc[i] = ld4(a.bc[i]); pga[i] = ld4(a.gam[i]); pbe[i] = ld4(a.bet[i]); }
+    const float4 pbr = ld4(a.br), pbo = ld4(a.bo), pbd = ld4(a.bd);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage x (zero halo, zero pad channels / positions); clear the halos of the activation planes ----
     {
-        const int r = tid >> 3, c4 = tid & 7;                            // 32 rows x 8 float4
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < L && 4 * c4 < a.F) v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + r) * a.F + 4 * c4);
+        const int r = xr, c4 = xc4;
+        const float4 v = xok ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
         half4v hi, lo;
         hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
         lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
@@ -1655,22 +1699,6 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
             if (cw < XPB / 4) { reinterpret_cast<float*>(&X0[0][row * XPB])[cw] = 0.f; reinterpret_cast<float*>(&X0[1][row * XPB])[cw] = 0.f; }
         }
     }
-    // per-lane channel parameters of the first block
-    const float4* Wc0 = reinterpret_cast<const float4*>(a.Wc[0]) + (size_t)w * (5 * 1 * 2 * 64);
-    const float4* Wc1 = reinterpret_cast<const float4*>(a.Wc[1]) + (size_t)w * (5 * 2 * 2 * 64);
-    const float4* Wc2 = reinterpret_cast<const float4*>(a.Wc[2]) + (size_t)w * (5 * 2 * 2 * 64);
-    const float4* Wc3 = reinterpret_cast<const float4*>(a.Wc[3]) + (size_t)w * (5 * 2 * 2 * 64);
-    const float4* Wr4 = reinterpret_cast<const float4*>(a.Wr) + (size_t)w * (1 * 1 * 2 * 64);
-    const float4* Wd4 = reinterpret_cast<const float4*>(a.Wd) + (size_t)w * (3 * 2 * 2 * 64);
-    auto ld4 = [&](const float* p) { return *reinterpret_cast<const float4*>(p + cl); };
-    const float4 tb0 = ld4(a.tb0 + (size_t)t_now * a.tb_ld), tb1 = ld4(a.tb1 + (size_t)t_now * a.tb_ld);
-    // every per-channel vector of the level, once (requested where they are used, each cost an L2 round trip inside an epilogue)
-    float4 pbc[4], pga[4], pbe[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pbc[i] = ld4(a.bc[i]); pga[i] = ld4(a.gam[i]); pbe[i] = ld4(a.bet[i]); }
-    const float4 pbr = ld4(a.br), pbo = ld4(a.bo), pbd = ld4(a.bd);
-    float4 w5a[5][2], w1[1][2], w10[10][2];
-    lvl_wload<5>(Wc0, lane, w5a); lvl_wload<1>(Wr4, lane, w1);
     __syncthreads();
     PH(1);
 
@@ -1969,7 +1997,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int L = a.L;
     const int s0 = blockIdx.x * NT, s_here = min(NT, a.Bp - s0);
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
     const int t0 = 2 * w;                                                // this wave's first 16-channel tile
     auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)t0 * taps * ks * 2 * 64; };
     LvlRing<2, 4> ring;                                                  // convolution fragments
@@ -1978,22 +2006,30 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     lvlm_prefetch<2, 1, 2, 2>(ring_r, wbase(a.Wr, 1, 2), lane);
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
-    if (tid < C) {
-        const float* src[17] = {a.bc[0], a.bc[1], a.bc[2], a.bc[3], a.gam[0], a.gam[1], a.gam[2], a.gam[3], a.bet[0], a.bet[1], a.bet[2], a.bet[3],
-                                a.tb0 + (size_t)t_now * a.tb_ld, a.tb1 + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bd};
-#pragma unroll
-        for (int i = 0; i < 17; ++i) PV[i][tid] = src[i][tid];
-    }
-    // ---- stage x: sample tile nt at rows nt*RS + 2 + position; everything else zero.  The rows are requested BEFORE the zero
-    // fill and its barrier (after them, their round trip opened every launch) ----
+    // (round 4) the input rows are requested BEFORE the parameter vectors go to LDS: `PV[i][tid] = src[i][tid]` waits for its loads,
+    // and rows requested after that wait were a second serial round trip at the head of the launch
     float4 xin[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         xin[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (nt < s_here && (tid >> 4) < L) xin[nt] = *reinterpret_cast<const float4*>(a.x + ((size_t)(s0 + nt) * L + (tid >> 4)) * CI + 4 * (tid & 15));
     }
+    float pvr[17];                                                       // requested now, written to LDS after the zero fill
+    if (tid < C) {
+        const float* src[17] = {a.bc[0], a.bc[1], a.bc[2], a.bc[3], a.gam[0], a.gam[1], a.gam[2], a.gam[3], a.bet[0], a.bet[1], a.bet[2], a.bet[3],
+                                a.tb0 + (size_t)t_now * a.tb_ld, a.tb1 + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bd};
+#pragma unroll
+        for (int i = 0; i < 17; ++i) pvr[i] = src[i][tid];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stage x: sample tile nt at rows nt*RS + 2 + position; everything else zero.  The rows are requested BEFORE the zero
+    // fill and its barrier (after them, their round trip opened every launch) ----
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(R)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < C) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) PV[i][tid] = pvr[i];
+    }
     __syncthreads();
     PH(1);
     {
@@ -2341,7 +2377,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     unsigned char* Aph = R; unsigned char* Apl = R + NP1 * APB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int L = a.L, L2 = 2 * a.L, b = blockIdx.x;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
     const int c0 = w * 16, cl = c0 + lq * 4;
     auto clb = [&](int mt) { return (2 * w + mt) * 16 + lq * 4; };       // the lane's channels in the 128-channel block
     auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)w * taps * ks * 2 * 64; };
@@ -2351,18 +2387,8 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), lane);
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
-    if (tid < CB) {
-        const float* src[8] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb0 + (size_t)t_now * a.tb_ld, a.br0};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) PVB[i][tid] = src[i][tid];
-    } else if (tid < CB + C) {
-        const int c = tid - CB;
-        const float* src[13] = {a.bc[2], a.gam[2], a.bet[2], a.bc[3], a.gam[3], a.bet[3], a.bc[4], a.gam[4], a.bet[4],
-                                a.tb1 + (size_t)t_now * a.tb_ld, a.br1, a.bo, a.bu};
-#pragma unroll
-        for (int i = 0; i < 13; ++i) PV[i][c] = src[i][c];
-        PV[13][c] = c < a.F ? a.bf[c] : 0.f;
-    }
+    // (round 4) the input rows are requested BEFORE the parameter vectors go to LDS: `PV[i][tid] = src[i][tid]` waits for its loads,
+    // and rows requested after that wait were a second serial round trip at the head of the launch
     float4 xin[4];                                                       // cat(x, skip) rows, requested before the zero fill and its barrier
     if ((tid >> 4) < L) {
 #pragma unroll
@@ -2372,9 +2398,32 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
             xin[q] = *reinterpret_cast<const float4*>(src);
         }
     }
+    float pvr[14];                                                       // requested now, written to LDS after the zero fill
+    if (tid < CB) {
+        const float* src[8] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb0 + (size_t)t_now * a.tb_ld, a.br0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pvr[i] = src[i][tid];
+    } else if (tid < CB + C) {
+        const int c = tid - CB;
+        const float* src[13] = {a.bc[2], a.gam[2], a.bet[2], a.bc[3], a.gam[3], a.bet[3], a.bc[4], a.gam[4], a.bet[4],
+                                a.tb1 + (size_t)t_now * a.tb_ld, a.br1, a.bo, a.bu};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) pvr[i] = src[i][c];
+        pvr[13] = a.bf[c < a.F ? c : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < 2 * ROWS1 * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < CB) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) PVB[i][tid] = pvr[i];
+    } else if (tid < CB + C) {
+        const int c = tid - CB;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) PV[i][c] = pvr[i];
+        PV[13][c] = c < a.F ? pvr[13] : 0.f;
+    }
     __syncthreads();
     PH(1);
     {
@@ -2581,7 +2630,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         // elements are fetched / generated BEFORE the final projection, so the update adds a few FMAs to this kernel's tail.
         float4 xq[2] = {}, zq[2] = {};
         const ComposeArgs& u = a.upd;
-        const int tu = a.fuse_upd ? (u.t_ptr ? *u.t_ptr : u.t_imm) : 0;
+        const int tu = a.fuse_upd ? step_scalar(u.t_ptr, u.t_imm) : 0;
         if (a.fuse_upd) {
             const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
             const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
@@ -2659,7 +2708,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     unsigned char* Aph = R; unsigned char* Apl = R + NP * APB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int L = a.L, L2 = 2 * a.L, b = blockIdx.x;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
     auto cl = [&](int mt) { return (2 * w + mt) * 16 + lq * 4; };
     auto wtile = [&](const float* W, int tile, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)tile * taps * ks * 2 * 64; };
     LvlRing<1, 8> ring, ring_r;
@@ -2667,18 +2716,26 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), lane);
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
-    if (tid < C) {
-        const float* src[10] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bu};
-#pragma unroll
-        for (int i = 0; i < 10; ++i) PV[i][tid] = src[i][tid];
-    }
+    // (round 4) the input rows are requested BEFORE the parameter vectors go to LDS: `PV[i][tid] = src[i][tid]` waits for its loads,
+    // and rows requested after that wait were a second serial round trip at the head of the launch
     float4 xin[4];                                                       // the input rows, requested before the zero fill and its barrier
     if ((tid >> 4) < L) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) xin[q] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + (tid >> 4)) * CI + 4 * ((tid & 15) + 16 * q));
     }
+    float pvr[10];                                                       // requested now, written to LDS after the zero fill
+    if (tid < C) {
+        const float* src[10] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb + (size_t)t_now * a.tb_ld, a.br, a.bo, a.bu};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) pvr[i] = src[i][tid];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < 2 * ROWS * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < C) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) PV[i][tid] = pvr[i];
+    }
     __syncthreads();
     PH(1);
     {
@@ -2980,7 +3037,7 @@ __global__ void compose_gather_kernel(const ComposeArgs a) {
 // One thread per state element (b, l, f) of the FULL sequence (cond rows skipped on output).
 __device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
     const int Lfull = a.Ltot + a.cond_steps;
-    const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t = step_scalar(a.t_ptr, a.t_imm);
     const int sidx = a.ddim_tab ? *a.step_idx : 0;
     const uint64_t dseed = a.dyn ? (uint64_t)a.dyn[0] : a.seed;
     const int64_t dsoff = a.dyn ? (int64_t)a.dyn[1] : a.sample_off;

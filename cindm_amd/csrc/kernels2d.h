@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_tile_kernel(const Conv2dArgs a)
     const int tyi = ti / a.tiles_x;
     const int ty0 = tyi * T2Y, tx0 = (ti - tyi * a.tiles_x) * T2X;
     const int HWi = a.Hin * a.Win;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
     const int tyi = ti / a.tiles_x;
     const int ty0 = tyi * T2Y, tx0 = (ti - tyi * a.tiles_x) * T2X;
     const int HWi = a.Hin * a.Win;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
 
     f32x4 accM[4][2], accL[4][2];
 #pragma unroll
@@ -2098,7 +2098,7 @@ __device__ __forceinline__ void noise2d_bound4(uint64_t seed, int64_t image, uin
 __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
     const int G = a.CP >> 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int t = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t = step_scalar(a.t_ptr, a.t_imm);
     const int total = a.B * a.HW * G;
     if (i < total) {
         const int g = i % G;

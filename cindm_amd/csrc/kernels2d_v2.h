@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     float* const outp = a.out;
     float* const stats_out = a.stats_out;
     const int so_gw = a.so_gw, dbg = a.dbg, stress = a.stress;
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
     const int gw_shift = 31 - __builtin_clz(a.src[0].gw | 1);
     const float* const gn_stats = a.src[0].stats;
     const int gn_P = a.src[0].P;

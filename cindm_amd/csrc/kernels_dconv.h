@@ -29,8 +29,10 @@ namespace cindm {
 // Bound of the hand-over spins.  A chain whose flag is already up (an earlier launch timed out: everything computed since
 // is garbage and the chain will be re-run) only waits briefly: a chain of launches that all wait the full bound would
 // turn one lost partner into minutes.  (~1 us per spin iteration: 2^20 ~ 1 s.)
+// Call it at the TOP of the kernel: the flag is a uniform address, i.e. a scalar load, requested with the step's other scalars
+// (a load at the spin itself is one more exposed round trip).
 __device__ __forceinline__ int spin_bound(const int* err_flag, bool forced_short, int full_log2 = 20) {
-    const int seen = err_flag ? __builtin_nontemporal_load(err_flag) : 0;
+    const int seen = err_flag ? uniform_word(err_flag) : 0;
     return (forced_short || seen) ? (1 << 8) : (1 << full_log2);
 }
 
@@ -81,6 +83,10 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     __shared__ uint4 Tile[2 * 48 * 5];        // output planes of this tile: [plane][row][16 dwords + 4 pad]
 
     if (a.dbg == 1) return;
+    // the step's scalars first (lines the previous step wrote: each a miss to memory), consumed after the operand streams
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
+    const unsigned tag = a.epoch ? (unsigned)uniform_word(a.epoch) : 0u;
+    const int spin_cap = spin_bound(a.err_flag, a.dbg == 9);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * S;
@@ -185,17 +191,21 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue operands: requested behind the operand streams, consumed after the K loop ------------------------
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
-    const unsigned tag = a.epoch ? (unsigned)*a.epoch : 0u;
-    const float bias = a.bias ? a.bias[gn] : 0.f;
+    // (optional vectors: the POINTER is selected and the load is unconditional -- `p ? p[i] : 0.f` is a load under a branch
+    // whose join waits vmcnt(0) before it may write the 0, which drains every operand load issued above it)
     const float gam = a.gamma[gn], bet = a.beta[gn];
-    const float tbv = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : 0.f;
+    const float bias_ld = (a.bias ? a.bias : a.gamma)[gn];
+    const float tbv_ld = (a.tb ? a.tb + (size_t)t_now * a.tb_ld : a.gamma)[gn];
+    const float bias = a.bias ? bias_ld : 0.f, tbv = a.tb ? tbv_ld : 0.f;
     float bias2 = 0.f;
-    if constexpr (RES) bias2 = a.bias2 ? a.bias2[gn] : 0.f;
+    if constexpr (RES) { const float b2 = (a.bias2 ? a.bias2 : a.gamma)[gn]; bias2 = a.bias2 ? b2 : 0.f; }
     float rs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (a.res) {
+    {
+        // residual rows: from `res`, or (no residual) one harmless word of gamma per lane
+        const float* rp = a.res ? a.res + gn : a.gamma + gn;
+        const size_t rld = a.res ? (size_t)a.ldres : 0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) rs[q] = a.res[(size_t)grow[q] * a.ldres + gn];
+        for (int q = 0; q < 6; ++q) { const float r = rp[(size_t)grow[q] * rld]; rs[q] = a.res ? r : 0.f; }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -263,7 +273,10 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
                 }
                 if constexpr (PF) load_r(chn);
             }
-            if constexpr (PF) load_b_tap(chn, tap);
+            if constexpr (PF) {           // requested HERE, behind the tap's last use, and pinned (see dconv2_kernel)
+                load_b_tap(chn, tap);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     if (a.dbg == 2) { if (Img[0][tid].x == 0x12345u) a.out2[0] = 1.f; return; }
@@ -334,7 +347,6 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     if (a.gw == 64 && a.dbg != 5) {
         // the group's other 32 columns belong to the workgroup nt ^ 1 of the same m-tile: swap (mean, M2) halves
         stress_delay(a.stress, 1u);
-        const int spin_cap = spin_bound(a.err_flag, a.dbg == 9);
         const int sbase = ((mt * a.NT + nt) * 16) * 2, pbase = ((mt * a.NT + (nt ^ 1)) * 16) * 2;
 #pragma unroll
         for (int js = 0; js < NSAMP; ++js) {
@@ -347,20 +359,28 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
             }
         }
         stress_delay(a.stress, 2u);
-#pragma unroll
-        for (int js = 0; js < NSAMP; ++js) {
-            const int s = (S == 16) ? rq + 8 * js : rq;
-            unsigned long long g0 = 0, g1 = 0;
+        // the partner's granules of BOTH samples in one sweep (one loop per sample was two serial round trips)
+        unsigned long long gq[NSAMP][2];
+        {
             int spins = 0;
             while (true) {
-                g0 = __hip_atomic_load(a.xchg + pbase + s * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g1 = __hip_atomic_load(a.xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+                bool ok = true;
+#pragma unroll
+                for (int js = 0; js < NSAMP; ++js) {
+                    const int s = (S == 16) ? rq + 8 * js : rq;
+                    gq[js][0] = __hip_atomic_load(a.xchg + pbase + s * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gq[js][1] = __hip_atomic_load(a.xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int js = 0; js < NSAMP; ++js) ok = ok & ((unsigned)(gq[js][0] >> 32) == tag) & ((unsigned)(gq[js][1] >> 32) == tag);
                 if (__all(ok)) break;
                 if (++spins > spin_cap) { if (lane == 0) atomicExch(a.err_flag, 1); break; }     // never hang the GPU
                 __builtin_amdgcn_s_sleep(2);
             }
-            asm volatile("" ::: "memory");      // (granules carry their own tag: nothing is read behind them; kept for uniformity)
+        }
+#pragma unroll
+        for (int js = 0; js < NSAMP; ++js) {
+            const unsigned long long g0 = gq[js][0], g1 = gq[js][1];
             const float mp = __builtin_bit_cast(float, (unsigned)g0), M2p = __builtin_bit_cast(float, (unsigned)g1);
             const float m = 0.5f * (mean[js] + mp);
             const float d0 = mean[js] - m, d1 = mp - m;
@@ -468,6 +488,12 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
 
     PH_DECL;
     PH(0);                                    // phase clocks, profiling builds (kernels.h): 0 = entry
+    // The step's scalars (timestep, exchange epoch, error flag) live in lines the PREVIOUS step's last kernel wrote: each is a
+    // miss all the way to memory.  Requested first, all three together, consumed after the operand streams have been issued
+    // (requested where they are used they were three serial round trips in the prologue).
+    const int t_now = step_scalar(a.t_ptr, a.t_imm);
+    const unsigned tag = (unsigned)uniform_word(a.epoch);
+    const int err_seen = uniform_word(a.err_flag);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = blockIdx.x, mt = blockIdx.y;
     const int b0 = mt * S;
@@ -566,14 +592,15 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue operands of both phases ----------------------------------------------------------------------------
-    const int t_now = a.t_ptr ? *a.t_ptr : a.t_imm;
-    const unsigned tag = (unsigned)*a.epoch;
-    const int spin_cap = spin_bound(a.err_flag, a.dbg == 9);
-    const float bias_a = a.bias_a ? a.bias_a[gn] : 0.f, bias_b = a.bias_b ? a.bias_b[gn] : 0.f;
+    const int spin_cap = (a.dbg == 9 || err_seen) ? (1 << 8) : (1 << 20);      // (spin_bound's rule)
+    // (optional vectors: the POINTER is selected, the load is unconditional.  `p ? p[i] : 0.f` compiles to a load under a
+    // branch whose join waits vmcnt(0) before it may write the 0 -- which drains every operand load issued above it)
     const float gam_a = a.gamma_a[gn], bet_a = a.beta_a[gn], gam_b = a.gamma_b[gn], bet_b = a.beta_b[gn];
-    const float tbv = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : 0.f;
+    const float bias_a_ld = (a.bias_a ? a.bias_a : a.gamma_a)[gn], bias_b_ld = (a.bias_b ? a.bias_b : a.gamma_a)[gn];
+    const float tbv_ld = a.tb ? a.tb[(size_t)t_now * a.tb_ld + gn] : bias_a_ld;      // (every dconv2 launch has a time bias: never taken)
+    const float bias_a = a.bias_a ? bias_a_ld : 0.f, bias_b = a.bias_b ? bias_b_ld : 0.f, tbv = a.tb ? tbv_ld : 0.f;
     float bias2 = 0.f;
-    if constexpr (RES) bias2 = a.bias2 ? a.bias2[gn] : 0.f;
+    if constexpr (RES) { const float b2 = (a.bias2 ? a.bias2 : a.gamma_a)[gn]; bias2 = a.bias2 ? b2 : 0.f; }
     float rs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (!RES) {
 #pragma unroll
@@ -647,7 +674,12 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
                 }
                 if constexpr (PF) load_r(chn);
             }
-            if constexpr (PF) load_b_tap(wb, chn, tap);
+            if constexpr (PF) {
+                // the next stage's fragments of this tap: requested HERE, behind the tap's last use (pinned: left to itself the
+                // scheduler gathers the requests at the end of the k-step, where the next k-step's first taps find them late)
+                load_b_tap(wb, chn, tap);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     constexpr std::true_type YES{};
@@ -728,19 +760,28 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             }
             stress_delay(a.stress, 2u);
             PH(PHB);
-#pragma unroll
-            for (int js = 0; js < NSAMP; ++js) {
-                const int s = (S == 16) ? rq + 8 * js : rq;
-                unsigned long long q0 = 0, q1 = 0;
+            // the partner's granules of BOTH samples in one sweep (one loop per sample was two serial round trips)
+            unsigned long long gq[NSAMP][2];
+            {
                 int spins = 0;
                 while (true) {
-                    q0 = __hip_atomic_load(xchg + pbase + s * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    q1 = __hip_atomic_load(xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = (unsigned)(q0 >> 32) == tag && (unsigned)(q1 >> 32) == tag;
+                    bool ok = true;
+#pragma unroll
+                    for (int js = 0; js < NSAMP; ++js) {
+                        const int s = (S == 16) ? rq + 8 * js : rq;
+                        gq[js][0] = __hip_atomic_load(xchg + pbase + s * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gq[js][1] = __hip_atomic_load(xchg + pbase + s * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int js = 0; js < NSAMP; ++js) ok = ok & ((unsigned)(gq[js][0] >> 32) == tag) & ((unsigned)(gq[js][1] >> 32) == tag);
                     if (__all(ok)) break;
                     if (++spins > spin_cap) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
+            }
+#pragma unroll
+            for (int js = 0; js < NSAMP; ++js) {
+                const unsigned long long q0 = gq[js][0], q1 = gq[js][1];
                 const float mp = __builtin_bit_cast(float, (unsigned)q0), M2p = __builtin_bit_cast(float, (unsigned)q1);
                 const float m = 0.5f * (mean[js] + mp);
                 const float d0 = mean[js] - m, d1 = mp - m;
@@ -812,19 +853,40 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     PH(8);                                    // 8 = the riding 1x1's reduction (RES)
 
     // ---- hand-over: this wave's k-steps of y0 (k-step ks = the 32 channels of producer nt = ks) -----------------------
-    uint4 rawb[KPWB][3][2];
+    // The fetch runs through a ring of YB k-steps of staging registers (24 VGPRs each): with all KPWB k-steps in registers
+    // (96 at C = 512) next to the weight ring (80) the kernel sat at the 256 architectural VGPRs and the compiler shortened
+    // live ranges by sinking every weight-fragment load of phase B to its use -- ~30 exposed L2 round trips in this K loop
+    // (7 us against phase A's 3 - 4 us; found with the in-replay phase clocks and the ISA).  k-step j + YB is requested when
+    // k-step j has gone to LDS; its round trip hides behind YB k-steps of MFMAs.
+    constexpr int YB = KPWB < 2 ? KPWB : 2;
+    uint4 rawb[YB][3][2];
     int slotb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const int item = lane + 64 * i, kq = item / 48, row = item - kq * 48; slotb[i] = kq * RPAD + H * S + row; }
+    const size_t y0_plane_bytes = a.y0_pstride * 16;
+    const auto y0_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.y0), 0, (unsigned)(2 * y0_plane_bytes), 0x00020000);
+    auto fetch_y0 = [&](int j, uint4 (&dst)[3][2]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned off = (unsigned)((((size_t)mt * a.NT + 4 * j + w) * 192 + lane + 64 * i) * 16);
+            dst[i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(y0_rsrc, off, 0, 16));            // sc1: past L1
+            dst[i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(y0_rsrc, off + (unsigned)y0_plane_bytes, 0, 16));
+        }
+    };
     {
         stress_delay(a.stress, 7u);
         int spins = 0;
         const int spin_max = spin_cap;
         while (true) {
-            bool ok = true;
+            // all KPWB flag words requested before the first is looked at (`ok = ok && load(..)` short-circuits: the loads
+            // were issued one by one, each behind the previous one's round trip -- up to four serial cross-XCD trips per poll)
+            unsigned fw[KPWB];
 #pragma unroll
             for (int j = 0; j < KPWB; ++j)
-                ok = ok && __hip_atomic_load(a.flags + 2 * ((size_t)mt * a.NT + 4 * j + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+                fw[j] = __hip_atomic_load(a.flags + 2 * ((size_t)mt * a.NT + 4 * j + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < KPWB; ++j) ok = ok & (fw[j] == tag);
             if (ok) break;                                        // (every lane reads the same words: uniform)
             if (++spins > spin_max) { if (lane == 0) atomicExch(a.err_flag, 1); break; }
             __builtin_amdgcn_s_sleep(1);
@@ -835,23 +897,24 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         // atomic loads of the spin).
         asm volatile("" ::: "memory");
         PH(9);                                // 9 = the flags of this wave's producers seen
-        const size_t plane_bytes = a.y0_pstride * 16;
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.y0), 0, (unsigned)(2 * plane_bytes), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < KPWB; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const unsigned off = (unsigned)((((size_t)mt * a.NT + 4 * j + w) * 192 + lane + 64 * i) * 16);
-                rawb[j][i][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16));            // sc1: past L1
-                rawb[j][i][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (unsigned)plane_bytes, 0, 16));
-            }
+        for (int j = 0; j < YB; ++j) fetch_y0(j, rawb[j]);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- phase B K loop --------------------------------------------------------------------------------------------------
     zero_acc();
 #pragma unroll
-    for (int j = 0; j < KPWB - 1; ++j) { store_raw(false, slotb, j, rawb[j]); kstep(wbase_b, j, j + 1, YES, NO); }
-    store_raw(false, slotb, KPWB - 1, rawb[KPWB - 1]);
-    kstep(wbase_b, KPWB - 1, 0, NO, NO);
+    for (int j = 0; j < KPWB; ++j) {
+        store_raw(false, slotb, j, rawb[j % YB]);
+        if (j + YB < KPWB) fetch_y0(j + YB, rawb[j % YB]);
+        // k-steps are scheduling regions of their own: in ONE region the scheduler sinks the next stage's weight requests
+        // (issued behind each tap's last use, a k-step ahead of their consumers) down to those consumers.  Phase A has the
+        // same protection by accident -- store_raw's run-time source-kind branch ends a basic block per k-step.
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < KPWB - 1) kstep(wbase_b, j, j + 1, YES, NO);
+        else kstep(wbase_b, j, 0, NO, NO);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     PH(10);                                   // 10 = phase B's K loop done (y0 fetch waits + MFMAs)
 
     // ---- phase B epilogue: out = Mish(GN(.)) + (x | r) -------------------------------------------------------------------
@@ -944,7 +1007,8 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     };
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
-    const float bias = a.bias ? a.bias[gn] : 0.f;
+    const float bias_ld = (a.bias ? a.bias : reinterpret_cast<const float*>(a.W))[gn];      // (pointer selected, load unconditional)
+    const float bias = a.bias ? bias_ld : 0.f;
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
     __builtin_amdgcn_sched_barrier(0);
@@ -993,7 +1057,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
                 for (int nb = 0; nb < 2; ++nb)
                     accL[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], breg[tap][nb][0], accL[lo][nb], 0, 0, 0);
             }
-            if constexpr (PF) load_b_tap(chn, tap);
+            if constexpr (PF) { load_b_tap(chn, tap); __builtin_amdgcn_sched_barrier(0); }      // pinned behind the tap's last use
         }
     };
     constexpr std::true_type YES{};
@@ -1095,7 +1159,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     const int s_here = min(a.S, a.Bp - grp * a.S);
     const int nend = s_here * slot;
     const size_t row0 = (size_t)grp * a.S * L;
-    const unsigned tag = (unsigned)*a.epoch;
+    const unsigned tag = (unsigned)uniform_word(a.epoch);
     const int spin_cap = spin_bound(a.err_flag, false, 18);
     const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
     int tile[6];
