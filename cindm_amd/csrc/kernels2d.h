@@ -1165,8 +1165,13 @@ __global__ __launch_bounds__(256) void tail_identity_kernel(const Conv2dArgs a) 
 // same epilogue as conv1x1_wide_kernel<.., EPI>; the input tile is split into hi / scaled-lo fp16 planes while it is
 // staged ([plane][pixel][KT halfs + 8]), B fragments are one ds_read_b128 per plane and 32-channel k-step.
 // Weights: [n-tile][k-step][plane][thread = wave * 64 + lane][8 halfs] = W[n = tile*64 + wave*16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e].
-template <int KT>
+// EP (round 4): which epilogue operand tensors the launch has -- bit 0 the block's second GroupNorm input e_y, bit 1 a residual --
+// as a TEMPLATE parameter: the operand rows do not depend on the product, so they are requested at the top of a tile, all rows
+// at once, and consumed behind its MFMAs.  As run-time `if (a.e_y)` / `if (a.res)` loads inside the epilogue they compiled to
+// load -> vmcnt(0) -> use, eight serial trips to memory per 64 pixels (found in the ISA; the launch ran at 2.8 TB/s).
+template <int KT, int EP>
 __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArgs a) {
+    constexpr bool HAS_Y = (EP & 1) != 0, HAS_R = (EP & 2) != 0;
     constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
     static_assert((64 * F4) % 256 == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
@@ -1187,7 +1192,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
             for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[(((size_t)it * KS + ks) * 2 + pl) * 256]);
     };
     load_w(0, wA);
-    if (a.e_y && w == 1) {
+    if (HAS_Y && w == 1) {
         float m, r;
         merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
         if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
@@ -1222,6 +1227,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
     const unsigned char* xl0 = &Xs[1][lq * PITCH + lg * 16];
     auto tile = [&](int it, const half8 (&wv)[KS][2]) {
         const int col = it * T2N + w * 16 + lg * 4;           // this lane's 4 consecutive output channels
+        // The epilogue's operands (the block's second GroupNorm input, an identity residual) do not depend on the product:
+        // requested HERE, all eight rows at once, and consumed behind the tile's MFMAs.  (Round 4, from the ISA: loaded inside the
+        // epilogue's `if (a.e_y)` / `if (a.res)` they were eight load -> vmcnt(0) -> use sequences per tile, i.e. eight serial
+        // trips to memory per 64 pixels -- the launch ran at 2.8 TB/s.)  Pointers are selected, loads are unconditional.
+        const int colc = col < a.N ? col : 0;
+        float4 yv[HAS_Y ? 4 : 1], rv[HAS_R ? 4 : 1];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const size_t prow = row0 + pb * 16 + lq;
+            if constexpr (HAS_Y) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + prow * a.e_ld + colc);
+            if constexpr (HAS_R) rv[pb] = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + colc);
+        }
+        // (likewise no `if (a.bias)` block: the pointer is selected, the load unconditional)
+        const float4 bias_ld = *reinterpret_cast<const float4*>(a.bias ? a.bias + colc : reinterpret_cast<const float*>(a.W));
+        float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (HAS_Y) { eg = *reinterpret_cast<const float4*>(a.e_gamma + colc); eb = *reinterpret_cast<const float4*>(a.e_beta + colc); }
+        __builtin_amdgcn_sched_barrier(0);                    // (left alone the scheduler sinks the requests below the MFMAs)
         f32x4 accM[4], accL[4];
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) { accM[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1235,14 +1257,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
             }
-        if (col >= a.N) return;                               // N is a multiple of 4 (host)
-        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col);
-        float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (no early return for the columns beyond N: a branch here lets the compiler SINK the operand requests above into the
+        // epilogue's block, behind the MFMAs; the stores are guarded instead)
+        const bool colok = col < a.N;                         // N is a multiple of 4 (host)
+        const float4 bias = a.bias ? bias_ld : make_float4(0.f, 0.f, 0.f, 0.f);
         float em = 0.f, er = 1.f;
-        if (a.e_y) {
-            eg = *reinterpret_cast<const float4*>(a.e_gamma + col); eb = *reinterpret_cast<const float4*>(a.e_beta + col);
-            const int g = col >> (31 - __builtin_clz(a.e_gw));
+        if constexpr (HAS_Y) {
+            const int g = colc >> (31 - __builtin_clz(a.e_gw));
             em = tabE[2 * g]; er = tabE[2 * g + 1];
         }
 #pragma unroll
@@ -1250,17 +1271,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
             const size_t prow = row0 + pb * 16 + lq;
             float4 v = make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
                                    (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
-            if (a.e_y) {
-                const float4 y = *reinterpret_cast<const float4*>(a.e_y + prow * a.e_ld + col);
+            if constexpr (HAS_Y) {
+                const float4 y = yv[pb];
                 v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
                 v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
             }
-            if (a.res) {
-                const float4 r4 = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + col);
+            if constexpr (HAS_R) {
+                const float4 r4 = rv[pb];
                 v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
             }
-            *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
-            if (a.ln_out) {
+            if (colok) *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
+            if (a.ln_out && colok) {
                 // LayerNorm partial of this pixel over the wave's 16 channels: 4 in this lane, 4 lanes (lg) per pixel
                 float sm = (v.x + v.y) + (v.z + v.w);
                 sm = xsum32(xsum16(sm));

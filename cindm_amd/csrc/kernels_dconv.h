@@ -700,11 +700,10 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         kstep(wbase, KPW1 - 1, 0, NO, RIDE_A);
     }
     PH(2);                                    // 2 = phase A's K loop done (staging waits + MFMAs)
-    // phase B's first stage of weights: in flight during phase A's epilogue and the hand-over
-#pragma unroll
-    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
+    // (phase B's first stage of weights is requested further down, where this wave would otherwise idle: requested HERE, the
+    // 20 KB per wave sat in front of the epilogue's first LDS writes in the issue queue -- the cross-wave reduction of phase A
+    // measured 1.5 us in the replayed step against 0.5 us for the same code in phase B)
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
 
     // ---- shared epilogue pieces ---------------------------------------------------------------------------------------
     auto reduce_to = [&](const f32x4 (&m)[3][2], const f32x4 (&l)[3][2], float bs, float (&v)[6]) {
@@ -847,6 +846,10 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     if (tid == 0 && !(a.dbg == 9 && (nt & 1)))
         __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PH(7);                                    // 7 = stores drained, flag raised
+    // phase B's first stage of weights + the next launch's L2 warm-up: in flight during the hand-over (flag poll, y0 fetch)
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
+    l2_prefetch(a.pf, pfr);
     // r = Wr x + br stays in registers (Red is free again: the barrier above)
     float r2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (RES) { reduce_to(accRM, accRL, bias2, r2); __syncthreads(); }
