@@ -85,7 +85,7 @@ struct cindm_unet1d {
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
-    struct WReg { size_t off[2]; unsigned bytes[2]; unsigned stride[2]; };      // byte offsets into blob
+    struct WReg { size_t off[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; };      // byte offsets into blob
     std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag, [2] prefetch sink, [8] second epoch slot
     int epoch_slot = 0;                    // which epoch slot (0 / 8) the forward being emitted reads (ping-pong sample loop)
@@ -200,6 +200,7 @@ static const OptDef kUnet1dOpts[] = {
     {"fuse_update", 1, "CINDM_FUSE_UPDATE"},   // plain single-model steps: the reverse-step update inside ups_last_kernel (no update launch)
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
     {"no_exchange", 0, "CINDM_NO_EXCHANGE"},   // 1: only kernels without an in-launch exchange between workgroups (run-time option: does not un-finalize)
+    {"tune", 0, "CINDM_TUNE"},         // experiment switches for same-box A/B runs (run-time; 0 = the shipped choices)
     {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
@@ -222,7 +223,8 @@ extern "C" int cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t
     if (it->second != value) {
         it->second = value;
         // "no_exchange" only selects among kernels whose operands are all packed already: the handle stays finalized
-        if (std::strcmp(key, "no_exchange") != 0) h->finalized = false;
+        if (std::strcmp(key, "no_exchange") != 0 && std::strcmp(key, "tune") != 0) h->finalized = false;
+        else h->generation = ++g_generation;         // (captured steps embed the switch: never replay an older capture)
     }
     return 0;
 }
@@ -634,7 +636,7 @@ struct Emitter {
         const auto& tab = h->pf_table;
         if (!dry && !pf_out && h->O("l2_prefetch") && !tab.empty()) {
             const cindm_unet1d::WReg& nx = tab[(size_t)(pf_idx + 1) % tab.size()];
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < PF_REGIONS; ++k) {
                 pf.base[k] = reinterpret_cast<const char*>(h->blob) + nx.off[k];
                 pf.bytes[k] = nx.bytes[k]; pf.stride[k] = nx.stride[k];
             }
@@ -933,7 +935,8 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
         cindm_unet1d::WReg r{};
         const size_t t0 = w0.sz * 4 / (size_t)NT, t1 = w1.sz * 4 / (size_t)NT;
         if (NT % 8 == 0) { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
-                           r.off[1] = w1.off * 4; r.bytes[1] = (unsigned)t1; r.stride[1] = (unsigned)t1; }
+                           r.off[1] = w1.off * 4; r.bytes[1] = (unsigned)t1; r.stride[1] = (unsigned)t1;
+                         }
         else { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)std::min(w0.sz * 4, (size_t)2 << 20); }
         Pf pf; E.pf_step(pf, r);
         if (E.dry) { E.drop(y0); return out; }
@@ -956,6 +959,7 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
         d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
         d.xchg_a = xa; d.xchg_b = xb; d.epoch = h->ep(); d.err_flag = h->epoch_dev + 1;
         d.stress = h->O("stress"); d.dbg = h->O("dbg") >= 30 ? h->O("dbg") - 30 : 0;
+        d.tune = h->O("tune");
         d.ph = E.ph_next("dconv2<" + std::to_string(L) + "," + std::to_string(k0) + "," + std::to_string(k1) + "," + (identity ? "false" : "true") + "," +
                          std::to_string(kb) + "> " + p);
         const dim3 grid((unsigned)NT, (unsigned)tiles);

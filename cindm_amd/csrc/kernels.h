@@ -132,8 +132,12 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 #define PH_FLUSH(pb) do { } while (0)
 #endif
 
-struct Pf { const char* base[2]; unsigned bytes[2]; unsigned stride[2]; int* sink; };
-struct PfRegs { unsigned v[2][2]; };
+// PF_REGIONS regions.  (Round 4 tried four -- a dconv2 launch streams two convolutions' weights and an XCD owns two n-tiles of
+// each, so tiles x + 8 are never warmed --: same-box A/B 329.9 us per reverse step with two regions, 332.4 with four.  The extra
+// touches cost more than cold tiles x + 8 do; two it stays.)
+constexpr int PF_REGIONS = 2;
+struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; };
+struct PfRegs { unsigned v[PF_REGIONS][2]; };
 // (Every caller is a 256-thread kernel.  Round 4: the block size is a CONSTANT here.  `blockDim.x` is a 16-bit VECTOR-memory load
 // from the dispatch packet: its use made hipcc wait `vmcnt(0)` in the middle of this function -- vector loads return in order, so
 // that drained every weight / activation load the kernel had in flight at that point, a full L2 / Infinity-Cache round trip on
@@ -144,7 +148,7 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
     const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, xcd = lin & 7, rank = lin >> 3;
     const int nshare = (int)((gridDim.x * gridDim.y * gridDim.z + 7) >> 3);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PF_REGIONS; ++k) {
         const int lines = (int)(p.bytes[k] >> 7);
         const int per = (lines + nshare - 1) / nshare;
         const char* base = p.base[k] + (size_t)xcd * p.stride[k];
@@ -158,7 +162,10 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
     }
 }
 __device__ __forceinline__ void l2_prefetch_done(const Pf& p, const PfRegs& r) {
-    if (p.sink && (r.v[0][0] ^ r.v[0][1] ^ r.v[1][0] ^ r.v[1][1]) == 0x9e3779b9u) p.sink[0] = 1;    // keeps the loads alive
+    unsigned x = 0u;
+#pragma unroll
+    for (int k = 0; k < PF_REGIONS; ++k) x ^= r.v[k][0] ^ r.v[k][1];
+    if (p.sink && x == 0x9e3779b9u) p.sink[0] = 1;    // keeps the loads alive
 }
 
 constexpr int TM = 48;        // tile rows
@@ -1309,6 +1316,25 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
     const int slot = a.slot;
     const int nend = s_here * slot;
     const size_t row0 = (size_t)blockIdx.x * a.S * L;
+    // ---- the rows first (round 4): they come from the previous launch, i.e. from memory, and the LayerNorm needs them before
+    // anything else; requested behind the weight ring they arrived behind it (loads return in order) ----
+    constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;
+    constexpr int RPP = 64 / LPR;
+    constexpr int NPASS = (RW + RPP - 1) / RPP;
+    const int lrow = lane / LPR, lcol = lane % LPR;
+    float4 xr[NPASS][CH];
+    bool okr[NPASS];
+#pragma unroll
+    for (int r = 0; r < NPASS; ++r) {
+        const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
+        okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
+        const size_t xrow = okr[r] ? row0 + sn * L + pn : row0;          // (address clamped, load unconditional)
+#pragma unroll
+        for (int m = 0; m < CH; ++m) xr[r][m] = *reinterpret_cast<const float4*>(a.x + xrow * a.ldx + 4 * (lcol + LPR * m));
+    }
+    float4 gv[CH];
+#pragma unroll
+    for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
     const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);      // one float4 = 8 halfs
     int tile[6];
 #pragma unroll
@@ -1327,26 +1353,13 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
 
     // ---- LayerNorm (as in attn1d_site_kernel), result split into the two fp16 planes ----
     {
-        constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;
-        constexpr int RPP = 64 / LPR;
-        constexpr int NPASS = (RW + RPP - 1) / RPP;
-        const int lrow = lane / LPR, lcol = lane % LPR;
-        float4 xr[NPASS][CH];
-        bool okr[NPASS];
-#pragma unroll
-        for (int r = 0; r < NPASS; ++r) {
-            const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
-            okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
-#pragma unroll
-            for (int m = 0; m < CH; ++m)
-                xr[r][m] = okr[r] ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + 4 * (lcol + LPR * m)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 gv[CH];
-#pragma unroll
-        for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
 #pragma unroll
         for (int r = 0; r < NPASS; ++r) {
             const int n = w * RW + r * RPP + lrow;
+            if (!okr[r]) {
+#pragma unroll
+                for (int m = 0; m < CH; ++m) xr[r][m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             float s1 = 0.f;
 #pragma unroll
             for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
@@ -1454,7 +1467,9 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
-            ex0[nt] = (n < nend && pn < L) ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (row clamped, load unconditional: the rows beyond the samples are never stored)
+            const size_t rowc = (n < nend && pn < L) ? row0 + sn * L + pn : row0;
+            ex0[nt] = *reinterpret_cast<const float4*>(a.x + rowc * a.ldx + c);
         }
     }
     // ---- core ----
@@ -1475,6 +1490,12 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
     __syncthreads();
 
     // ---- out = Wo att + bo + x ----
+    // the epilogue's bias and residual rows of tile t + 1 are requested before tile t's MFMAs (round 4: loaded where they were
+    // used, they were a load -> vmcnt(0) -> use round trip per tile after the first)
+    float4 eb[2], ex[2][NT];
+    eb[0] = eb0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ex[0][nt] = ex0[nt];
     if (a.dbg != 2)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -1485,6 +1506,16 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     wo[(t + WOR - 1) % WOR][k][pl] = Wo4[(((size_t)(ct + WOR - 1) * 4 + k) * 2 + pl) * 64 + lane];
+        }
+        if (t + 1 < TPW) {
+            const int cn = (ct + 1) * 16 + lq * 4;
+            eb[(t + 1) & 1] = *reinterpret_cast<const float4*>(a.bo + cn);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
+                const size_t rowc = (n < nend && pn < L) ? row0 + sn * L + pn : row0;
+                ex[(t + 1) & 1][nt] = *reinterpret_cast<const float4*>(a.x + rowc * a.ldx + cn);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 zM[NT], zL[NT];
@@ -1504,14 +1535,14 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             }
         }
         const int c = ct * 16 + lq * 4;
-        const float4 b = t == 0 ? eb0 : *reinterpret_cast<const float4*>(a.bo + c);
+        const float4 b = eb[t & 1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 z = zM[nt] + zL[nt] * H3_INV;
             const int n = nt * 16 + lr, sn = n / slot, pn = n - sn * slot;
             if (n < nend && pn < L) {
                 const size_t row = row0 + sn * L + pn;
-                const float4 xv = t == 0 ? ex0[nt] : *reinterpret_cast<const float4*>(a.x + row * a.ldx + c);
+                const float4 xv = ex[t & 1][nt];
                 float4 o;
                 o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
                 *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
@@ -1895,12 +1926,17 @@ struct Level1Args {
 // MT x NT tiles of a k-tap convolution.  The weight fragments stream through a register ring of RING taps that the
 // CALLER owns: lvlm_prefetch() issues the first RING - 1 taps (while the previous layer's epilogue runs -- a workgroup of
 // these kernels is alone on its CU, nothing else hides a load), lvlm_conv() keeps RING - 1 taps in flight.
+// RING is a parameter of the ring's type (round 4): the 256-input-channel layers of the up-path kernels hold 64 registers per tap,
+// and with three taps of them (192) next to the residual ring the kernel ran out of ARCHITECTURAL registers -- hipcc then parked
+// the ring in accumulator registers and filled it through ONE staging quad, load -> vmcnt(0) -> v_accvgpr_write per pair: eight
+// serial L2 round trips per tile (ISA of ups_last_kernel; that phase measured 8.3 us against a 5.1 us streaming floor).  Those
+// layers use RING = 2.
 constexpr int LVL_RING = 3;
-template <int MT, int KSMAX>
-struct LvlRing { float4 wr[LVL_RING][MT][KSMAX][2]; };
+template <int MT, int KSMAX, int RING = LVL_RING>
+struct LvlRing { float4 wr[RING][MT][KSMAX][2]; };
 
-template <int MT, int TAPS, int KS, int KSMAX>
-__device__ __forceinline__ void lvlm_load_tap(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, int tap, int slot, int lane) {
+template <int MT, int TAPS, int KS, int KSMAX, int RING>
+__device__ __forceinline__ void lvlm_load_tap(LvlRing<MT, KSMAX, RING>& rg, const float4* __restrict__ Wt, int tap, int slot, int lane) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1908,15 +1944,15 @@ __device__ __forceinline__ void lvlm_load_tap(LvlRing<MT, KSMAX>& rg, const floa
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) rg.wr[slot][mt][k][pl] = Wt[((((size_t)mt * TAPS + tap) * KS + k) * 2 + pl) * 64 + lane];
 }
-template <int MT, int TAPS, int KS, int KSMAX>
-__device__ __forceinline__ void lvlm_prefetch(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, int lane) {
+template <int MT, int TAPS, int KS, int KSMAX, int RING>
+__device__ __forceinline__ void lvlm_prefetch(LvlRing<MT, KSMAX, RING>& rg, const float4* __restrict__ Wt, int lane) {
 #pragma unroll
-    for (int tap = 0; tap < LVL_RING - 1; ++tap) if (tap < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap, tap % LVL_RING, lane);
+    for (int tap = 0; tap < RING - 1; ++tap) if (tap < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap, tap % RING, lane);
 }
 // RMODE 1 = ConvTranspose1d(k = 4, stride 2, pad 1): output position n reads input (n + 1 - tap) / 2 when that is a whole
 // number >= 0 (rows beyond the input are zero), otherwise the zero halo row 0
-template <int MT, int NT, int TAPS, int KS, int PITCHB, int KSMAX, int RMODE = 0>
-__device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX>& rg, const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
+template <int MT, int NT, int TAPS, int KS, int PITCHB, int KSMAX, int RMODE = 0, int RING = LVL_RING>
+__device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX, RING>& rg, const float4* __restrict__ Wt, const unsigned char* Xh, const unsigned char* Xl,
                                           int tile_rows, int stride, int row0, int maxrow, int lane, f32x4 (&out)[MT][NT]) {
     const int lr = lane & 15, lq = lane >> 4;
     f32x4 M[MT][NT], Lo[MT][NT];
@@ -1926,7 +1962,7 @@ __device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX>& rg, const float4* 
         for (int nt = 0; nt < NT; ++nt) { M[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-        if (tap + LVL_RING - 1 < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap + LVL_RING - 1, (tap + LVL_RING - 1) % LVL_RING, lane);
+        if (tap + RING - 1 < TAPS) lvlm_load_tap<MT, TAPS, KS, KSMAX>(rg, Wt, tap + RING - 1, (tap + RING - 1) % RING, lane);
         // all activation fragments of the tap first (one exposed LDS latency per tap instead of one per k-step), then the MFMAs
         half8 xh[KS][NT], xl[KS][NT];
 #pragma unroll
@@ -1946,7 +1982,7 @@ __device__ __forceinline__ void lvlm_conv(LvlRing<MT, KSMAX>& rg, const float4* 
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const half8 wh = __builtin_bit_cast(half8, rg.wr[tap % LVL_RING][mt][k][0]), wl = __builtin_bit_cast(half8, rg.wr[tap % LVL_RING][mt][k][1]);
+                    const half8 wh = __builtin_bit_cast(half8, rg.wr[tap % RING][mt][k][0]), wl = __builtin_bit_cast(half8, rg.wr[tap % RING][mt][k][1]);
                     M[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[k][nt], M[mt][nt], 0, 0, 0);
                     Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[k][nt], Lo[mt][nt], 0, 0, 0);
                     Lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[k][nt], Lo[mt][nt], 0, 0, 0);
@@ -2333,6 +2369,29 @@ __device__ void compose_update_element(const ComposeArgs& a, int64_t i);
 __device__ __forceinline__ void counter_normal4(uint64_t seed, uint64_t sample, uint32_t step, uint32_t elem4, float (&z)[4]);
 // x_{t-1} of one element of a PLAIN single-model step from the model output o (compose_update_element's mode 0 followed
 // by its unguided DDPM tail, operation for operation: the fused and the separate update are bit-identical)
+// The five schedule values of timestep t that plain_step_value reads, fetched ONCE (uniform addresses: scalar loads).  Round 4:
+// ups_last_kernel evaluated plain_step_value eight times per lane and every evaluation re-read its table entries under the
+// objective's branches -- ~30 load -> vmcnt(0) -> use sequences at the very end of the step's LAST kernel (the in-replay phase
+// clocks showed 5 us for the waves that run the update: the tail of every reverse step).
+struct StepCoefs { float cx, co, k1, k2, sigma; };
+typedef const float __attribute__((address_space(4))) cindm_cfloat4;
+__device__ __forceinline__ float uniform_float(const float* p) { return *(cindm_cfloat4*)(const void*)p; }
+__device__ __forceinline__ StepCoefs plain_step_coefs(const ComposeArgs& a, int t) {
+    StepCoefs c;
+    if (a.objective == 2) { c.cx = uniform_float(a.sqrt_ac + t); c.co = uniform_float(a.sqrt_1mac + t); }
+    else { c.cx = uniform_float(a.sqrt_recip + t); c.co = uniform_float(a.sqrt_recipm1 + t); }
+    c.k1 = uniform_float(a.coef1 + t); c.k2 = uniform_float(a.coef2 + t);
+    c.sigma = (a.add_noise && t > 0) ? expf(0.5f * uniform_float(a.logvar + t)) : 0.f;
+    return c;
+}
+// plain_step_value with the coefficients in hand: operation for operation the same expression
+__device__ __forceinline__ float plain_step_value(const ComposeArgs& a, const StepCoefs& c, int t, float xv, float o, float z) {
+    float x0 = (a.objective == 1) ? o : __fsub_rn(__fmul_rn(c.cx, xv), __fmul_rn(c.co, o));
+    if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    float v = __fadd_rn(__fmul_rn(c.k1, x0), __fmul_rn(c.k2, xv));
+    if (a.add_noise && t > 0) v += c.sigma * z;
+    return v;
+}
 __device__ __forceinline__ float plain_step_value(const ComposeArgs& a, int t, float xv, float o, float z) {
     float x0;
     if (a.objective == 0) x0 = __fsub_rn(__fmul_rn(a.sqrt_recip[t], xv), __fmul_rn(a.sqrt_recipm1[t], o));
@@ -2382,8 +2441,9 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     auto clb = [&](int mt) { return (2 * w + mt) * 16 + lq * 4; };       // the lane's channels in the 128-channel block
     auto wbase = [&](const float* W, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)w * taps * ks * 2 * 64; };
     LvlRing<1, 8> ring, ring_r;                                          // weight rings (one 16-channel tile at a time)
+    LvlRing<1, 8, 2> ring8;                                              // ... of the 256-input-channel block: two taps deep (see LvlRing)
     auto wtile = [&](const float* W, int tile, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)tile * taps * ks * 2 * 64; };
-    lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), lane);
+    lvlm_prefetch<1, 5, 8, 8>(ring8, wtile(a.Wc[0], 2 * w, 5, 8), lane);
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), lane);
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
@@ -2467,11 +2527,11 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     f32x4 vb[2][1], rb[2][1], h1b[2][1];
     {
         f32x4 t[1][1];
-        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS1 - 1, lane, t); vb[0][0] = t[0][0];
-        lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), lane);
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring8, wtile(a.Wc[0], 2 * w, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS1 - 1, lane, t); vb[0][0] = t[0][0];
+        lvlm_prefetch<1, 5, 8, 8>(ring8, wtile(a.Wc[0], 2 * w + 1, 5, 8), lane);
         lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS1 - 1, lane, t); rb[0][0] = t[0][0];
         lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w + 1, 1, 8), lane);
-        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS1 - 1, lane, t); vb[1][0] = t[0][0];
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring8, wtile(a.Wc[0], 2 * w + 1, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS1 - 1, lane, t); vb[1][0] = t[0][0];
         lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), lane);
         lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr0, 2 * w + 1, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS1 - 1, lane, t); rb[1][0] = t[0][0];
         lvlm_prefetch<1, 1, 4, 8>(ring_r, wtile(a.Wr1, w, 1, 4), lane);                   // second block's residual_conv (128 -> 64)
@@ -2631,6 +2691,8 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         float4 xq[2] = {}, zq[2] = {};
         const ComposeArgs& u = a.upd;
         const int tu = a.fuse_upd ? step_scalar(u.t_ptr, u.t_imm) : 0;
+        StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.fuse_upd) sc = plain_step_coefs(u, tu);
         if (a.fuse_upd) {
             const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
             const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
@@ -2663,8 +2725,8 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
                 *reinterpret_cast<float4*>(a.eps + i0) = o;
                 if (a.fuse_upd)
                     *reinterpret_cast<float4*>(u.x_out + i0) =
-                        make_float4(plain_step_value(u, tu, xq[nt].x, o.x, zq[nt].x), plain_step_value(u, tu, xq[nt].y, o.y, zq[nt].y),
-                                    plain_step_value(u, tu, xq[nt].z, o.z, zq[nt].z), plain_step_value(u, tu, xq[nt].w, o.w, zq[nt].w));
+                        make_float4(plain_step_value(u, sc, tu, xq[nt].x, o.x, zq[nt].x), plain_step_value(u, sc, tu, xq[nt].y, o.y, zq[nt].y),
+                                    plain_step_value(u, sc, tu, xq[nt].z, o.z, zq[nt].z), plain_step_value(u, sc, tu, xq[nt].w, o.w, zq[nt].w));
             }
         }
         if (a.fuse_upd && blockIdx.x == 0 && lane == 0) compose_advance(u, tu);
@@ -2712,7 +2774,8 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     auto cl = [&](int mt) { return (2 * w + mt) * 16 + lq * 4; };
     auto wtile = [&](const float* W, int tile, int taps, int ks) { return reinterpret_cast<const float4*>(W) + (size_t)tile * taps * ks * 2 * 64; };
     LvlRing<1, 8> ring, ring_r;
-    lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), lane);
+    LvlRing<1, 8, 2> ring8;                                              // the 256-input-channel block: two taps deep (see LvlRing)
+    lvlm_prefetch<1, 5, 8, 8>(ring8, wtile(a.Wc[0], 2 * w, 5, 8), lane);
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), lane);
     PfRegs pfr;
     l2_prefetch(a.pf, pfr);
@@ -2782,11 +2845,11 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     f32x4 v[2], r[2], h2[2];
     {
         f32x4 t[1][1];
-        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS - 1, lane, t); v[0] = t[0][0];
-        lvlm_prefetch<1, 5, 8, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), lane);
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring8, wtile(a.Wc[0], 2 * w, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS - 1, lane, t); v[0] = t[0][0];
+        lvlm_prefetch<1, 5, 8, 8>(ring8, wtile(a.Wc[0], 2 * w + 1, 5, 8), lane);
         lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS - 1, lane, t); r[0] = t[0][0];
         lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w + 1, 1, 8), lane);
-        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring, wtile(a.Wc[0], 2 * w + 1, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS - 1, lane, t); v[1] = t[0][0];
+        lvlm_conv<1, 1, 5, 8, XPB, 8>(ring8, wtile(a.Wc[0], 2 * w + 1, 5, 8), XI[0], XI[1], 0, 1, 0, ROWS - 1, lane, t); v[1] = t[0][0];
         lvlm_prefetch<1, 5, 4, 8>(ring, wtile(a.Wc[1], 2 * w, 5, 4), lane);
         lvlm_conv<1, 1, 1, 8, XPB, 8>(ring_r, wtile(a.Wr, 2 * w + 1, 1, 8), XI[0], XI[1], 0, 1, 2, ROWS - 1, lane, t); r[1] = t[0][0];
     }

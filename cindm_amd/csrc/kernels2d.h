@@ -453,7 +453,10 @@ __device__ __forceinline__ void conv2d_h3_epilogue(const Conv2dArgs& a, f32x4 (&
     const int h = tid >> 7, n = tid & 31, rq = (tid >> 5) & 3;          // column half, column, row phase
     const int gn = nt * T2N + h * 32 + n;
     const bool nok = gn < a.N;
-    const float bias = (a.bias && nok) ? a.bias[gn] : 0.f;
+    // (pointer selected, load unconditional and requested before the barrier: `(a.bias && nok) ? a.bias[gn] : 0.f` is a load under
+    // a branch whose join waits vmcnt(0))
+    const float bias_ld = (a.bias ? a.bias : a.out)[nok ? gn : 0];
+    const float bias = (a.bias && nok) ? bias_ld : 0.f;
     const size_t img_base = (size_t)img * a.Hout * a.Wout;
     __syncthreads();
     float v[16];
@@ -713,15 +716,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem7_h3_kernel(const Conv2dArg
     // stage the halo tile: R rows x 8 float4 (channels >= the source's pitch are zero)
     const float* src = a.src[0].p;
     const int ld = a.src[0].ld;
+    // all NP requests first, then the conversions (round 4, from the ISA: `if (ok) v = load` followed by its conversion compiled
+    // to load -> vmcnt(0) -> convert -> store per pass, i.e. NP = 7 serial trips to memory at the head of every workgroup -- the
+    // launch ran at ~0.8 TB/s).  Addresses are clamped, loads unconditional.
+    float4 sv[NP];
+    bool okv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int i = tid + 256 * p;
         const int r = i >> 3, c4 = i & 7;
         const int hy = r / SW, hx = r - hy * SW;
         const int y = ty0 - 3 + hy, x = tx0 - 3 + hx;
-        const bool ok = (r < R) && (c4 * 4 < ld) && (y >= 0) && (y < a.Hin) && (x >= 0) && (x < a.Win);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(src + ((size_t)img * HWi + (size_t)y * a.Win + x) * ld + c4 * 4);
+        okv[p] = (r < R) && (c4 * 4 < ld) && (y >= 0) && (y < a.Hin) && (x >= 0) && (x < a.Win);
+        const size_t off = okv[p] ? ((size_t)img * HWi + (size_t)y * a.Win + x) * ld + c4 * 4 : (size_t)img * HWi * ld;
+        sv[p] = *reinterpret_cast<const float4*>(src + off);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = tid + 256 * p;
+        const int r = i >> 3, c4 = i & 7;
+        const float4 v = okv[p] ? sv[p] : make_float4(0.f, 0.f, 0.f, 0.f);
         half4v hi, lo;
         hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
         lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
@@ -1165,13 +1179,8 @@ __global__ __launch_bounds__(256) void tail_identity_kernel(const Conv2dArgs a) 
 // same epilogue as conv1x1_wide_kernel<.., EPI>; the input tile is split into hi / scaled-lo fp16 planes while it is
 // staged ([plane][pixel][KT halfs + 8]), B fragments are one ds_read_b128 per plane and 32-channel k-step.
 // Weights: [n-tile][k-step][plane][thread = wave * 64 + lane][8 halfs] = W[n = tile*64 + wave*16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e].
-// EP (round 4): which epilogue operand tensors the launch has -- bit 0 the block's second GroupNorm input e_y, bit 1 a residual --
-// as a TEMPLATE parameter: the operand rows do not depend on the product, so they are requested at the top of a tile, all rows
-// at once, and consumed behind its MFMAs.  As run-time `if (a.e_y)` / `if (a.res)` loads inside the epilogue they compiled to
-// load -> vmcnt(0) -> use, eight serial trips to memory per 64 pixels (found in the ISA; the launch ran at 2.8 TB/s).
-template <int KT, int EP>
+template <int KT>
 __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArgs a) {
-    constexpr bool HAS_Y = (EP & 1) != 0, HAS_R = (EP & 2) != 0;
     constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
     static_assert((64 * F4) % 256 == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
@@ -1192,7 +1201,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
             for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[(((size_t)it * KS + ks) * 2 + pl) * 256]);
     };
     load_w(0, wA);
-    if (HAS_Y && w == 1) {
+    if (a.e_y && w == 1) {
         float m, r;
         merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
         if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
@@ -1227,23 +1236,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
     const unsigned char* xl0 = &Xs[1][lq * PITCH + lg * 16];
     auto tile = [&](int it, const half8 (&wv)[KS][2]) {
         const int col = it * T2N + w * 16 + lg * 4;           // this lane's 4 consecutive output channels
-        // The epilogue's operands (the block's second GroupNorm input, an identity residual) do not depend on the product:
-        // requested HERE, all eight rows at once, and consumed behind the tile's MFMAs.  (Round 4, from the ISA: loaded inside the
-        // epilogue's `if (a.e_y)` / `if (a.res)` they were eight load -> vmcnt(0) -> use sequences per tile, i.e. eight serial
-        // trips to memory per 64 pixels -- the launch ran at 2.8 TB/s.)  Pointers are selected, loads are unconditional.
-        const int colc = col < a.N ? col : 0;
-        float4 yv[HAS_Y ? 4 : 1], rv[HAS_R ? 4 : 1];
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-            const size_t prow = row0 + pb * 16 + lq;
-            if constexpr (HAS_Y) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + prow * a.e_ld + colc);
-            if constexpr (HAS_R) rv[pb] = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + colc);
-        }
-        // (likewise no `if (a.bias)` block: the pointer is selected, the load unconditional)
-        const float4 bias_ld = *reinterpret_cast<const float4*>(a.bias ? a.bias + colc : reinterpret_cast<const float*>(a.W));
-        float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (HAS_Y) { eg = *reinterpret_cast<const float4*>(a.e_gamma + colc); eb = *reinterpret_cast<const float4*>(a.e_beta + colc); }
-        __builtin_amdgcn_sched_barrier(0);                    // (left alone the scheduler sinks the requests below the MFMAs)
         f32x4 accM[4], accL[4];
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) { accM[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1257,13 +1249,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
             }
-        // (no early return for the columns beyond N: a branch here lets the compiler SINK the operand requests above into the
-        // epilogue's block, behind the MFMAs; the stores are guarded instead)
-        const bool colok = col < a.N;                         // N is a multiple of 4 (host)
-        const float4 bias = a.bias ? bias_ld : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col >= a.N) return;                               // N is a multiple of 4 (host)
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col);
+        float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
         float em = 0.f, er = 1.f;
-        if constexpr (HAS_Y) {
-            const int g = colc >> (31 - __builtin_clz(a.e_gw));
+        if (a.e_y) {
+            eg = *reinterpret_cast<const float4*>(a.e_gamma + col); eb = *reinterpret_cast<const float4*>(a.e_beta + col);
+            const int g = col >> (31 - __builtin_clz(a.e_gw));
             em = tabE[2 * g]; er = tabE[2 * g + 1];
         }
 #pragma unroll
@@ -1271,17 +1264,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
             const size_t prow = row0 + pb * 16 + lq;
             float4 v = make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
                                    (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
-            if constexpr (HAS_Y) {
-                const float4 y = yv[pb];
+            if (a.e_y) {
+                const float4 y = *reinterpret_cast<const float4*>(a.e_y + prow * a.e_ld + col);
                 v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
                 v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
             }
-            if constexpr (HAS_R) {
-                const float4 r4 = rv[pb];
+            if (a.res) {
+                const float4 r4 = *reinterpret_cast<const float4*>(a.res + prow * a.ldres + col);
                 v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
             }
-            if (colok) *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
-            if (a.ln_out && colok) {
+            *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
+            if (a.ln_out) {
                 // LayerNorm partial of this pixel over the wave's 16 channels: 4 in this lane, 4 lanes (lg) per pixel
                 float sm = (v.x + v.y) + (v.z + v.w);
                 sm = xsum32(xsum16(sm));

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DconvArgs a) {
     };
     if (a.dbg == 2) { if (Img[0][tid].x == 0x12345u) a.out2[0] = 1.f; return; }
     PfRegs pfr;
-    pfr.v[0][0] = pfr.v[0][1] = pfr.v[1][0] = pfr.v[1][1] = 0u;
+#pragma unroll
+    for (int k = 0; k < PF_REGIONS; ++k) pfr.v[k][0] = pfr.v[k][1] = 0u;
     if (a.dbg != 3) {
         constexpr std::true_type PFY{};
         constexpr std::false_type PFN{};
@@ -471,6 +472,7 @@ struct Dconv2Args {
     unsigned long long* xchg_a; unsigned long long* xchg_b; const int* epoch; int* err_flag;     // gw == 64 pair exchanges
     Pf pf; int stress; int dbg;
     PhaseBuf ph;                                          // phase clocks (profiling builds; kernels.h)
+    int tune;                                             // experiment switches for same-box A/B runs (option "tune"; 0 = the shipped choice)
 };
 
 template <int L, int KPW0, int KPW1, bool RES, int KPWB>
@@ -704,6 +706,11 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     // 20 KB per wave sat in front of the epilogue's first LDS writes in the issue queue -- the cross-wave reduction of phase A
     // measured 1.5 us in the replayed step against 0.5 us for the same code in phase B)
     PfRegs pfr;
+    if (a.tune & 1) {                         // A/B: the round-3 placement
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
+        l2_prefetch(a.pf, pfr);
+    }
 
     // ---- shared epilogue pieces ---------------------------------------------------------------------------------------
     auto reduce_to = [&](const f32x4 (&m)[3][2], const f32x4 (&l)[3][2], float bs, float (&v)[6]) {
@@ -847,9 +854,11 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PH(7);                                    // 7 = stores drained, flag raised
     // phase B's first stage of weights + the next launch's L2 warm-up: in flight during the hand-over (flag poll, y0 fetch)
+    if (!(a.tune & 1)) {
 #pragma unroll
-    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
-    l2_prefetch(a.pf, pfr);
+        for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
+        l2_prefetch(a.pf, pfr);
+    }
     // r = Wr x + br stays in registers (Red is free again: the barrier above)
     float r2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (RES) { reduce_to(accRM, accRL, bias2, r2); __syncthreads(); }
@@ -1168,6 +1177,26 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     int tile[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) tile[s] = (s >> 1) * 8 + 2 * hd + (s & 1);
+    // ---- the group's rows first (round 4): they come from the previous launch, i.e. from memory, and the LayerNorm needs them
+    // before anything else -- requested behind the 56 KB of weight fragments per wave they arrived behind them (loads return
+    // in order): the LayerNorm phase measured 3 us in the replayed step ----
+    constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;
+    constexpr int RPP = 64 / LPR;
+    constexpr int NPASS = (RW + RPP - 1) / RPP;
+    const int lrow = lane / LPR, lcol = lane % LPR;
+    float4 xr[NPASS][CH];
+    bool okr[NPASS];
+#pragma unroll
+    for (int r = 0; r < NPASS; ++r) {
+        const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
+        okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
+        const size_t xrow = okr[r] ? row0 + sn * L + pn : row0;          // (address clamped, load unconditional)
+#pragma unroll
+        for (int m = 0; m < CH; ++m) xr[r][m] = *reinterpret_cast<const float4*>(a.x + xrow * a.ldx + 4 * (lcol + LPR * m));
+    }
+    float4 gv[CH];
+#pragma unroll
+    for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
     // this wave's k32 steps of the head's six tiles: everything in flight at once (KPW * 12 KiB per wave)
     float4 wr[KPW][6][2];
 #pragma unroll
@@ -1195,26 +1224,13 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
 
     // ---- LayerNorm of the group's positions -> split-fp16 planes (as attn1d_site_h3_kernel) ----
     {
-        constexpr int LPR = (C / 4 < 64) ? C / 4 : 64;
-        constexpr int RPP = 64 / LPR;
-        constexpr int NPASS = (RW + RPP - 1) / RPP;
-        const int lrow = lane / LPR, lcol = lane % LPR;
-        float4 xr[NPASS][CH];
-        bool okr[NPASS];
-#pragma unroll
-        for (int r = 0; r < NPASS; ++r) {
-            const int n = w * RW + r * RPP + lrow, sn = n / slot, pn = n - sn * slot;
-            okr[r] = (r * RPP + lrow < RW) && n < nend && pn < L;
-#pragma unroll
-            for (int m = 0; m < CH; ++m)
-                xr[r][m] = okr[r] ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + 4 * (lcol + LPR * m)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 gv[CH];
-#pragma unroll
-        for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
 #pragma unroll
         for (int r = 0; r < NPASS; ++r) {
             const int n = w * RW + r * RPP + lrow;
+            if (!okr[r]) {
+#pragma unroll
+                for (int m = 0; m < CH; ++m) xr[r][m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             float s1 = 0.f;
 #pragma unroll
             for (int m = 0; m < CH; ++m) s1 += (xr[r][m].x + xr[r][m].y) + (xr[r][m].z + xr[r][m].w);
