@@ -191,7 +191,7 @@ static const OptDef kUnet1dOpts[] = {
     {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
-    {"level_occ2", 3, nullptr},        // above 320 rows: level0_down (bit 0) / level1_down (bit 1) capped at 256 registers, two workgroups per CU
+    {"level_occ2", 3, nullptr},        // above 320 rows: level0_down (bit 0) / level1_down (bit 1) / ups_last (bit 2) / ups_tail128 (bit 3) capped at 256 registers, two workgroups per CU
     {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled: 0 never, 1 above 320 rows, 2 always
     {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
     {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
@@ -1494,7 +1494,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.ph = E.ph_next("ups_last " + p + " + final_conv");
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
-                    KLAUNCH(E, ups_last_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    if (E.rows > 320 && (h->O("level_occ2") & 4)) KLAUNCH(E, ups_last_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    else KLAUNCH(E, ups_last_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, l);
                 E.prof_end();
             }
             if (taps) { E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre); }
@@ -1534,7 +1535,8 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.ph = E.ph_next("ups_tail128 " + p);
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
-                    KLAUNCH(E, ups_tail128_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    if (E.rows > 320 && (h->O("level_occ2") & 8)) KLAUNCH(E, ups_tail128_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    else KLAUNCH(E, ups_tail128_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, l);
                 E.prof_end();
             }
             if (taps) { E.tap(p + ".1", h2); E.tap(p + ".2", h3); }

@@ -326,7 +326,11 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             for (int i = 0; i < MAXPV; ++i) s += pv[i].x;          // absent partials were loaded as zeros
             s = seg_total(s, 8);                                  // group totals at lanes 7 (mod 8)
             const float invP = 1.0f / (float)gn_P;
-            const float m = group8_total(s, lane >> 3) * invP;
+            // dbg == 77: the shuffle (ds_bpermute) form of the three group totals, the variant that staged stale window pixels while
+            // this kernel was written (round 2).  Same values bit for bit when the hand-overs are right: tools/ws_shfl_experiment.py
+            // counts non-repeating forwards with and without the stress mode.
+            const bool shf = dbg == 77;
+            const float m = (shf ? __shfl(s, (lane & ~7) | 7) : group8_total(s, lane >> 3)) * invP;
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < MAXPV; ++i) {
@@ -334,8 +338,8 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                 q += ((lane & 7) + 8 * i < gn_P) ? pv[i].y + gn_cnt * d * d : 0.f;
             }
             q = seg_total(q, 8);
-            const float gm = group8_total(s, gsel) * invP;
-            const float gr = 1.0f / sqrtf(group8_total(q, gsel) / (gn_cnt * (float)gn_P) + 1e-5f);
+            const float gm = (shf ? __shfl(s, 8 * gsel + 7) : group8_total(s, gsel)) * invP;
+            const float gr = 1.0f / sqrtf((shf ? __shfl(q, 8 * gsel + 7) : group8_total(q, gsel)) / (gn_cnt * (float)gn_P) + 1e-5f);
             // ((v - gm) gr g + b)(sc + 1) + sh  =  v fa + fb   (one fma per element in the staging loop)
             const float sx = psc.x + 1.0f, sy = psc.y + 1.0f, sz = psc.z + 1.0f, sw = psc.w + 1.0f;
             fa.x = gr * pg.x * sx; fa.y = gr * pg.y * sy; fa.z = gr * pg.z * sz; fa.w = gr * pg.w * sw;

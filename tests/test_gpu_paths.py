@@ -251,20 +251,22 @@ def test_pingpong_step_state(device, unet8, cfg):
 
 
 def test_level_kernels_two_workgroups_per_cu(device, unet8):
-    """Above 320 rows level0_down / level1_down are instantiated with 256 registers so that two workgroups share a CU (option
-    level_occ2): the same arithmetic under another register allocation -- the 768-row forward (config 3's row count) is
-    bit-identical with and without it."""
+    """Above 320 rows the level kernels are instantiated with 256 registers so that two workgroups share a CU (option
+    level_occ2, one bit per kernel: level0_down, level1_down, ups_last, ups_tail128): the same arithmetic under another
+    register allocation -- the 768-row forward (config 3's row count) is bit-identical under every choice."""
     m, _ = unet8
     x = torch.randn((768, 24, 8), generator=torch.Generator().manual_seed(21)).to(device)
     t = torch.full((768,), 432, device=device)
     out = {}
     try:
-        for v in (0, 3):
+        default = m.get_option("level_occ2")
+        for v in (0, 3, 12, 15):
             m.set_option("level_occ2", v)
             out[v] = m(x, t).clone()
     finally:
-        m.set_option("level_occ2", 3)
-    assert torch.equal(out[0], out[3])
+        m.set_option("level_occ2", default)
+    for v in (3, 12, 15):
+        assert torch.equal(out[0], out[v]), v
 
 
 def test_workspace_recycling(device, unet8):
