@@ -133,4 +133,148 @@ __global__ __launch_bounds__(256) void fu_attn64_bwd_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) ob[(size_t)r * 384 + 256 + 16 * dt] = O[dt][r];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention for MORE than 64 tokens (coarsest level 16 x 16 or 32 x 32: n = 256 / 1024, a multiple of 64).  Not a
+// shape of the paper's configuration (image_size 64, four levels -> 8 x 8), so plain fp32 arithmetic: thread = query row (or
+// key row), the other side streamed through LDS in 64-token chunks, online softmax.  grid (4 heads, images, n / 64).
+// stat[((img * 4 + h) * n + i) * 3 + {0, 1, 2}] = row maximum, row sum, D_i = dout_i . out_i (the backward's softmax term).
+__global__ __launch_bounds__(64) void fu_attn_gen_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ stat, int n) {
+    __shared__ float K[64][33], V[64][33];
+    const int h = blockIdx.x, img = blockIdx.y, t = threadIdx.x, i = blockIdx.z * 64 + t;
+    const float* base = qkv + (size_t)img * n * 384 + h * 32;
+    float q[32], o[32];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)i * 384 + d4 * 4);
+        q[d4 * 4] = v.x * 0.17677669529663687f; q[d4 * 4 + 1] = v.y * 0.17677669529663687f;
+        q[d4 * 4 + 2] = v.z * 0.17677669529663687f; q[d4 * 4 + 3] = v.w * 0.17677669529663687f;
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int c = 0; c < n; c += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)(c + t) * 384 + 128 + d4 * 4);
+            const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)(c + t) * 384 + 256 + d4 * 4);
+            K[t][d4 * 4] = kv.x; K[t][d4 * 4 + 1] = kv.y; K[t][d4 * 4 + 2] = kv.z; K[t][d4 * 4 + 3] = kv.w;
+            V[t][d4 * 4] = vv.x; V[t][d4 * 4 + 1] = vv.y; V[t][d4 * 4 + 2] = vv.z; V[t][d4 * 4 + 3] = vv.w;
+        }
+        __syncthreads();
+        for (int j = 0; j < 64; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s += q[d] * K[j][d];
+            const float mn = fmaxf(m, s), corr = __expf(m - mn), p = __expf(s - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] = o[d] * corr + p * V[j][d];
+            m = mn;
+        }
+    }
+    const float il = 1.0f / l;
+    float* op = out + ((size_t)img * n + i) * 128 + h * 32;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4)
+        *reinterpret_cast<float4*>(op + d4 * 4) = make_float4(o[d4 * 4] * il, o[d4 * 4 + 1] * il, o[d4 * 4 + 2] * il, o[d4 * 4 + 3] * il);
+    float* sp = stat + (((size_t)img * 4 + h) * n + i) * 3;
+    sp[0] = m; sp[1] = l;
+}
+// dq (thread = query row i): P is recomputed from the row statistics; also leaves D_i for the key-side pass.
+__global__ __launch_bounds__(64) void fu_attn_gen_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+                                                               float* __restrict__ stat, float* __restrict__ dqkv, int n) {
+    __shared__ float K[64][33], V[64][33];
+    const int h = blockIdx.x, img = blockIdx.y, t = threadIdx.x, i = blockIdx.z * 64 + t;
+    const float sc = 0.17677669529663687f;
+    const float* base = qkv + (size_t)img * n * 384 + h * 32;
+    float q[32], g[32], dq[32];
+    float D = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)i * 384 + d4 * 4);
+        const float4 gv = *reinterpret_cast<const float4*>(dout + ((size_t)img * n + i) * 128 + h * 32 + d4 * 4);
+        const float4 ov = *reinterpret_cast<const float4*>(out + ((size_t)img * n + i) * 128 + h * 32 + d4 * 4);
+        q[d4 * 4] = v.x * sc; q[d4 * 4 + 1] = v.y * sc; q[d4 * 4 + 2] = v.z * sc; q[d4 * 4 + 3] = v.w * sc;
+        g[d4 * 4] = gv.x; g[d4 * 4 + 1] = gv.y; g[d4 * 4 + 2] = gv.z; g[d4 * 4 + 3] = gv.w;
+        D += (gv.x * ov.x + gv.y * ov.y) + (gv.z * ov.z + gv.w * ov.w);
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+    float* sp = stat + (((size_t)img * 4 + h) * n + i) * 3;
+    const float m = sp[0], il = 1.0f / sp[1];
+    sp[2] = D;
+    for (int c = 0; c < n; c += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)(c + t) * 384 + 128 + d4 * 4);
+            const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)(c + t) * 384 + 256 + d4 * 4);
+            K[t][d4 * 4] = kv.x; K[t][d4 * 4 + 1] = kv.y; K[t][d4 * 4 + 2] = kv.z; K[t][d4 * 4 + 3] = kv.w;
+            V[t][d4 * 4] = vv.x; V[t][d4 * 4 + 1] = vv.y; V[t][d4 * 4 + 2] = vv.z; V[t][d4 * 4 + 3] = vv.w;
+        }
+        __syncthreads();
+        for (int j = 0; j < 64; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += q[d] * K[j][d]; dp += g[d] * V[j][d]; }
+            const float ds = __expf(s - m) * il * (dp - D);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dq[d] += ds * K[j][d];
+        }
+    }
+    float* op = dqkv + ((size_t)img * n + i) * 384 + h * 32;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4)
+        *reinterpret_cast<float4*>(op + d4 * 4) = make_float4(dq[d4 * 4] * sc, dq[d4 * 4 + 1] * sc, dq[d4 * 4 + 2] * sc, dq[d4 * 4 + 3] * sc);
+}
+// dk, dv (thread = key row j): queries, their gradients and row statistics streamed through LDS.
+__global__ __launch_bounds__(64) void fu_attn_gen_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ stat,
+                                                                float* __restrict__ dqkv, int n) {
+    __shared__ float Q[64][33], G[64][33], St[64][3];
+    const int h = blockIdx.x, img = blockIdx.y, t = threadIdx.x, j = blockIdx.z * 64 + t;
+    const float sc = 0.17677669529663687f;
+    const float* base = qkv + (size_t)img * n * 384 + h * 32;
+    float k[32], v[32], dk[32], dv[32];
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)j * 384 + 128 + d4 * 4);
+        const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)j * 384 + 256 + d4 * 4);
+        k[d4 * 4] = kv.x; k[d4 * 4 + 1] = kv.y; k[d4 * 4 + 2] = kv.z; k[d4 * 4 + 3] = kv.w;
+        v[d4 * 4] = vv.x; v[d4 * 4 + 1] = vv.y; v[d4 * 4 + 2] = vv.z; v[d4 * 4 + 3] = vv.w;
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int c = 0; c < n; c += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const float4 qv = *reinterpret_cast<const float4*>(base + (size_t)(c + t) * 384 + d4 * 4);
+            const float4 gv = *reinterpret_cast<const float4*>(dout + ((size_t)img * n + c + t) * 128 + h * 32 + d4 * 4);
+            Q[t][d4 * 4] = qv.x * sc; Q[t][d4 * 4 + 1] = qv.y * sc; Q[t][d4 * 4 + 2] = qv.z * sc; Q[t][d4 * 4 + 3] = qv.w * sc;
+            G[t][d4 * 4] = gv.x; G[t][d4 * 4 + 1] = gv.y; G[t][d4 * 4 + 2] = gv.z; G[t][d4 * 4 + 3] = gv.w;
+        }
+        {
+            const float* sp = stat + (((size_t)img * 4 + h) * n + c + t) * 3;
+            St[t][0] = sp[0]; St[t][1] = 1.0f / sp[1]; St[t][2] = sp[2];
+        }
+        __syncthreads();
+        for (int i = 0; i < 64; ++i) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += Q[i][d] * k[d]; dp += G[i][d] * v[d]; }
+            const float p = __expf(s - St[i][0]) * St[i][1];
+            const float ds = p * (dp - St[i][2]);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { dv[d] += p * G[i][d]; dk[d] += ds * Q[i][d]; }      // (Q carries the scale)
+        }
+    }
+    float* op = dqkv + ((size_t)img * n + j) * 384 + h * 32;
+#pragma unroll
+    for (int d4 = 0; d4 < 8; ++d4) {
+        *reinterpret_cast<float4*>(op + 128 + d4 * 4) = make_float4(dk[d4 * 4], dk[d4 * 4 + 1], dk[d4 * 4 + 2], dk[d4 * 4 + 3]);
+        *reinterpret_cast<float4*>(op + 256 + d4 * 4) = make_float4(dv[d4 * 4], dv[d4 * 4 + 1], dv[d4 * 4 + 2], dv[d4 * 4 + 3]);
+    }
+}
+
 }  // namespace cindm

@@ -143,15 +143,18 @@ def test_forceunet_fp32_convolution_paths(device, force, opt):
     assert torch.equal(dx2, dx)
 
 
-def test_forceunet_rejects_a_bottleneck_larger_than_64_tokens():
-    with pytest.raises(cindm_amd.CindmError, match="coarsest level must be 8 x 8"):
-        cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4, image_size=128)
+def test_forceunet_rejects_a_bottleneck_larger_than_1024_tokens():
+    with pytest.raises(cindm_amd.CindmError, match="coarsest level must be 8 x 8, 16 x 16 or 32 x 32"):
+        cindm_amd.ForceUnet(dim=64, dim_mults=(8,), channels=4, image_size=64)
 
 
-@pytest.mark.parametrize("size,mults,n", [(32, (1, 2, 8), 4), (16, (1, 8), 6)])
+@pytest.mark.parametrize("size,mults,n", [(32, (1, 2, 8), 4), (16, (1, 8), 6), (32, (1, 8), 3), (64, (1, 2, 8), 2), (32, (8,), 2),
+                                          (128, (1, 2, 4, 8), 1)])
 def test_forceunet_other_image_sizes(device, size, mults, n):
     """Shapes other than the paper's 64 x 64 / (1, 2, 4, 8): 32 x 32 with three levels (split-fp16 tiles at 32 and 16 pixels,
-    paired images at 8, the stem's input gradient on the generic kernel) and 16 x 16 with two."""
+    paired images at 8, the stem's input gradient on the generic kernel) and 16 x 16 with two; and coarsest levels LARGER than
+    the reference's 8 x 8 -- 16 x 16 (256 tokens in the bottleneck attention: 32 / two levels, 64 / three, 128 / four) and
+    32 x 32 (1024 tokens) -- which the class the library replaces accepts (model/diffusion_2d.py:411-486)."""
     sd = O.synth_state_dict_2d(O.force_unet_param_shapes(dim_mults=mults), 5)
     m = cindm_amd.ForceUnet(dim=64, dim_mults=mults, channels=4, image_size=size)
     m.load_state_dict(sd, strict=True)
