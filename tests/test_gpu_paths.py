@@ -524,3 +524,60 @@ def test_cfg5_at_64x2(device):
     assert torch.equal(full[30:34], part)
     assert torch.equal(full[:, 0, :-3], full[:, 1, :-3])
     assert not torch.equal(full[:, 0, -3:], full[:, 1, -3:])
+
+
+_PROF_CHILD = r"""
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import cindm_amd
+from cindm_amd import _ffi
+from cindm_amd.synthetic import synthetic_init_
+dev = torch.device("cuda:0")
+m = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=0, dim=64, dim_mults=(1, 2, 4, 8), attention=True), 0).to(dev)
+x = torch.randn((256, 24, 8), generator=torch.Generator().manual_seed(5)).to(dev)
+t = torch.full((256,), 417, device=dev)
+ref = torch.load(sys.argv[2]).to(dev)
+L = _ffi.lib()
+out = m(x, t).clone()
+assert torch.equal(out, ref), "profiling build, clocks not armed: output differs from the production library"
+assert L.cindm_unet1d_phase_prof_enable(m._h, 1) == 0, L.cindm_last_error()
+out = m(x, t).clone()
+torch.cuda.synchronize()
+assert torch.equal(out, ref), "profiling build, clocks armed: output differs from the production library"
+cap = 32 * 1024 * 8 * 16
+buf = np.zeros(cap, dtype=np.uint64)
+n = L.cindm_unet1d_phase_prof_read(m._h, buf.ctypes.data_as(C.c_void_p), cap, _ffi.current_stream(dev))
+assert n >= 18, (n, L.cindm_last_error())
+names = [L.cindm_unet1d_phase_prof_name(m._h, i).decode() for i in range(n)]
+assert any(s.startswith("dconv2") for s in names) and any(s.startswith("ups_last") for s in names), names
+rec = buf[: n * 1024 * 8 * 16].reshape(n, 1024, 8, 16)
+for i in range(n):
+    st = rec[i, 0, 0]                      # workgroup 0, wave 0 of launch i: the marks this kernel variant passes ascend
+    st = st[st > 0].astype(np.int64)
+    assert len(st) >= 2 and bool((np.diff(st) >= 0).all()), (names[i], st)
+    if i:
+        assert rec[i, 0, 0, 0] >= rec[i - 1, 0, 0, 0], "launch order"
+print("PROF_OK", n)
+"""
+
+
+def test_phase_clock_build(device, tmp_path):
+    """The in-replay phase clocks (DESIGN 4.13) exist only in the profiling build: the production library refuses to arm them;
+    libcindm_hip_prof.so (same sources, -DCINDM_PHASE_PROF) computes bit-identical outputs armed or not, and its records name every
+    launch of a forward, ascend inside a wave and follow the launch order."""
+    import subprocess
+    import sys
+    from cindm_amd.synthetic import synthetic_init_
+    L = cindm_amd._ffi.lib()
+    m = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=0, dim=64, dim_mults=(1, 2, 4, 8), attention=True), 0).to(device)
+    assert L.cindm_unet1d_phase_prof_enable(m._h, 1) != 0 and b"not a profiling build" in L.cindm_last_error()
+    here = os.path.dirname(os.path.abspath(cindm_amd.__file__))
+    if not os.path.exists(os.path.join(here, "libcindm_hip_prof.so")):
+        pytest.skip("libcindm_hip_prof.so has not been built (python -m cindm_amd.build --prof)")
+    x = torch.randn((256, 24, 8), generator=torch.Generator().manual_seed(5)).to(device)
+    t = torch.full((256,), 417, device=device)
+    ref = tmp_path / "ref.pt"
+    torch.save(m(x, t).cpu(), ref)
+    env = dict(os.environ, CINDM_LIB_VARIANT="prof")
+    r = subprocess.run([sys.executable, "-c", _PROF_CHILD, os.path.dirname(here), str(ref)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PROF_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
