@@ -2474,6 +2474,28 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
         pvr[13] = a.bf[c < a.F ? c : 0];
     }
     __builtin_amdgcn_sched_barrier(0);
+    // Fused update (UpsLastArgs::upd): the noise of this sample's state elements depends on nothing this kernel computes, so it is
+    // generated HERE, while the first loads are in flight, by all four waves (slot s = nt * 64 + lane of the final stage's wave 0;
+    // wave w takes slots 32 w ..), parked in R -- free until block 1's output goes there -- and picked up by wave 0 after barrier 4.
+    // At the kernel's tail (one wave, after the last barrier) Philox + Box-Muller were 2.5 us of a 3 us phase (phase clocks, round 4).
+    const int tu_z = a.fuse_upd ? step_scalar(a.upd.t_ptr, a.upd.t_imm) : 0;
+    const bool gen_z = a.fuse_upd && a.upd.add_noise && tu_z > 0;
+    if (gen_z && lane < 32) {
+        const ComposeArgs& u = a.upd;
+        const int s = 32 * w + lane, nt = s >> 6, ln = s & 63, n = nt * 16 + (ln & 15), q4 = (ln >> 4) * 4;
+        if (n < L2 && q4 < a.F) {
+            float4 z;
+            if (u.noise) z = *reinterpret_cast<const float4*>(u.noise + (size_t)tu_z * u.noise_t_stride + ((size_t)b * L2 + n) * a.F + q4);
+            else {
+                const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
+                const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
+                float z4[4];
+                counter_normal4(dseed, (uint64_t)(dsoff + b), (uint32_t)tu_z, (uint32_t)((n * a.F + q4) >> 2), z4);
+                z = make_float4(z4[0], z4[1], z4[2], z4[3]);
+            }
+            reinterpret_cast<float4*>(R)[s] = z;
+        }
+    }
     for (int i = tid; i < 2 * ROWS1 * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2564,6 +2586,12 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     __syncthreads();
     PH(4);
     // ---- block 1 (128 -> 64, residual_conv) ----
+    float4 zq[2] = {};                                                   // (wave 0) the fused update's noise, out of R before H goes there
+    if (w == 0 && gen_z) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (nt * 16 + lr < L2 && lq * 4 < a.F) zq[nt] = reinterpret_cast<const float4*>(R)[nt * 64 + lane];
+    }
     f32x4 v1[1][1], r1[1][1], h2[1];
     lvlm_conv<1, 1, 5, 4, QPB, 8>(ring, wtile(a.Wc[2], w, 5, 4), Q[1][0], Q[1][1], 0, 1, 0, ROWS1 - 1, lane, v1);
     lvlm_prefetch<1, 5, 2, 8>(ring, wbase(a.Wc[3], 5, 2), lane);
@@ -2677,6 +2705,16 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     __syncthreads();
     PH(10);
     // ---- final Conv1dBlock(64 -> 64, k5) and Conv1d(64 -> F, 1) ----
+    float4 xq[2] = {};                                                   // (wave 0) x_t of the elements it will update: a layer ahead
+    StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f};                            // ... and the step's schedule values (scalar loads)
+    if (a.fuse_upd) sc = plain_step_coefs(a.upd, tu_z);
+    if (w == 0 && a.fuse_upd) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nt * 16 + lr;
+            if (n < L2 && lq * 4 < a.F) xq[nt] = *reinterpret_cast<const float4*>(a.upd.x + ((size_t)b * L2 + n) * a.F + lq * 4);
+        }
+    }
     f32x4 y[1][2];
     lvlm_conv<1, 2, 5, 2, PPB, 8>(ring, wbase(a.Wc[4], 5, 2), P[1][0], P[1][1], 16, 1, 0, ROWS2 - 1, lane, y);
     if (w == 0) lvlm_prefetch<1, 1, 2, 8>(ring, reinterpret_cast<const float4*>(a.Wf), lane);
@@ -2688,33 +2726,10 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     PH(11);
     if (w == 0) {
         // Plain single-model step (UpsLastArgs::upd): the lanes that hold the prediction of 4 state elements also apply the
-        // reverse-step update to them, in place -- no compose_update_kernel launch.  The state values and the noise of those
-        // elements are fetched / generated BEFORE the final projection, so the update adds a few FMAs to this kernel's tail.
-        float4 xq[2] = {}, zq[2] = {};
+        // reverse-step update to them, in place -- no compose_update_kernel launch.  Their state values (xq) were requested a
+        // layer ago and their noise (zq) was generated at the top of the kernel, so the update adds a few FMAs to this tail.
         const ComposeArgs& u = a.upd;
-        const int tu = a.fuse_upd ? step_scalar(u.t_ptr, u.t_imm) : 0;
-        StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (a.fuse_upd) sc = plain_step_coefs(u, tu);
-        if (a.fuse_upd) {
-            const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
-            const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = nt * 16 + lr;
-                if (n < L2 && lq * 4 < a.F) {
-                    const size_t i0 = ((size_t)b * L2 + n) * a.F + lq * 4;
-                    xq[nt] = *reinterpret_cast<const float4*>(u.x + i0);
-                    if (u.add_noise && tu > 0) {
-                        if (u.noise) zq[nt] = *reinterpret_cast<const float4*>(u.noise + (size_t)tu * u.noise_t_stride + i0);
-                        else {
-                            float z4[4];
-                            counter_normal4(dseed, (uint64_t)(dsoff + b), (uint32_t)tu, (uint32_t)((n * a.F + lq * 4) >> 2), z4);
-                            zq[nt] = make_float4(z4[0], z4[1], z4[2], z4[3]);
-                        }
-                    }
-                }
-            }
-        }
+        const int tu = tu_z;
         f32x4 e[1][2];
         lvlm_conv<1, 2, 1, 2, PPB, 8>(ring, reinterpret_cast<const float4*>(a.Wf), P[0][0], P[0][1], 16, 1, 2, ROWS2 - 1, lane, e);
         const float4 bf = *reinterpret_cast<const float4*>(&PV[13][lq * 4]);
