@@ -120,12 +120,14 @@ def test_constructor_validation_2d_and_force():
         args.update(kw)
         with pytest.raises(_ffi.CindmError):
             cindm_amd.Unet(**args)
-    for kw in (dict(image_size=128), dict(image_size=32), dict(dim_mults=(1, 2, 4)), dict(dim_mults=(1, 3, 4, 8)), dict(dim=32)):
+    # (image_size 128 with four levels -- a 16 x 16 bottleneck -- is accepted since round 4; coarsest levels of 64 or 4 pixels are not)
+    for kw in (dict(dim_mults=(8,)), dict(image_size=32), dict(dim_mults=(1, 2, 4)), dict(dim_mults=(1, 3, 4, 8)), dict(dim=32)):
         args = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=4, image_size=64)
         args.update(kw)
         with pytest.raises(_ffi.CindmError):
             cindm_amd.ForceUnet(**args)
     cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 8), channels=4, image_size=32)      # three levels: 32 -> 16 -> 8
+    cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4, image_size=128)  # four levels: 128 -> ... -> 16 (256 tokens)
 
 
 def test_diffusion_buffers_and_schedule(gold_dir):
