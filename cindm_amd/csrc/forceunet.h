@@ -227,11 +227,12 @@ __device__ __forceinline__ void fu_group_reduce(float v, float (&red)[256], floa
     __syncthreads();
 }
 __global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int HW, int C,
-                                                           unsigned* __restrict__ amax_reset) {
+                                                           unsigned* __restrict__ amax_reset, unsigned long long* __restrict__ xch_reset) {
     __shared__ float red[256];
     __shared__ float tot[8];
     const int img = blockIdx.x, tid = threadIdx.x, f4 = C >> 2, tpg = f4 >> 3, ppp = 256 / f4;      // pixels per pass
     if (amax_reset && tid == 0) amax_reset[img] = 0u;           // the backward pass of this block accumulates the image's max |dx| here
+    if (xch_reset) xch_reset[(size_t)img * 256 + tid] = 0ull;   // ... and exchanges its partial sums through these granules (16 x 8 x 2 per image)
     const int c4 = tid % f4, p0 = tid / f4;
     const float4* base = reinterpret_cast<const float4*>(x + (size_t)img * HW * C) + c4;
     const float n = (float)HW * (float)(C / 8);
@@ -257,9 +258,11 @@ __global__ __launch_bounds__(256) void fu_gn_stats_kernel(const float* __restric
 // ... or, when conv2d_ws_kernel produced x, from the (mean, M2) partials its store path leaves per (tile, memory wave):
 // [img][8][P][2], P equal-count partials of cnt elements each; one wave per image (kernels2d.h merge_stats8)
 __global__ __launch_bounds__(64) void fu_gn_merge_kernel(const float* __restrict__ part, float* __restrict__ stats, int P, float cnt,
-                                                         unsigned* __restrict__ amax_reset) {
+                                                         unsigned* __restrict__ amax_reset, unsigned long long* __restrict__ xch_reset) {
     const int img = blockIdx.x, lane = threadIdx.x;
     if (amax_reset && lane == 0) amax_reset[img] = 0u;
+    if (xch_reset)
+        for (int i = lane; i < 256; i += 64) xch_reset[(size_t)img * 256 + i] = 0ull;
     float m, r;
     merge_stats8(part + (size_t)img * 8 * P * 2, P, cnt, lane, m, r);
     if ((lane & 7) == 0) { stats[((size_t)img * 8 + (lane >> 3)) * 2] = m; stats[((size_t)img * 8 + (lane >> 3)) * 2 + 1] = r; }
@@ -416,6 +419,113 @@ __global__ __launch_bounds__(512) void fu_gn_silu_bwd_fused_kernel(const float* 
 #pragma unroll
             for (int i = 1; i < 8; ++i) t = fmaxf(t, wm[i]);
             pmax[(size_t)img * 8 + g] = __builtin_bit_cast(unsigned, t);
+        }
+    }
+}
+
+// The same derivative with COALESCED rows (option gn_bwd_fused = 2, round 4).  In the kernel above a workgroup owns (image, group):
+// its slice is C / 8 channels = 32 bytes of every 256-byte pixel row at C = 64, so one float4 load instruction of a wave touches 32
+// cache lines and uses a quarter of each -- 3.7 TB/s at the 64 x 64 level however many bytes are in flight.  Here a workgroup owns
+// (image, slab of HW / NS pixels) with ALL channels: whole rows, every line used once.  The two sums of a group then span the NS
+// workgroups of an image, which exchange their 8 x 2 partial sums through {tag, value} granules (agent-scope relaxed atomics, as the
+// 1-D kernels' pair exchange; the forward pass of the same block clears the image's granules, so the tag is a constant and a
+// captured graph replays).  The workgroups of an image are consecutive block indices: at most one image straddles the residency
+// boundary at any time and its missing members are the next to be dispatched; the spin is bounded and a time-out
+// poisons the output with NaN instead of returning a wrong gradient.  Every reduction runs in a fixed order.
+// NS = slabs (workgroups) per image: 8, or 16 at the 64 x 64 level -- E = 8 float4 per thread and tensor instead of 16 keeps the kernel
+// under 128 registers, so two workgroups share a CU and one's loads run under the other's exchange and stores
+// (645 us per (image, group) -> 554 us with 8 slabs -> 432 us with 16, 768 images of 64 x 64 x 64).
+template <int E, int NS>
+__global__ __launch_bounds__(512, NS == 16 ? 2 : 1) void fu_gn_silu_bwd_cluster_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      const float* __restrict__ stats, const float* __restrict__ gam,
+                                                                      const float* __restrict__ bet, float* __restrict__ dx, float beta,
+                                                                      int HW, int C, unsigned* __restrict__ pmax,
+                                                                      unsigned long long* __restrict__ xch, int stress) {
+    __shared__ float wred[2][8][8];                          // [sum][wave][group]
+    __shared__ float tot[2][NS][8];                          // [sum][slab][group]
+    __shared__ float wm[8];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int img = blockIdx.x / NS, slab = blockIdx.x % NS;
+    const int F4 = C >> 2, QP = C >> 5, PPS = HW / NS;       // float4 per pixel / per group and pixel; pixels per slab
+    const int c4 = tid % F4, g = c4 / QP;                    // (512 is a multiple of F4: a thread keeps its channel quad)
+    const float m = stats[((size_t)img * 8 + g) * 2], r = stats[((size_t)img * 8 + g) * 2 + 1];
+    const float4 ga = *reinterpret_cast<const float4*>(gam + 4 * c4), be = *reinterpret_cast<const float4*>(bet + 4 * c4);
+    const size_t base = ((size_t)img * HW + (size_t)slab * PPS) * C + 4 * c4;
+    float4 a[E], b[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = (tid + 512 * k) / F4;
+        a[k] = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+        b[k] = *reinterpret_cast<const float4*>(dy + base + (size_t)p * C);
+    }
+    if (tid < 128) reinterpret_cast<float*>(wred)[tid] = 0.f;        // (C = 512: a wave covers four of the eight groups)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        float z, dz;
+        fu_gn_dz(a[k].x, b[k].x, m, r, ga.x, be.x, z, dz); a[k].x = z; b[k].x = dz; s1 += dz; s2 += dz * z;
+        fu_gn_dz(a[k].y, b[k].y, m, r, ga.y, be.y, z, dz); a[k].y = z; b[k].y = dz; s1 += dz; s2 += dz * z;
+        fu_gn_dz(a[k].z, b[k].z, m, r, ga.z, be.z, z, dz); a[k].z = z; b[k].z = dz; s1 += dz; s2 += dz * z;
+        fu_gn_dz(a[k].w, b[k].w, m, r, ga.w, be.w, z, dz); a[k].w = z; b[k].w = dz; s1 += dz; s2 += dz * z;
+    }
+    // the lanes of one group inside the wave: the other pixel rows (lane bits >= LPP) and the group's QP quads (lane bits < QP)
+    const int LPP = F4 < 64 ? F4 : 64;
+    for (int o = 32; o >= LPP; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    for (int o = QP >> 1; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    __syncthreads();
+    if (lane < LPP && (lane % QP) == 0) { wred[0][w][g] = s1; wred[1][w][g] = s2; }
+    __syncthreads();
+    stress_delay(stress, 300u);
+    if (tid < 16) {
+        const int sm = tid >> 3, gg = tid & 7;
+        const float p = ((wred[sm][0][gg] + wred[sm][1][gg]) + (wred[sm][2][gg] + wred[sm][3][gg])) +
+                        ((wred[sm][4][gg] + wred[sm][5][gg]) + (wred[sm][6][gg] + wred[sm][7][gg]));
+        __hip_atomic_store(xch + (((size_t)img * NS + slab) * 8 + gg) * 2 + sm, (1ull << 32) | __builtin_bit_cast(unsigned, p),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    stress_delay(stress, 301u);
+    if (tid < 16 * NS) {
+        const int sm = tid / (8 * NS), sl = (tid >> 3) % NS, gg = tid & 7;
+        const unsigned long long* src = xch + (((size_t)img * NS + sl) * 8 + gg) * 2 + sm;
+        unsigned long long q = 0;
+        int spins = 0;
+        while (true) {
+            q = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(q >> 32) == 1u) break;
+            if (++spins > (1 << 22)) { q = 0x7fc00000ull; break; }               // never a wrong gradient: NaN
+            __builtin_amdgcn_s_sleep(2);
+        }
+        tot[sm][sl][gg] = __builtin_bit_cast(float, (unsigned)q);
+    }
+    __syncthreads();
+    const float n = (float)HW * (float)(C / 8);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < NS; sl += 4) {                     // fixed order: quads of slabs, ascending
+        a1 += (tot[0][sl][g] + tot[0][sl + 1][g]) + (tot[0][sl + 2][g] + tot[0][sl + 3][g]);
+        a2 += (tot[1][sl][g] + tot[1][sl + 1][g]) + (tot[1][sl + 2][g] + tot[1][sl + 3][g]);
+    }
+    a1 /= n; a2 /= n;
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = (tid + 512 * k) / F4;
+        float4 v = make_float4(r * (b[k].x - a1 - a[k].x * a2), r * (b[k].y - a1 - a[k].y * a2), r * (b[k].z - a1 - a[k].z * a2), r * (b[k].w - a1 - a[k].w * a2));
+        float4* o = reinterpret_cast<float4*>(dx + base + (size_t)p * C);
+        if (beta != 0.f) { const float4 e = *o; v.x += beta * e.x; v.y += beta * e.y; v.z += beta * e.z; v.w += beta * e.w; }
+        *o = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (pmax) {
+        if (!(mx <= 3.0e38f)) mx = 3.0e38f;
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) wm[w] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float t = wm[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) t = fmaxf(t, wm[i]);
+            pmax[(size_t)img * NS + slab] = __builtin_bit_cast(unsigned, t);
         }
     }
 }

@@ -117,16 +117,18 @@ def test_guided_chain_fused_equals_loop(device, force):
     assert not torch.equal(fused, plain)
 
 
-@pytest.mark.parametrize("opt", ["h3", "h3_bwd", "gn_bwd_fused"])
-def test_forceunet_fp32_convolution_paths(device, force, opt):
-    """The exact fp32-MFMA convolutions behind set_option("h3", 0) (forward) / ("h3_bwd", 0) (input gradient), and the two-pass
-    GroupNorm derivative behind ("gn_bwd_fused", 0), against the oracle's autograd, and the default path against them."""
+@pytest.mark.parametrize("opt,val", [("h3", 0), ("h3_bwd", 0), ("gn_bwd_fused", 0), ("gn_bwd_fused", 1)])
+def test_forceunet_fp32_convolution_paths(device, force, opt, val):
+    """The exact fp32-MFMA convolutions behind set_option("h3", 0) (forward) / ("h3_bwd", 0) (input gradient), the two-pass
+    GroupNorm derivative behind ("gn_bwd_fused", 0) and its one-workgroup-per-(image, group) form behind ("gn_bwd_fused", 1),
+    against the oracle's autograd, and the default path (split-fp16 convolutions, the derivative on whole pixel rows with the
+    partial sums exchanged between the eight workgroups of an image) against them."""
     m, sd = force
     m32 = cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
     m32.load_state_dict(sd, strict=True)
     m32 = m32.to(device)
-    m32.set_option(opt, 0)
-    assert m32.get_option(opt) == 0 and m.get_option(opt) == 1
+    m32.set_option(opt, val)
+    assert m32.get_option(opt) == val and m.get_option(opt) == (2 if opt == "gn_bwd_fused" else 1)
     x = torch.randn((4, 4, 64, 64), generator=torch.Generator().manual_seed(11))   # even: the 8 x 8 level pairs images per tile
     out32, dx32 = m32.input_grad(x.to(device), lambda_force=2.0)
     out, dx = m.input_grad(x.to(device), lambda_force=2.0)
