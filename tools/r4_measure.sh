@@ -47,7 +47,8 @@ if [ "$what" = bench ] || [ "$what" = all ]; then
 import json
 l = json.load(open("/root/repo/gpurun_out/meas4/r04_bench_default.json"))
 print("roofline", l.get("roofline")); print("cpu_baseline", l.get("cpu_baseline"))
-for w in l.get("workloads", []):
-    print({k: w.get(k) for k in ("workload", "value", "ms_per_step", "rel_err")}, (w.get("roofline") or {}).get("frac"), (w.get("roofline") or {}).get("traffic"))
+for name, w in (l.get("workloads") or {}).items():
+    if isinstance(w, dict):
+        print(name, {k: w.get(k) for k in ("value", "us_per_reverse_step", "rel_err")}, (w.get("roofline") or {}).get("frac"), w.get("hbm_bytes_per_step"), (w.get("cpu_baseline") or {}).get("value"))
 PY
 fi
