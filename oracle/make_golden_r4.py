@@ -6,7 +6,11 @@
 against oracle/cindm_oracle.py::model_predictions_2d.  Every comparison must be <= 2e-6 (it is 0.0); vectors ->
 tests/golden/predict_2d_r4.npz, report -> tests/golden/PINNING_REPORT_R4.json.
 
+``eval_simu`` (utils.py:1127-1148): the reference function itself with its pymunk simulator (not installable here) replaced by a
+deterministic stand-in, against cindm_amd.data_utils.eval_simu given the same stand-in -> tests/golden/eval_simu_r4.npz.
+
     python oracle/make_golden_r4.py          # ~1 min on 8 cores
+    python oracle/make_golden_r4.py eval_simu     # only the eval_simu pin (seconds); merges into the report
 """
 import json
 import os
@@ -37,7 +41,52 @@ def input_for(g, t):
     return torch.randn((2, 21, 64, 64), generator=g) * (1.0 if t > 100 else 1.4)
 
 
+def standin_simulation(features, n_steps, **kw):
+    """Deterministic stand-in for utils.simulation (pymunk): constant velocity with reflecting walls of a 200-wide arena,
+    [batch, n_bodies, 4] -> [batch, n_steps, n_bodies, 4].  Only its signature and shapes matter to eval_simu."""
+    f = features.double()
+    steps = torch.arange(1, n_steps + 1, dtype=torch.float64).view(1, -1, 1, 1)
+    pos = f[:, None, :, :2] + f[:, None, :, 2:] * steps / 60.0
+    pos = 200.0 - (pos.remainder(400.0) - 200.0).abs()
+    vel = f[:, None, :, 2:].expand(-1, n_steps, -1, -1)
+    return torch.cat([pos, vel], dim=-1).float()
+
+
+def design_fn_standin(pred):
+    """A design objective with the signature get_design_fn returns (inference/inverse_design_diffusion_1d.py:211-229)."""
+    return ((pred[:, -1, 0:2] - 0.5) ** 2).sum(-1).sqrt().mean()
+
+
+def eval_simu_pin(report):
+    import importlib
+    ref_import.import_reference()
+    ru = importlib.import_module("cindm.utils")
+    ru.simulation = standin_simulation                               # eval_simu looks `simulation` up in its module's globals
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    worst = 0.0
+    sys.path.insert(0, os.path.dirname(HERE))
+    from cindm_amd.data_utils import eval_simu as mine_fn            # pure tensor code
+    for tag, (B, cs, nb, roll, ti) in {"nb2": (5, 4, 2, 23, 4), "nb4": (3, 1, 4, 10, 2), "nb8": (2, 2, 8, 6, 1)}.items():
+        cond = torch.rand((B, cs, nb * 4), generator=g)
+        ref_pred, ref_obj = ru.eval_simu(cond, design_fn_standin, nb, roll, time_interval=ti)
+        my_pred, my_obj = mine_fn(cond, design_fn_standin, nb, roll, time_interval=ti, simulation=standin_simulation)
+        worst = max(worst, relerr(my_pred, ref_pred), abs(float(my_obj) - float(ref_obj)))
+        out[f"{tag}.cond"] = cond.numpy(); out[f"{tag}.pred"] = ref_pred.numpy(); out[f"{tag}.obj"] = np.float32(float(ref_obj))
+        out[f"{tag}.args"] = np.array([nb, roll, ti])
+    np.savez_compressed(os.path.join(GOLD, "eval_simu_r4.npz"), **out)
+    report["eval_simu"] = worst
+    print("eval_simu", worst, flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "eval_simu":
+        path = os.path.join(GOLD, "PINNING_REPORT_R4.json")
+        report = json.load(open(path))
+        eval_simu_pin(report)
+        json.dump(report, open(path, "w"), indent=1)
+        assert report["eval_simu"] <= 2e-6, report["eval_simu"]
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     d1, d2 = ref_import.import_reference()
@@ -70,6 +119,7 @@ def main():
         report["predict2d." + tag] = worst
         print("predict2d", tag, worst, time.time() - t0, flush=True)
     np.savez_compressed(os.path.join(GOLD, "predict_2d_r4.npz"), **out)
+    eval_simu_pin(report)
     report["seconds"] = time.time() - t0
     with open(os.path.join(GOLD, "PINNING_REPORT_R4.json"), "w") as f:
         json.dump(report, f, indent=1)

@@ -301,6 +301,38 @@ def test_get_item_1d_golden(gold_dir):
     assert torch.allclose(to_simulator_units(out, 4), y, rtol=0, atol=2e-5)
 
 
+def _standin_simulation(features, n_steps, **kw):
+    """The deterministic stand-in oracle/make_golden_r4.py put in place of utils.simulation (pymunk is not installable here):
+    constant velocity with reflecting walls, [batch, n_bodies, 4] -> [batch, n_steps, n_bodies, 4]."""
+    f = features.double()
+    steps = torch.arange(1, n_steps + 1, dtype=torch.float64).view(1, -1, 1, 1)
+    pos = f[:, None, :, :2] + f[:, None, :, 2:] * steps / 60.0
+    pos = 200.0 - (pos.remainder(400.0) - 200.0).abs()
+    vel = f[:, None, :, 2:].expand(-1, n_steps, -1, -1)
+    return torch.cat([pos, vel], dim=-1).float()
+
+
+def test_eval_simu_golden(gold_dir):
+    """cindm_amd.data_utils.eval_simu against the reference's own eval_simu (utils.py:1127-1148) run in the build container with
+    the same stand-in simulator: units, layout, sub-sampling by time_interval and the objective call, bit for bit; and the
+    loud failure when no simulator is available."""
+    from cindm_amd.data_utils import eval_simu
+    g = np.load(os.path.join(gold_dir, "eval_simu_r4.npz"))
+
+    def design_fn(pred):
+        return ((pred[:, -1, 0:2] - 0.5) ** 2).sum(-1).sqrt().mean()
+
+    for tag in ("nb2", "nb4", "nb8"):
+        nb, roll, ti = (int(v) for v in g[f"{tag}.args"])
+        cond = torch.from_numpy(g[f"{tag}.cond"])
+        pred, obj = eval_simu(cond, design_fn, nb, roll, time_interval=ti, simulation=_standin_simulation)
+        assert pred.shape == (cond.shape[0], roll, nb * 4)
+        assert torch.equal(pred, torch.from_numpy(g[f"{tag}.pred"])), tag
+        assert float(obj) == float(g[f"{tag}.obj"]), tag
+    with pytest.raises(RuntimeError, match="pymunk"):
+        eval_simu(torch.zeros((1, 1, 8)), design_fn, 2, 3)
+
+
 def test_get_item_1d_matches_reference_formula():
     """The layout in words: sample b, step s, body k, feature f of the diffusion tensor is field[b * n_bodies + k, s, f] / 200,
     and to_simulator_units inverts it."""

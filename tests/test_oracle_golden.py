@@ -426,3 +426,4 @@ def test_pinning_report_round4(gold_dir):
         rep = json.load(f)
     for tag in PREDICT_2D:
         assert rep["predict2d." + tag] <= 2e-6, (tag, rep)
+    assert rep["eval_simu"] <= 2e-6, rep                     # the glue of utils.eval_simu around a stand-in simulator
