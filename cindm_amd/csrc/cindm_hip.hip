@@ -2151,7 +2151,10 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     a.noise = io.noise; a.noise_t_stride = io.noise_t_stride; a.seed = io.seed; a.sample_off = io.sample_off; a.add_noise = io.add_noise;
     a.dyn = io.dyn;
     a.inp_cond = io.inp_cond; a.inp_steps = io.inp_steps; a.inp_noise = io.inp_noise; a.inp_noise_t_stride = io.inp_noise_t_stride;
-    if (io.ddim_tab) { a.ddim_tab = io.ddim_tab; a.ddim_tnext = io.ddim_tnext; a.step_idx = h->t_dev + 2; }
+    if (io.ddim_tab) {
+        a.ddim_tab = io.ddim_tab; a.ddim_tnext = io.ddim_tnext; a.step_idx = h->t_dev + 2;
+        if (io.pingpong) { a.step_idx = h->t_dev + 4 * q + 2; a.sidx_next = h->t_dev + 4 * (1 - q) + 2; }      // the slot's own step index
+    }
     const bool guided = io.dz && io.x_out;
     if (guided) {
         a.dz_mode = io.dz->mode; a.dz_alpha = io.dz->alpha; a.dz_last_n = io.dz->last_n_step; a.dz_coef = io.dz->coef;
@@ -2172,11 +2175,11 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     // A plain single-model step (configs 1 and 2: the U-Net reads the state, its output row IS the row's prediction, the
     // update is element-wise and in place): ups_last_kernel runs the update on the rows it has just predicted, so the step
     // has no compose_update_kernel launch.  Everything else (composition over windows / pairs, a second U-Net, guidance,
-    // DDIM, callers that want mean / x0 / eps back) keeps the separate kernel.
+    // callers that want mean / x0 / eps back) keeps the separate kernel.  Round 4: the DDIM loop fuses too (objective pred_noise).
     // sample() reaches this path as COMPOSE_MEAN_OUTSIDE with one window and one pair (p_sample_loop -> outside=True): for
     // s.direct every mode 0..4 aggregates exactly one prediction with weight 1 -- (0 + e) / 1 -- so the element-wise result is
     // the plain one (the bitwise identities outside(mean) == inside == plain are GPU tests) and all of them fuse.
-    const bool can_fuse = c->mode >= CINDM_COMPOSE_PLAIN && c->mode <= 4 && s.direct && !s.single_rows && !guided && !io.ddim_tab &&
+    const bool can_fuse = c->mode >= CINDM_COMPOSE_PLAIN && c->mode <= 4 && s.direct && !s.single_rows && !guided && (!io.ddim_tab || c->objective == 0) &&
                           io.x_out == io.x && !io.mean_out && !io.x0_out && !io.eps_out && !io.inp_cond && pair->O("fuse_update") &&
                           (a.F & 3) == 0;
     pair->fused_done = false;
@@ -2429,15 +2432,20 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
     io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
     io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
+    // (round 4) as in the DDPM loop the step state -- t, the step index, the epochs -- lives in two slots advanced by the step's own
+    // update: no step_counter_kernel launch, and a plain single-model step runs its update inside the last U-Net kernel
+    const bool pp = pair->O("pingpong") != 0;
+    io.pingpong = pp ? 1 : 0;
     cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
     return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
         if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
         start_loop(h, pair, uncond, c, (int)times[0], stream, seed, sample_offset);
         KeyBuilder K;
         key_common(K, 1, pair, uncond, c, io, B, ws, ws_bytes);
+        K(pp);
         return replay_steps(h, K.k, stream, n_steps, use_graph,
-                            [&](int) { return run_step(h, pair, uncond, c, io, 0, h->t_dev, B, ws, ws_bytes, stream); },
-                            pair, un);
+                            [&](int q) { StepIO it = io; it.parity = q; return run_step(h, pair, uncond, c, it, 0, h->t_dev, B, ws, ws_bytes, stream); },
+                            pair, un, pp);
     });
 }
 

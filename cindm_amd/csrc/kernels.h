@@ -2342,6 +2342,7 @@ struct ComposeArgs {
     // DDIM (ddim_sample :1724-1804): per-step (sqrt(alpha_next), c, sigma, -) and time_next tables indexed by the
     // device step index; noise tapes are then indexed by the step index instead of t
     const float* ddim_tab; const int* ddim_tnext; int* step_idx;
+    int* sidx_next;                     // ping-pong DDIM loop: the other slot's step index (written with t_next by the step's update)
     // built-in design objective (the paper's point objective, inference/inverse_design_diffusion_1d.py:211-229) with
     // "standard" / "standard-alpha" (-recurrence-N) guidance: pred = mean - [eta_t] * grad_x objective(x)
     int dz_mode;                 // 0 off, 1 "L2", 2 "L2square"
@@ -2360,7 +2361,8 @@ struct ComposeArgs {
 };
 __device__ __forceinline__ void compose_advance(const ComposeArgs& a, int t) {
     if (!a.t_next) return;
-    a.t_next[0] = t - 1;
+    if (a.ddim_tab) { const int sidx = a.step_idx[0]; a.t_next[0] = max(a.ddim_tnext[sidx], 0); a.sidx_next[0] = sidx + 1; }   // (step_counter_kernel's rule)
+    else a.t_next[0] = t - 1;
     if (a.ep_next0) a.ep_next0[0] = a.ep_cur0[0] + 1;
     if (a.ep_next1) a.ep_next1[0] = a.ep_cur1[0] + 1;
 }
@@ -2373,7 +2375,7 @@ __device__ __forceinline__ void counter_normal4(uint64_t seed, uint64_t sample, 
 // ups_last_kernel evaluated plain_step_value eight times per lane and every evaluation re-read its table entries under the
 // objective's branches -- ~30 load -> vmcnt(0) -> use sequences at the very end of the step's LAST kernel (the in-replay phase
 // clocks showed 5 us for the waves that run the update: the tail of every reverse step).
-struct StepCoefs { float cx, co, k1, k2, sigma; };
+struct StepCoefs { float cx, co, k1, k2, sigma; float san, cc, sg; int tn, sidx; };     // (san, cc, sg, tn, sidx: the DDIM step's table row)
 typedef const float __attribute__((address_space(4))) cindm_cfloat4;
 __device__ __forceinline__ float uniform_float(const float* p) { return *(cindm_cfloat4*)(const void*)p; }
 __device__ __forceinline__ StepCoefs plain_step_coefs(const ComposeArgs& a, int t) {
@@ -2382,12 +2384,28 @@ __device__ __forceinline__ StepCoefs plain_step_coefs(const ComposeArgs& a, int 
     else { c.cx = uniform_float(a.sqrt_recip + t); c.co = uniform_float(a.sqrt_recipm1 + t); }
     c.k1 = uniform_float(a.coef1 + t); c.k2 = uniform_float(a.coef2 + t);
     c.sigma = (a.add_noise && t > 0) ? expf(0.5f * uniform_float(a.logvar + t)) : 0.f;
+    c.san = c.cc = c.sg = 0.f; c.tn = -1; c.sidx = 0;
+    if (a.ddim_tab) {
+        c.sidx = uniform_word(a.step_idx);
+        c.tn = uniform_word(a.ddim_tnext + c.sidx);
+        c.san = uniform_float(a.ddim_tab + 4 * c.sidx); c.cc = uniform_float(a.ddim_tab + 4 * c.sidx + 1); c.sg = uniform_float(a.ddim_tab + 4 * c.sidx + 2);
+    }
     return c;
+}
+// does the fused update of this step draw noise?  (compose_update_element's conditions: DDPM t > 0; DDIM a next time and sigma != 0
+// -- or an explicit tape, which is read whenever there is a next time)
+__device__ __forceinline__ bool plain_step_draws(const ComposeArgs& a, const StepCoefs& c, int t) {
+    if (a.ddim_tab) return c.tn >= 0 && (a.noise != nullptr || c.sg != 0.f);
+    return a.add_noise && t > 0;
 }
 // plain_step_value with the coefficients in hand: operation for operation the same expression
 __device__ __forceinline__ float plain_step_value(const ComposeArgs& a, const StepCoefs& c, int t, float xv, float o, float z) {
     float x0 = (a.objective == 1) ? o : __fsub_rn(__fmul_rn(c.cx, xv), __fmul_rn(c.co, o));
     if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    if (a.ddim_tab) {       // compose_update_element's DDIM tail (objective pred_noise: eps = o; the host fuses only that objective)
+        if (c.tn < 0) return x0;
+        return __fadd_rn(__fadd_rn(__fmul_rn(x0, c.san), __fmul_rn(c.cc, o)), __fmul_rn(c.sg, z));
+    }
     float v = __fadd_rn(__fmul_rn(c.k1, x0), __fmul_rn(c.k2, xv));
     if (a.add_noise && t > 0) v += c.sigma * z;
     return v;
@@ -2479,13 +2497,16 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     // wave w takes slots 32 w ..), parked in R -- free until block 1's output goes there -- and picked up by wave 0 after barrier 4.
     // At the kernel's tail (one wave, after the last barrier) Philox + Box-Muller were 2.5 us of a 3 us phase (phase clocks, round 4).
     const int tu_z = a.fuse_upd ? step_scalar(a.upd.t_ptr, a.upd.t_imm) : 0;
-    const bool gen_z = a.fuse_upd && a.upd.add_noise && tu_z > 0;
+    StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};      // the step's schedule values (scalar loads; DDIM: its table row)
+    if (a.fuse_upd) sc = plain_step_coefs(a.upd, tu_z);
+    const bool gen_z = a.fuse_upd && plain_step_draws(a.upd, sc, tu_z);
     if (gen_z && lane < 32) {
         const ComposeArgs& u = a.upd;
         const int s = 32 * w + lane, nt = s >> 6, ln = s & 63, n = nt * 16 + (ln & 15), q4 = (ln >> 4) * 4;
         if (n < L2 && q4 < a.F) {
             float4 z;
-            if (u.noise) z = *reinterpret_cast<const float4*>(u.noise + (size_t)tu_z * u.noise_t_stride + ((size_t)b * L2 + n) * a.F + q4);
+            // (explicit tapes are indexed by t in the DDPM loop and by the step index in the DDIM loop)
+            if (u.noise) z = *reinterpret_cast<const float4*>(u.noise + (size_t)(u.ddim_tab ? sc.sidx : tu_z) * u.noise_t_stride + ((size_t)b * L2 + n) * a.F + q4);
             else {
                 const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
                 const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
@@ -2706,8 +2727,6 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     PH(10);
     // ---- final Conv1dBlock(64 -> 64, k5) and Conv1d(64 -> F, 1) ----
     float4 xq[2] = {};                                                   // (wave 0) x_t of the elements it will update: a layer ahead
-    StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f};                            // ... and the step's schedule values (scalar loads)
-    if (a.fuse_upd) sc = plain_step_coefs(a.upd, tu_z);
     if (w == 0 && a.fuse_upd) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
