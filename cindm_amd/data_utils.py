@@ -9,7 +9,7 @@ inference/inverse_design_diffusion_1d.py:286-300).  Pure tensor reshapes: host o
 ``eval_simu`` mirrors utils.py:1127-1148 around an injectable ``simulation`` callable: the reference's own simulator
 (utils.py:1076-1124) is a pymunk / pygame program and neither package is installed in this image, so the simulator itself stays out
 of reach -- everything eval_simu does AROUND it (units, layout, sub-sampling, the objective) is here and pinned against the reference
-function run with the same stand-in simulator (oracle/make_golden_r4.py, tests/golden/eval_simu_r4.npz)."""
+function run with the same stand-in simulator (tests/golden/eval_simu_r4.npz and the script that made it)."""
 import torch
 
 NBODY_SCALE = 200.0
