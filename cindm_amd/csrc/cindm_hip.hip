@@ -59,6 +59,7 @@ struct RtbDesc { std::string p; int cin, cout; int tb_off; };
 struct cindm_unet1d {
     const cindm::ComposeArgs* fuse_upd = nullptr;   // set by run_step around one forward: ups_last_kernel also runs this update
     bool fused_done = false;                          // ... and reports here that it did
+    int gatherB = 0, gather_cs = 0, gather_Ltot = 0;  // set by run_step around one forward: x is the sampler's state, level0_down_kernel reads its windows in place
     cindm_unet1d_desc d;
     std::vector<Param> params;
     std::unordered_map<std::string, int> index;
@@ -197,6 +198,7 @@ static const OptDef kUnet1dOpts[] = {
     {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
     {"dconv2", 1, "CINDM_DCONV2"},     // a whole deep-level ResidualTemporalBlock per launch (dconv2_kernel: in-launch all-gather between its convolutions)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
+    {"fuse_gather", 1, nullptr},       // time composition of two-body states: level0_down_kernel reads the state's windows in place (no compose_gather_kernel launch)
     {"fuse_update", 1, "CINDM_FUSE_UPDATE"},   // plain single-model steps: the reverse-step update inside ups_last_kernel (no update launch)
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
     {"no_exchange", 0, "CINDM_NO_EXCHANGE"},   // 1: only kernels without an in-launch exchange between workgroups (run-time option: does not un-finalize)
@@ -1327,6 +1329,14 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
     return out;
 }
 
+// does level0_down_kernel consume the forward's INPUT tensor?  (emit_forward's condition for its first level; run_step asks before
+// it decides to let that kernel read the sampler's state in place instead of launching compose_gather_kernel)
+static bool level0_serves_input(const cindm_unet1d* h) {
+    const int L = h->d.horizon;
+    return h->level0_ok && h->d.attention != 0 && L <= 32 && (L & 1) == 0 && h->packed.count("downs.0.2.fn.fn.to_qkv#site") &&
+           h->packed.at("downs.0.2.fn.fn.to_qkv#site").h3;
+}
+
 static int emit_forward(Emitter& E, const float* x, float* eps) {
     const bool taps = E.h->O("taps") != 0;      // tap-only block outputs of the level kernels (tests); off on the sampling path
     cindm_unet1d* h = E.h;
@@ -1367,6 +1377,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 std::memset(&l, 0, sizeof(l));
                 l.pf = pfl;
                 l.x = cur.p; l.F = cur.C; l.h1 = taps ? h1.p : nullptr; l.h2 = taps ? h2.p : nullptr; l.skip = sk.p; l.down = dn.p;
+                l.gB = h->gatherB; l.gcs = h->gather_cs; l.gLtot = h->gather_Ltot;
                 const char* cv[4] = {"downs.0.0.blocks.0", "downs.0.0.blocks.1", "downs.0.1.blocks.0", "downs.0.1.blocks.1"};
                 for (int i = 0; i < 4; ++i) {
                     const std::string cp = cv[i];
@@ -2166,7 +2177,14 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     }
 
     const float* unet_in = io.x;
-    if (!s.direct) {
+    // Time composition of two-body states (config 3: W windows of one pair): the gathered batch is a row-wise COPY of the state --
+    // row (window kk, design b) = state[b, kk * cs .. + Tw) -- so the first kernel of the forward reads the state in place and
+    // compose_gather_kernel is not launched (option fuse_gather; level0_down_kernel must be the kernel that consumes the input)
+    const bool gather_fused = !s.direct && c->mode >= 1 && c->mode <= 4 && c->n_bodies == 2 && c->cond_steps == 0 && !s.single_rows &&
+                              pair->O("fuse_gather") && level0_serves_input(pair) && pair->d.horizon == s.Tw && pair->d.transition_dim == 8;
+    pair->gatherB = 0;
+    if (gather_fused) { pair->gatherB = (int)B; pair->gather_cs = c->compose_start_step; pair->gather_Ltot = Ltot; }
+    else if (!s.direct) {
         const int64_t n = (c->mode == CINDM_COMPOSE_PLAIN) ? B * (int64_t)s.Lfull * a.F
                           : s.pair_rows * s.Tw * 8 + s.single_rows * s.Tw * 4;
         hipLaunchKernelGGL(compose_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
@@ -2187,12 +2205,13 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
     const int frc = cindm_unet1d_forward(pair, unet_in, t, t_dev, (float*)(w + s.off_pair_eps), s.pair_rows, w + s.off_ws_pair,
                                          ws_bytes - s.off_ws_pair, stream);
     pair->fuse_upd = nullptr;
+    pair->gatherB = 0;
     if (frc != 0) return -1;
     if (s.single_rows &&
         cindm_unet1d_forward(uncond, a.single_in, t, t_dev, (float*)(w + s.off_single_eps), s.single_rows,
                              w + s.off_ws_single, ws_bytes - s.off_ws_single, stream) != 0) return -1;
     const int64_t ne = B * (int64_t)Ltot * a.F;
-    h->last_step_launches = (s.direct ? 0 : 1) + pair->launches + (s.single_rows ? uncond->launches : 0) + (pair->fused_done ? 0 : 1) +
+    h->last_step_launches = ((s.direct || gather_fused) ? 0 : 1) + pair->launches + (s.single_rows ? uncond->launches : 0) + (pair->fused_done ? 0 : 1) +
                             ((io.dec_t && !io.pingpong) ? 1 : 0);
     h->last_step_fused = pair->fused_done ? 1 : 0;
     if (!pair->fused_done) hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);

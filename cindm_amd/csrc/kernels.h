@@ -1573,6 +1573,9 @@ struct Level0Args {
     const int* t_ptr; int t_imm;
     int L;
     Pf pf; PhaseBuf ph;                                 // L2 warm-up for the next launch
+    // gB > 0: x is the sampler's STATE [gB, gLtot, F] and row r of this launch is window r / gB of design r % gB, positions
+    // (r / gB) * gcs .. + L - 1 (the time composition of two-body states: compose_gather_kernel's copy, read in place)
+    int gB, gcs, gLtot;
 };
 
 // one 16-channel x (NT*16)-position tile of a k-tap convolution: A = this wave's weight fragments [tap][k32][plane],
@@ -1690,7 +1693,8 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     // load: a full round trip from memory, and only then were the weights requested -- a second one) ----
     const int xr = tid >> 3, xc4 = tid & 7;                              // 32 rows x 8 float4
     const bool xok = xr < L && 4 * xc4 < a.F;
-    const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)b * L + (xok ? xr : 0)) * a.F + (xok ? 4 * xc4 : 0));
+    const size_t xrow0 = a.gB ? (size_t)(b % a.gB) * a.gLtot + (size_t)(b / a.gB) * a.gcs : (size_t)b * L;
+    const float4 xv = *reinterpret_cast<const float4*>(a.x + (xrow0 + (xok ? xr : 0)) * a.F + (xok ? 4 * xc4 : 0));
     const float4* Wc0 = reinterpret_cast<const float4*>(a.Wc[0]) + (size_t)w * (5 * 1 * 2 * 64);
     const float4* Wc1 = reinterpret_cast<const float4*>(a.Wc[1]) + (size_t)w * (5 * 2 * 2 * 64);
     const float4* Wc2 = reinterpret_cast<const float4*>(a.Wc[2]) + (size_t)w * (5 * 2 * 2 * 64);
