@@ -581,3 +581,55 @@ def test_phase_clock_build(device, tmp_path):
     env = dict(os.environ, CINDM_LIB_VARIANT="prof")
     r = subprocess.run([sys.executable, "-c", _PROF_CHILD, os.path.dirname(here), str(ref)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PROF_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("mode", ["mean-inside", "sum-inside", "mean", "noise_sum"])
+def test_gather_read_in_place(device, unet8, mode):
+    """Time composition of two-body states: the gathered U-Net batch is a row-wise copy of the state's windows, so level0_down_kernel
+    reads them in place and compose_gather_kernel is not launched (option fuse_gather): one launch fewer per step, bit-identical
+    designs (three windows -> 56 steps, counter noise and an explicit tape, graph and stream)."""
+    m, _ = unet8
+    d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device)
+    tape = _tape(9, (5, 56, 8), 1000)
+    kw = dict(n_composed=2, compose_start_step=16, compose_n_bodies=2, compose_mode=mode, t_stop=992)
+    res, info = {}, {}
+    try:
+        for v in (0, 1):
+            m.set_option("fuse_gather", v)
+            res[v] = (d.sample(batch_size=5, seed=23, sample_offset=1, **kw), d.sample(batch_size=5, noise=tape, **kw),
+                      d.sample(batch_size=5, seed=23, sample_offset=1, use_graph=False, **kw))
+            info[v] = d.last_step_info()
+    finally:
+        m.set_option("fuse_gather", 1)
+    assert info[1][0] == info[0][0] - 1, info
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[1][0], res[1][2])
+
+
+def test_ddim_loop_fuses_and_pingpongs(device, unet8):
+    """The DDIM loop (round 4) keeps its step state in two slots and runs the update of a plain single-model step inside
+    ups_last_kernel, as the DDPM loop does: 20 launches per step instead of 22, bit-identical to the separate update kernel and to
+    the counter-kernel loop -- eta = 0 and eta > 0, counter noise and an explicit tape, an odd and an even number of steps."""
+    m, _ = unet8
+    out, info = {}, {}
+    try:
+        for eta in (0.0, 0.5):
+            d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=50,
+                                              ddim_sampling_eta=eta).to(device)
+            tape = _tape(4, (6, 24, 8), 50)
+            for fu, pp in ((1, 1), (0, 1), (1, 0), (0, 0)):
+                m.set_option("fuse_update", fu); m.set_option("pingpong", pp)
+                z = torch.zeros((6, 24, 8), device=device)
+                out[eta, fu, pp] = (d.ddim_sample((6, 24, 8), None, seed=5, step_range=(0, 7), init_img=z),
+                                    d.ddim_sample((6, 24, 8), None, noise=tape, step_range=(0, 8), init_img=z),
+                                    d.ddim_sample((6, 24, 8), None, seed=5, step_range=(43, 50), init_img=z + 0.3))     # incl. the last step (x_start)
+                info[eta, fu, pp] = d.last_step_info()
+    finally:
+        m.set_option("fuse_update", 1); m.set_option("pingpong", 1)
+    for eta in (0.0, 0.5):
+        assert info[eta, 1, 1][1] is True and info[eta, 0, 0][1] is False, info
+        assert info[eta, 1, 1][0] == info[eta, 0, 0][0] - 2, info
+        for key in ((eta, 0, 1), (eta, 1, 0), (eta, 0, 0)):
+            for a, b in zip(out[eta, 1, 1], out[key]):
+                assert torch.equal(a, b), key
