@@ -94,13 +94,19 @@ __global__ __launch_bounds__(256) void fu_conv_kernel(const FuConvArgs a) {
             const int dy = tap / KS, dx = tap - dy * KS;
             const float* ap = &As[((py + dy) * TW + px + dx) * CKP + (lane >> 4)];
             const float* wp = a.W + ((((size_t)tap * kcs + c0 / 4) * nq_total + ntq) * 64 + lane) * NB;
+            // (round 4) the tap's four weight quads are requested together: one by one, each sat in front of its own MFMAs
+            float4 bq[CK / 4];
+            if constexpr (NB == 4) {
+#pragma unroll
+                for (int kk = 0; kk < CK / 4; ++kk) bq[kk] = *reinterpret_cast<const float4*>(wp + (size_t)kk * nq_total * 64 * NB);
+            }
 #pragma unroll
             for (int kk = 0; kk < CK / 4; ++kk) {
                 if (KS == 7 && NB == 4 && kk >= nk) break;   // the stem forward: 4 of the 16 staged channels exist (the rest multiply packed zeros)
                 const float av = ap[kk * 4];
                 const float* wk = wp + (size_t)kk * nq_total * 64 * NB;
                 if constexpr (NB == 4) {
-                    const float4 b = *reinterpret_cast<const float4*>(wk);
+                    const float4 b = bq[kk];
                     acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.x, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.y, acc[1], 0, 0, 0);
                     acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b.z, acc[2], 0, 0, 0);
