@@ -87,7 +87,10 @@ int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
  * "wide_qkv", "level0", "level1", "ups_last", "ups_tail", "h3_resample", "site_pack", "dconv", "dconv_pair",
  * "attn_head", "l2_prefetch", "auto_range" (1 = a checkpoint whose conv / projection weights leave the split-fp16 window
  * 2^-12 <= max|w| <= 2^15 runs on the fp32 kernels; "range_fallback" then reads 1), "fuse_update" (plain single-model
- * steps apply the DDPM update inside the last U-Net kernel), "taps" (1 = block outputs that live
+ * steps -- DDPM and DDIM loops -- apply the update inside the last U-Net kernel), "fuse_gather" (time composition of two-body
+ * states: the first U-Net kernel reads the state's windows in place, no gather launch), "dconv2", "dresample", "pingpong" (the
+ * sample loops keep t / step index / epochs in two slots advanced by the step's update), "ws_alias", "level_occ2" (bits: which
+ * level kernels run two workgroups per CU above 320 rows), "stress", "taps" (1 = block outputs that live
  * only inside a level kernel are also stored for cindm_unet1d_tap; off on the sampling path),
  * "dbg"/"dbg3"/"dbg4" (timing ablations, wrong results).  No reference counterpart (PyTorch picks its own kernels). */
 int  cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value);
