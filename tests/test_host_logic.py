@@ -473,3 +473,23 @@ def test_bench_cpu_leg_takes_the_best_of_three_repetitions():
     delays = iter([0.03] * 4 + [0.01] * 100)
     dt, n, per = bench.timed_cpu_steps(lambda k: _t.sleep(next(delays)), budget_s=0.3, reps=3, max_steps=60)
     assert len(per) == 3 and abs(dt - min(per) / 1e3) < 2e-3 and dt < 0.02 and n >= 6
+
+
+def test_isa_audit_counts_exposed_loads(tmp_path):
+    """tools/isa_audit.py on a hand-written ISA fragment: a load waited for at once is an immediate-wait load, a
+    load covered by many MFMAs is not, vmcnt(N) leaves the N youngest operations in flight, stores are tracked but not ranked."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    ia = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ia)
+    body = ["global_load_dwordx4 v[0:3], v[8:9], off", "s_waitcnt vmcnt(0)",                       # immediate
+            "global_load_dwordx4 v[4:7], v[8:9], off", "global_load_dwordx4 v[12:15], v[8:9], off"]
+    body += ["v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]"] * 40
+    body += ["s_waitcnt vmcnt(1)",                                                                # waits for v[4:7]: 40 MFMAs of cover
+             "global_store_dwordx4 v[8:9], v[0:3], off", "s_waitcnt vmcnt(0)", "s_endpgm"]
+    w = list(ia.waits(body))
+    assert [(x[2], x[3], x[5]) for x in w] == [(0, 0, 'L'), (1, 40, 'L'), (0, 0, 'S')]
+    asm = tmp_path / "k.s"
+    asm.write_text("_ZN5cindm6kernelEv:\n" + "\n".join("\t" + l for l in body) + "\n")
+    names = [n for n, _ in ia.kernels(asm.read_text().split("\n"))]
+    assert names == ["_ZN5cindm6kernelEv"]
