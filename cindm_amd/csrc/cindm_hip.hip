@@ -59,6 +59,8 @@ struct RtbDesc { std::string p; int cin, cout; int tb_off; };
 struct cindm_unet1d {
     const cindm::ComposeArgs* fuse_upd = nullptr;   // set by run_step around one forward: ups_last_kernel also runs this update
     bool fused_done = false;                          // ... and reports here that it did
+    int issued = 0;                                   // kernels the last cindm_unet1d_forward actually launched (the plan's `launches` counts the epoch
+                                                      // launch of a bare forward, which a sample loop's step does not issue: its predecessor advanced the epoch)
     int gatherB = 0, gather_cs = 0, gather_Ltot = 0;  // set by run_step around one forward: x is the sampler's state, level0_down_kernel reads its windows in place
     cindm_unet1d_desc d;
     std::vector<Param> params;
@@ -1190,6 +1192,7 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
             s.L = L; s.Bp = Bp;
             s.dbg = h->O("dbg3");
+            s.ph = site->second.h3 ? E.ph_next("attn1d_site<" + std::to_string(C) + "> " + p) : PhaseBuf{nullptr, 0};
             // samples per workgroup: as many 4-aligned slots as fit one 16-position tile (weights are streamed once
             // per workgroup); CINDM_SITE_PACK=0 keeps one sample per workgroup
             const int pack = h->O("site_pack");
@@ -1881,6 +1884,7 @@ extern "C" int cindm_unet1d_forward(cindm_unet1d* h, const float* x, int32_t t, 
     if (unet1d_prepare_ws(h, ws, rows, (hipStream_t)stream) != 0) return -1;
     Emitter E{h, (hipStream_t)stream, false, (char*)ws, 0, rows, t_dev, t};
     emit_forward(E, x, eps);
+    h->issued = E.launches;
     if (E.err != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(E.err));
     return 0;
 }
@@ -2211,7 +2215,7 @@ static int run_step(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, c
         cindm_unet1d_forward(uncond, a.single_in, t, t_dev, (float*)(w + s.off_single_eps), s.single_rows,
                              w + s.off_ws_single, ws_bytes - s.off_ws_single, stream) != 0) return -1;
     const int64_t ne = B * (int64_t)Ltot * a.F;
-    h->last_step_launches = ((s.direct || gather_fused) ? 0 : 1) + pair->launches + (s.single_rows ? uncond->launches : 0) + (pair->fused_done ? 0 : 1) +
+    h->last_step_launches = ((s.direct || gather_fused) ? 0 : 1) + pair->issued + (s.single_rows ? uncond->issued : 0) + (pair->fused_done ? 0 : 1) +
                             ((io.dec_t && !io.pingpong) ? 1 : 0);
     h->last_step_fused = pair->fused_done ? 1 : 0;
     if (!pair->fused_done) hipLaunchKernelGGL(compose_update_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream, a);

@@ -1035,6 +1035,7 @@ struct AttnSiteArgs {
     int Bp;                // samples in the batch
     int dbg;               // timing ablations (wrong results): 1 no qkv loop, 2 no projection, 3 no core
     Pf pf;                 // L2 warm-up for the next launch
+    PhaseBuf ph;           // phase clocks (profiling builds)
 };
 
 // Core of a site for the head of this wave, per sample s of the workgroup: q *= 32^-1/2 ; k = softmax over the sample's
@@ -1302,6 +1303,8 @@ __global__ __launch_bounds__(256) void attn1d_site_kernel(const AttnSiteArgs a) 
 // k = k32*32 + (lane/16)*8 + e.
 template <int C, int NT, int PF>
 __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs a) {
+    PH_DECL;
+    PH(0);        // phase clocks (profiling builds): 0 entry, 1 LayerNorm -> planes, 2 q | k | v + core + att planes, 3 out projection + stores
     constexpr int NP = NT * 16, K32 = C / 32, CT = C / 16;
     constexpr int YPB = 2 * C + 16;                      // bytes per position per plane (pad keeps b128 reads conflict-free)
     constexpr int APB = 2 * 128 + 16;
@@ -1392,6 +1395,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
         }
     }
     __syncthreads();
+    PH(1);
 
     // ---- q, k, v of head w: main and low-order accumulators ----
     f32x4 qM[2][NT], qL[2][NT], kM[NT][2], kL[NT][2], vM[NT][2], vL[NT][2];
@@ -1488,6 +1492,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             *reinterpret_cast<half4v*>(&Ap[1][off]) = lo;
         }
     __syncthreads();
+    PH(2);
 
     // ---- out = Wo att + bo + x ----
     // the epilogue's bias and residual rows of tile t + 1 are requested before tile t's MFMAs (round 4: loaded where they were
@@ -1549,7 +1554,9 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             }
         }
     }
+    PH(3);
     l2_prefetch_done(a.pf, pfr);
+    PH_FLUSH(a.ph);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -609,7 +609,7 @@ def test_gather_read_in_place(device, unet8, mode):
 
 def test_ddim_loop_fuses_and_pingpongs(device, unet8):
     """The DDIM loop (round 4) keeps its step state in two slots and runs the update of a plain single-model step inside
-    ups_last_kernel, as the DDPM loop does: 20 launches per step instead of 22, bit-identical to the separate update kernel and to
+    ups_last_kernel, as the DDPM loop does: 19 launches per step instead of 21, bit-identical to the separate update kernel and to
     the counter-kernel loop -- eta = 0 and eta > 0, counter noise and an explicit tape, an odd and an even number of steps."""
     m, _ = unet8
     out, info = {}, {}

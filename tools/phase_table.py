@@ -37,6 +37,7 @@ PHASES = {
     "dresample": ["entry", "loads issued", "K loop", "cross-wave reduce", "planes + stores issued"],
     "attn1d_head": ["entry", "weight loads issued", "LayerNorm -> planes", "q|k|v K share (MFMA)", "cross-wave sum", "core",
                     "tile published", "four heads gathered (spin)", "att planes in LDS", "out projection + stores issued"],
+    "attn1d_site": ["entry", "rows + weights requested, LayerNorm -> planes", "q|k|v + core + att planes", "out projection + stores issued"],
     "level0_down": ["entry", "stage x + zero fill", "b0.conv0 + residual_conv", "b0.conv1", "b1.conv0", "b1.conv1 -> h2", "LayerNorm",
                     "q|k|v + core", "out projection", "downsample + stores"],
     "level1_down": ["entry", "zero fill", "stage x", "b0.conv0 + residual_conv", "b0.conv1", "b1.conv0", "b1.conv1 -> h2", "LayerNorm",
