@@ -113,6 +113,19 @@ def spawn_ranks_if_needed(args):
     sys.exit(subprocess.run(cmd).returncode)
 
 
+def rank_device():
+    """(device of this rank, process-group backend, shared).  One GPU per rank over RCCL ("nccl") is the contract; when the box
+    has FEWER GPUs than ranks (the one-GPU test boxes) the ranks share devices round-robin and rendezvous over gloo, so that the
+    N-rank code path -- spawn, barrier, max-over-ranks, one gathered result, rank 0's line -- can be executed end to end.  Such a line
+    says so ("shared_gpus") and is not a benchmark: the ranks time-share a device."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    shared = world > 1 and ndev < world
+    idx = local_rank % max(ndev, 1) if shared else local_rank
+    return torch.device("cuda", idx), ("gloo" if shared else "nccl"), shared
+
+
 FLOP_PER_IMAGE_2D = 10.467e9       # per Unet evaluation of one 64x64 image (SURVEY.md section 8, row a15)
 PMC_CFG5_FILE = "r04_pmc_traffic_cfg5.json"
 
@@ -257,7 +270,7 @@ def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    dev = torch.device("cuda", local_rank)
+    dev = rank_device()[0]
     import torch.distributed as dist
     import cindm_amd
     from cindm_amd import dist as cdist
@@ -299,7 +312,7 @@ def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=
         fence()
         elapsed = time.perf_counter() - t0
         if distributed:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], device=(dev if dist.get_backend() == "nccl" else "cpu"), dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         assert tuple(out.shape) == (total, nb, 21, 64, 64) and bool(torch.isfinite(out).all())
@@ -400,14 +413,18 @@ def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=
 
 def main_cfg5(args):
     """bench.py --workload cfg5 | cfg5g as the headline."""
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev, backend, shared = rank_device()
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     line = measure_2d(args, args.workload, args.steps, args.warmup, 20.0)
+    if line is not None and shared:
+        line["shared_gpus"] = f"{world} ranks on {torch.cuda.device_count()} GPU(s), gloo rendezvous: code-path run, not a benchmark"
     if line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -550,7 +567,7 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    dev = torch.device("cuda", local_rank)
+    dev = rank_device()[0]
     import torch.distributed as dist
     from cindm_amd import dist as cdist
     B = args.batch or (128 if wl == "cfg4" else BATCH)
@@ -579,7 +596,7 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
         fence()
         elapsed = time.perf_counter() - t0
         if distributed:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], device=(dev if dist.get_backend() == "nccl" else "cpu"), dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         assert tuple(out.shape) == (total,) + w["out_shape"] and bool(torch.isfinite(out).all())
@@ -710,14 +727,18 @@ def main():
         return main_cfg5(args)
     wl = args.workload
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev, backend, shared = rank_device()
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     line = measure_1d(args, wl, args.steps, args.warmup, 20.0)
+    if line is not None and shared:
+        line["shared_gpus"] = f"{world} ranks on {torch.cuda.device_count()} GPU(s), gloo rendezvous: code-path run, not a benchmark"
     if line is not None and wl == "cfg2" and world == 1 and not args.no_extra_workloads and not args.batch:
         # every other BASELINE configuration, driver-timed in the same run; each builds its own models and frees them
         hint = (line.get("cpu_baseline") or {}).get("cores")

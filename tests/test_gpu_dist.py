@@ -208,3 +208,26 @@ def test_two_processes_sampling_concurrently_on_one_device(device):
                 continue
             pytest.fail(f"rank {rank} chain {i}: neither the fast nor the exchange-free result (recovered {recovered}, "
                         f"max diff {float((o - refs[i]).abs().max()):.3e})")
+
+
+def test_bench_two_ranks_end_to_end(device):
+    """`python bench.py --gpus 2` for real: bench starts a child torch.distributed.run, two ranks rendezvous, each samples its 256
+    designs (32 here: two full-size chains time-sharing one device would spend the test in recoveries), the chains are gathered, the time is the maximum over ranks and rank 0 prints ONE line for the whole job.  On a box
+    with fewer GPUs than ranks the ranks share devices over gloo (the line says so: "shared_gpus"; it is a code-path run, not a
+    benchmark -- two chains time-share one device, exchange time-outs are recovered); with two GPUs it is the RCCL path itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "32",
+                        "--no-cpu-baseline", "--no-extra-workloads"], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["designs_per_step"] == 64 and line["config"]["parallelism"].startswith("dp2")      # 32 designs per rank
+    assert line["value"] > 0 and abs(line["value"] - 64 / (line["ms_per_step"] / 1000.0)) < 1e-2 * line["value"]
+    if torch.cuda.device_count() < 2:
+        assert "shared_gpus" in line
