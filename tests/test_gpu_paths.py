@@ -633,3 +633,29 @@ def test_ddim_loop_fuses_and_pingpongs(device, unet8):
         for key in ((eta, 0, 1), (eta, 1, 0), (eta, 0, 0)):
             for a, b in zip(out[eta, 1, 1], out[key]):
                 assert torch.equal(a, b), key
+
+
+@pytest.mark.parametrize("F", [4, 16])
+def test_fused_update_other_state_widths(device, F):
+    """The fused update (noise generated at the top of ups_last_kernel, state rows requested a layer ahead) for state widths other
+    than the paper's 8 features: F = 4 (a quarter of the final stage's lanes hold state elements) and F = 16 (all of them).  The
+    plain single-model loop that accepts any width is the DDIM one: fused against the separate update kernel bit for bit, counter
+    noise and an explicit tape, eta > 0 so that noise is drawn."""
+    m, _ = build_unet(device, F=F, seed=7)
+    res = {}
+    try:
+        for v in (0, 1):
+            m.set_option("fuse_update", v)
+            dd = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=50,
+                                               ddim_sampling_eta=0.3).to(device)
+            tape = _tape(2, (5, 24, F), 50)
+            z = torch.zeros((5, 24, F), device=device)
+            res[v] = (dd.ddim_sample((5, 24, F), None, seed=11, sample_offset=2, step_range=(0, 6), init_img=z),
+                      dd.ddim_sample((5, 24, F), None, noise=tape, step_range=(0, 5), init_img=z),
+                      dd.ddim_sample((5, 24, F), None, seed=11, step_range=(44, 50), init_img=z + 0.2))
+            assert dd.last_step_info()[1] is bool(v)
+    finally:
+        m.set_option("fuse_update", 1)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert float(res[1][0].abs().max()) > 0
