@@ -199,67 +199,147 @@ def timed_cpu_steps(step_once, budget_s, reps=3, max_steps=100):
     return min(per), k, [round(v * 1e3, 1) for v in per]
 
 
-def thread_sweep(step_fn, hint=None):
-    """One CPU step per thread count; returns (fastest count, {count: seconds}).  With `hint` (the count another workload's
-    sweep on this host chose) nothing is swept."""
+# ---- the CPU leg runs in CHILD processes -------------------------------------------------------------------------------
+# Round 4's line was not self-consistent: the sweep measured 38.7 ms per step at 32 threads, the timed leg at the same 32 threads
+# 82 ms, three times over.  Both ran in the bench process, whose OpenMP / MKL / oneDNN state had seen every thread count of the
+# sweep (up to all logical cores) before it was set back to the winner.  Now every measurement is its own short-lived process
+# whose thread count is fixed in its environment (OMP_NUM_THREADS / MKL_NUM_THREADS) before torch is imported and never changes:
+# one child per swept count, one child for the timed leg at the winner.  The parent only reads their result files (the tape
+# the rel_err leg replays comes back that way too).  tests/test_host_logic.py::test_cpu_leg_is_self_consistent holds the timed
+# leg to 1.3 x the sweep's value at the same count.
+def cpu_leg_make_step(spec):
+    """(x0, draw(k) -> noise of step k, step(x, k, noise) -> x', label) of a CPU-leg spec; runs in the child."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cindm_oracle as O
+    g = torch.Generator().manual_seed(0)
+    if spec["kind"] == "1d":
+        workload, B = spec["workload"], spec["B"]
+        L, F = spec["out_shape"]
+        x0 = torch.randn((B, L, F), generator=g)
+        cond = spec.get("cond")
+        if workload == "cfg4":
+            od = O.Diffusion1D(spec["sd"], image_size=20, conditioned_steps=4, sd_uncond=spec["sd_single"])
+            t_first = 399
+            step = lambda x, k, nz: O.p_sample(od, x, cond, t_first - k, nz)[0]
+        elif workload == "cfg3":
+            od = O.Diffusion1D(spec["sd"], image_size=24, conditioned_steps=0)
+            kw = dict(spec["compose_kw"], single_model_step=24)
+            t_first = 500
+            step = lambda x, k, nz: O.p_sample_compose_inside(od, x, None, t_first - k, nz, **kw)[0]
+        else:
+            od = O.Diffusion1D(spec["sd"], image_size=24, conditioned_steps=0)
+            kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
+            t_first = 500
+            step = lambda x, k, nz: O.p_sample_compose_outside(od, x, None, t_first - k, nz, **kw)[0]
+        draw = lambda k: torch.randn((B, L, F), generator=g)
+        return x0, draw, step, t_first
+    Bc, nb = spec["Bc"], 2
+    od = O.Diffusion2D(spec["sd"], image_size=64, frames=6)
+    x0 = torch.randn((Bc * nb, 21, 64, 64), generator=g)
+    shape = (Bc, nb, 21, 64, 64)
+    draw = lambda k: O.sample_noise_2d(torch.randn((Bc, 1, 18, 64, 64), generator=g), torch.randn((Bc, nb, 3, 64, 64), generator=g)).reshape(Bc * nb, 21, 64, 64)
+    fn, guid = None, "standard"
+    if spec.get("guided_sd") is not None:
+        gsd = spec["guided_sd"]
+
+        def fn(z):
+            with torch.enable_grad():       # (the oracle takes the objective's gradient with autograd, as the reference's design_fn does)
+                return O.airfoil_design_grad(gsd, z, Bc, nb, 6, p_min=-37.7, p_max=57.6).detach()
+        guid = "standard-alpha"
+    step = lambda x, k, nz: O.p_sample_2d(od, shape, x, 500 - k, nz, fn, guid)[0]
+    return x0, draw, step, 500
+
+
+def cpu_leg_child(spec_path):
+    """`python bench.py --cpu-leg-child SPEC`: one measurement at the thread count the parent fixed in this process's environment."""
+    spec = torch.load(spec_path, weights_only=False)
+    torch.set_num_threads(int(spec["threads"]))          # (the environment already says so; this pins ATen's own count as well)
+    x0, draw, step, t_first = cpu_leg_make_step(spec)
+    with torch.no_grad():
+        if spec["mode"] == "sweep":
+            nz = draw(0)
+            step(x0, 0, nz)
+            t0 = time.time()
+            step(x0, 0, nz)
+            res = {"seconds": time.time() - t0}
+        else:
+            state = {"x": x0.clone()}
+            tape = []
+
+            def once(k):
+                nz = draw(k)
+                tape.append((t_first - k, nz))
+                state["x"] = step(state["x"], k, nz)
+
+            step(x0, 0, draw(-1)) if spec.get("warm") else None       # one untimed step: first-touch, primitive creation
+            dt, n, per = timed_cpu_steps(once, spec["budget_s"], max_steps=spec["max_steps"])
+            res = {"dt": dt, "n": n, "per": per, "x0": x0, "tape": tape, "final": state["x"]}
+    res["threads_seen"] = torch.get_num_threads()
+    torch.save(res, spec_path + ".out")
+
+
+def run_cpu_leg_child(spec, threads, mode, tmpdir, **kw):
+    import subprocess
+    path = os.path.join(tmpdir, f"{mode}_{threads}.pt")
+    torch.save(dict(spec, threads=int(threads), mode=mode, **kw), path)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["HIP_VISIBLE_DEVICES"] = ""; env["CUDA_VISIBLE_DEVICES"] = ""       # the child is a host-only process
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg-child", path], env=env, capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.isfile(path + ".out"):
+        raise RuntimeError(f"cpu leg child ({mode}, {threads} threads) failed: {r.stderr[-600:]}")
+    return torch.load(path + ".out", weights_only=False)
+
+
+def sweep_counts():
     model, phys = cpu_info()
     default_threads = torch.get_num_threads()
-    if hint:
-        return int(hint), {}
-    sweep = {}
-    for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)}):
-        torch.set_num_threads(nt)
-        step_fn()
-        t0 = time.time()
-        step_fn()
-        sweep[nt] = time.time() - t0
-    return min(sweep, key=sweep.get), sweep
+    return sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n and n <= max(default_threads, phys or 1)})
+
+
+def run_cpu_leg(spec, budget_s, threads_hint=None, max_steps=100, counts=None):
+    """Sweep (one child per thread count; skipped with `threads_hint`, the count another workload's sweep on this host chose), then
+    the timed leg in a child of its own at the winner.  Returns (best count, {count: seconds}, timed-leg result dict)."""
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="cindm_cpu_leg_") as td:
+        sweep = {}
+        if threads_hint:
+            best = int(threads_hint)
+        else:
+            for nt in (counts or sweep_counts()):
+                sweep[nt] = run_cpu_leg_child(spec, nt, "sweep", td)["seconds"]
+            best = min(sweep, key=sweep.get)
+        res = run_cpu_leg_child(spec, best, "timed", td, budget_s=budget_s, max_steps=max_steps, warm=True)
+    return best, sweep, res
+
+
+def cpu_leg_record(value, best, sweep, res, sample):
+    cpu_model, phys = cpu_info()
+    out = {"value": value, "unit": "samples/s", "cores": best, "kind": "port", "sample": sample,
+           "ms_per_step_per_repetition": res["per"],
+           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())} if sweep
+                                       else f"not swept: {best} threads, the count the headline workload's sweep chose on this host",
+           "process_model": "every thread count of the sweep and the timed leg run in their own child process (thread count fixed in the "
+                            "environment before torch is imported)",
+           "cpu_model": cpu_model, "physical_cores": phys}
+    if sweep:
+        out["timed_vs_sweep_at_cores"] = round(res["dt"] / sweep[best], 3)
+    return out
 
 
 def cpu_baseline_2d(sd, budget_s=20.0, threads_hint=None, guided_sd=None, Bc=4):
     """The oracle's 2-D reverse step (torch-CPU port of the reference) on a bounded sample: steps of Bc designs x 2
     boundaries, extrapolated to 1000 steps; `guided_sd`: under the airfoil design objective (the ForceUnet surrogate's
     forward + autograd per step, inference/inverse_design_2d.py:208-214).  Also returns what the rel_err leg replays:
-    (x0, [(t, noise)], final CPU state, design_fn or None)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cindm_oracle as O
-    od = O.Diffusion2D(sd, image_size=64, frames=6)
+    (x0, [(t, noise)], final CPU state, Bc)."""
     nb = 2
-    g = torch.Generator().manual_seed(0)
-    x0 = torch.randn((Bc * nb, 21, 64, 64), generator=g)
-    shape = (Bc, nb, 21, 64, 64)
-    draw = lambda: O.sample_noise_2d(torch.randn((Bc, 1, 18, 64, 64), generator=g), torch.randn((Bc, nb, 3, 64, 64), generator=g)).reshape(Bc * nb, 21, 64, 64)
-    fn, guid = None, "standard"
-    if guided_sd is not None:
-        def fn(z):
-            with torch.enable_grad():       # (the oracle takes the objective's gradient with autograd, as the reference's design_fn does)
-                return O.airfoil_design_grad(guided_sd, z, Bc, nb, 6, p_min=-37.7, p_max=57.6).detach()
-        guid = "standard-alpha"
-    cpu_model, phys = cpu_info()
-    default_threads = torch.get_num_threads()
-    nz0 = draw()
-    step = lambda x, t, nz: O.p_sample_2d(od, shape, x, t, nz, fn, guid)[0]
-    with torch.no_grad():
-        best, sweep = thread_sweep(lambda: step(x0, 500, nz0), threads_hint)
-        torch.set_num_threads(best)
-        state = {"x": x0.clone()}
-        tape = []
-
-        def once(k):
-            nz = draw()
-            tape.append((500 - k, nz))
-            state["x"] = step(state["x"], 500 - k, nz)
-
-        dt, n, per = timed_cpu_steps(once, budget_s, max_steps=30)
-        torch.set_num_threads(default_threads)
-    out = {"value": Bc / (dt * TIMESTEPS), "unit": "samples/s", "cores": best, "kind": "port",
-           "sample": f"{n} reverse steps of {Bc} designs x {nb} boundaries" + (" under the force objective" if fn else "")
-                     + f" (best of 3 repetitions: {dt * 1e3:.0f} ms/step), extrapolated x{TIMESTEPS}",
-           "ms_per_step_per_repetition": per,
-           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())} if sweep
-                                       else f"not swept: {best} threads, the count the headline workload's sweep chose on this host"}
-    out.update({"cpu_model": cpu_model, "physical_cores": phys})
-    return out, (x0, tape, state["x"], Bc)
+    spec = {"kind": "2d", "sd": sd, "guided_sd": guided_sd, "Bc": Bc}
+    best, sweep, res = run_cpu_leg(spec, budget_s, threads_hint, max_steps=30)
+    dt, n = res["dt"], res["n"]
+    out = cpu_leg_record(Bc / (dt * TIMESTEPS), best, sweep, res,
+                         f"{n} reverse steps of {Bc} designs x {nb} boundaries" + (" under the force objective" if guided_sd is not None else "")
+                         + f" (best of 3 repetitions: {dt * 1e3:.0f} ms/step), extrapolated x{TIMESTEPS}")
+    return out, (res["x0"], res["tape"], res["final"], Bc)
 
 
 def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=0):
@@ -483,58 +563,33 @@ def build_1d(workload, B, dev):
 
 def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0, threads_hint=None):
     """cpu_baseline + rel_err of a 1-D workload: the oracle's reverse steps (t = 500 downwards) on the host cores for
-    ~budget_s -- the fastest thread count of a short sweep, best of three repetitions -- extrapolated to the chain length;
-    then the same steps on the same inputs and explicit noise through the HIP path."""
+    ~budget_s -- the fastest thread count of a short sweep, best of three repetitions, every measurement in its own child
+    process (run_cpu_leg) -- extrapolated to the chain length; then the same steps on the same inputs and explicit noise
+    through the HIP path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cindm_oracle as O
     d = w["diffusion"]
     sd = cpu_state_dict(w["pair"])
-    g = torch.Generator().manual_seed(0)
     L, F = w["out_shape"]
-    x0 = torch.randn((B, L, F), generator=g)
-    cond = w["cond"].cpu() if "cond" in w else None
+    spec = {"kind": "1d", "workload": workload, "B": B, "out_shape": (L, F), "sd": sd}
     if workload == "cfg4":
-        od = O.Diffusion1D(sd, image_size=20, conditioned_steps=4, sd_uncond=cpu_state_dict(w["single"]))
-        t_first = 399
-        cpu_step = lambda x, t, nz: O.p_sample(od, x, cond, t, nz)[0]
+        spec["sd_single"] = cpu_state_dict(w["single"]); spec["cond"] = w["cond"].cpu()
         gpu_step = lambda x, t, nz: d.p_sample(x, w["cond"], t, noise=nz)[0]
     elif workload == "cfg3":
-        od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+        spec["compose_kw"] = dict(w["compose_kw"])
         kw = dict(w["compose_kw"], single_model_step=24)
-        t_first = 500
-        cpu_step = lambda x, t, nz: O.p_sample_compose_inside(od, x, None, t, nz, **kw)[0]
         gpu_step = lambda x, t, nz: d.p_sample_compose_inside(x, None, t, noise=nz, **kw)[0]
     else:
-        od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
         kw = dict(compose_mode="mean", n_composed=0, compose_start_step=4, single_model_step=24, compose_n_bodies=2)
-        t_first = 500
-        cpu_step = lambda x, t, nz: O.p_sample_compose_outside(od, x, None, t, nz, **kw)[0]
         gpu_step = lambda x, t, nz: d.p_sample_compose_outside(x, None, t, noise=nz, **kw)[0]
-    model, phys = cpu_info()
-    default_threads = torch.get_num_threads()
-    with torch.no_grad():
-        nz = torch.randn((B, L, F), generator=g)
-        best, sweep = thread_sweep(lambda: cpu_step(x0, t_first, nz), threads_hint)
-        torch.set_num_threads(best)
-        state = {"x": x0.clone()}
-        noises = []
-
-        def once(k):
-            nzk = torch.randn((B, L, F), generator=g)
-            noises.append(nzk)
-            state["x"] = cpu_step(state["x"], t_first - k, nzk)
-
-        dt, n, per = timed_cpu_steps(once, budget_s)
-        x = state["x"]
-        torch.set_num_threads(default_threads)
+    best, sweep, res = run_cpu_leg(spec, budget_s, threads_hint)
+    dt, n, x0, x = res["dt"], res["n"], res["x0"], res["final"]
+    noises = [nz for _, nz in res["tape"]]
+    t_first = res["tape"][0][0]
     S = w["steps_per_design"]
-    out = {"value": B / (dt * S), "unit": "samples/s", "cores": best, "kind": "port",
-           "sample": f"{n} reverse steps of batch {B} (best of 3 repetitions: {dt * 1e3:.1f} ms/step), extrapolated x{S}"
-                     + (" (a DDIM step costs the same U-Net evaluation)" if workload == "cfg2-ddim250" else ""),
-           "ms_per_step_per_repetition": per,
-           "cpu_model": model, "physical_cores": phys,
-           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sorted(sweep.items())} if sweep
-                                       else f"not swept: {best} threads, the count the headline workload's sweep chose on this host"}
+    out = cpu_leg_record(B / (dt * S), best, sweep, res,
+                         f"{n} reverse steps of batch {B} (best of 3 repetitions: {dt * 1e3:.1f} ms/step), extrapolated x{S}"
+                         + (" (a DDIM step costs the same U-Net evaluation)" if workload == "cfg2-ddim250" else ""))
     xg = x0.to(dev)
     for k, nzk in enumerate(noises):
         xg = gpu_step(xg, t_first - k, nzk.to(dev))
@@ -546,6 +601,7 @@ def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0, threads_hint=None):
         # the CPU reference's own U-Net output moves a 50-step result by 1e-3): every one of the first
         # 10 DDIM steps (eta = 0) is taken by the HIP path FROM THE CPU PATH'S STATE and compared with the CPU path's next state
         times = O.ddim_time_pairs(TIMESTEPS, 250)[:10]
+        od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
         img, worst = x0.clone(), 0.0
         with torch.no_grad():
             for i, (time_, time_next) in enumerate(times):
@@ -558,6 +614,31 @@ def cpu_baseline_1d(workload, w, B, dev, budget_s=20.0, threads_hint=None):
         extra["rel_err_ddim_teacher_forced"] = worst
         extra["rel_err_ddim_note"] = "max over the first 10 DDIM steps, each taken from the CPU path's state (eta = 0)"
     return out, rel, extra
+
+
+def bench_line_1d(world, B, steps, warmup, elapsed, text, S, evals, roof, recovered=0):
+    """The bench line of a 1-D workload as a pure function of what was measured: `world` ranks of `B` designs each ran `steps`
+    chains of `S` reverse steps in `elapsed` seconds (the slowest rank's time between the two barriers).  `value` is the
+    whole job's designs per second; weak scaling (B per GPU is fixed).  tests/test_host_logic.py calls this for a world of 8."""
+    total = B * world
+    chains = steps
+    value = total * chains / elapsed
+    flop_design = S * (evals[0] * FLOP_PER_EVAL + evals[1] * FLOP_PER_EVAL_F4)
+    return {
+        "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / chains * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": text, "designs_per_step": total, "unet_evals_per_design": S * sum(evals),
+                   "reverse_steps_per_design": S,
+                   "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
+        "us_per_reverse_step": round(elapsed / (chains * S) * 1e6, 1),
+        "sample_steps_per_s": round(value * S, 1),
+        "model_tflops": round(value * flop_design / 1e12, 2),
+        "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
+        "exchange_timeouts_recovered": recovered,
+        "roofline": roof,
+    }
 
 
 def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
@@ -654,24 +735,8 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
 
         line = None
         if rank == 0:
-            chains = steps
-            value = total * chains / elapsed
-            flop_design = S * (w["evals"][0] * FLOP_PER_EVAL + w["evals"][1] * FLOP_PER_EVAL_F4)
-            line = {
-                "metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref",
-                "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-                "ms_per_step": round(elapsed / chains * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": w["text"], "designs_per_step": total, "unet_evals_per_design": S * sum(w["evals"]),
-                           "reverse_steps_per_design": S,
-                           "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
-                "us_per_reverse_step": round(elapsed / (chains * S) * 1e6, 1),
-                "sample_steps_per_s": round(value * S, 1),
-                "model_tflops": round(value * flop_design / 1e12, 2),
-                "frac_of_f32_mfma_peak_whole_job": round(value * flop_design / 1e12 / (PEAK_F32_MFMA_TF * world), 4),
-                "exchange_timeouts_recovered": int(model.recovered) + (int(w["single"].recovered) if w["single"] is not None else 0),
-                "roofline": roof,
-            }
+            recovered = int(model.recovered) + (int(w["single"].recovered) if w["single"] is not None else 0)
+            line = bench_line_1d(world, B, steps, warmup, elapsed, w["text"], S, w["evals"], roof, recovered)
             if not args.no_cpu_baseline and world == 1:
                 line["cpu_baseline"], line["rel_err"], extra = cpu_baseline_1d(wl, w, B, dev, budget_s=cpu_budget_s, threads_hint=threads_hint)
                 line.update(extra)
@@ -708,6 +773,8 @@ EXTRA_WORKLOADS = (("cfg3", 2, 1, 4.0, 0), ("cfg4", 3, 1, 4.0, 0), ("cfg2-ddim25
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-leg-child":
+        return cpu_leg_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "cindm_abi_version": (C.c_int, []),
     "cindm_last_error": (C.c_char_p, []),
     "cindm_source_hash": (C.c_char_p, []),
+    "cindm_ws_prof_read": (C.c_int, [_vp]),
     "cindm_unet1d_status": (C.c_int, [_vp, _vp]),
     "cindm_unet1d_poll": (C.c_int, [_vp, _vp]),
     "cindm_unet1d_recovered": (C.c_int, [_vp]),

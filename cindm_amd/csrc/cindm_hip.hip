@@ -32,6 +32,22 @@ extern "C" int cindm_abi_version(void) { return CINDM_ABI_VERSION; }
 // the hash behind a marker the build script finds in the file's bytes (cindm_amd/build.py: embedded_hash)
 extern "C" const char cindm_source_hash_marker[] = "CINDM_SRC_HASH=" CINDM_SRC_HASH;
 extern "C" const char* cindm_source_hash(void) { return cindm_source_hash_marker + 15; }
+// In-kernel clocks of conv2d_ws_kernel (kernels2d_v2.h, profiling build only): copies [8 categories][2 roles][8 phases] sums of
+// 10 ns ticks to dst and clears them.  Returns 0 in the production build (nothing is recorded there), 1 in the profiling build.
+extern "C" int cindm_ws_prof_read(unsigned long long* dst) {
+    if (!dst) return fail("null argument");
+#ifdef CINDM_PHASE_PROF
+    const size_t n = sizeof(unsigned long long) * cindm::WSP_CAT * 2 * cindm::WSP_NPH;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(cindm::g_ws_prof), n));
+    std::vector<unsigned long long> z(cindm::WSP_CAT * 2 * cindm::WSP_NPH, 0ull);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(cindm::g_ws_prof), z.data(), n));
+    return 1;
+#else
+    std::memset(dst, 0, sizeof(unsigned long long) * cindm::WSP_CAT * 2 * cindm::WSP_NPH);
+    return 0;
+#endif
+}
 extern "C" const char* cindm_last_error(void) { return g_err.c_str(); }
 
 static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }

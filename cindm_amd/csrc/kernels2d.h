@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
 // over nh = w >> 1 -- the same (k-group, column half) structure and epilogue as conv2d_h3_kernel.
 constexpr int STEM3_NI = 25;             // tap slots per wave pair (the 25th of the odd pair is a zero pad)
 __global__ __launch_bounds__(256, 2) void conv2d_stem7_h3_kernel(const Conv2dArgs a) {
-    constexpr int SW = 22, SH = 10, R = SW * SH, PITCH = 80, PLANE = R * PITCH, NP = (R * 8 + 255) / 256;
+    constexpr int SW = 22, SH = 10, R = SW * SH, PITCH = 96, PLANE = R * PITCH, NP = (R * 8 + 255) / 256;      // pitch = 32 (mod 64) bytes: conflict-free ds_read_b128 fragments (kernels2d_v2.h, V2PITCH)
     __shared__ __attribute__((aligned(16))) unsigned char planes[2 * PLANE];
     __shared__ __attribute__((aligned(16))) float Red[4][T2M * LDR2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256) void tail_identity_kernel(const Conv2dArgs a) 
 // Weights: [n-tile][k-step][plane][thread = wave * 64 + lane][8 halfs] = W[n = tile*64 + wave*16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e].
 template <int KT>
 __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArgs a) {
-    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
+    constexpr int KS = KT / 32, PITCH = KT * 2 + 32, F4 = KT / 4, NPASS = (64 * F4) / 256;      // pitch = 32 (mod 64) bytes: conflict-free ds_read_b128 fragments (kernels2d_v2.h, V2PITCH)
     static_assert((64 * F4) % 256 == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
     __shared__ float tabE[16];
@@ -1500,7 +1500,7 @@ constexpr int la2_px(int C) { return C == 64 ? LA2_PX : LA2_PX / 2; }
 // columns 4*lcol.. of rows r*RPP + lrow) -> (hi, scaled lo) fp16 planes
 template <int C, int NPX>
 struct LnTile {
-    static constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 16;
+    static constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 32;
     __device__ static __forceinline__ void load(float4 (&xr)[NPASS], const float* __restrict__ x0, int ldx, int tid) {
         const int lrow = tid / LPR, lcol = tid % LPR;
 #pragma unroll
@@ -1534,7 +1534,7 @@ template <int C>
 __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
     constexpr int PX = la2_px(C);
     using LN = LnTile<C, PX>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = PX / 16;
+    constexpr int K32 = C / 32, YPB = 2 * C + 32, NTL = PX / 16;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][PX * YPB];
     __shared__ float fac[4][32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict
 template <int C>
 __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
     using LN = LnTile<C, 64>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
+    constexpr int K32 = C / 32, YPB = 2 * C + 32, APB = 2 * 128 + 32, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];
     __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NPX * APB];
     static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "Z aliases the y planes");
@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 // accumulators hold the probabilities -- are contiguous: P goes from the accumulators into the second product with
 // no data movement.  The exponentials and the fp16 splits of P are now the dominant work (VALU), not the MFMAs.
 __global__ __launch_bounds__(256, 2) void attn_full_h3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
-    constexpr int KPB = 80, VPB = 144;                   // bytes per key row (32 d) / per d row (64 key slots), padded
+    constexpr int KPB = 96, VPB = 160;                   // bytes per key row (32 d) / per d row (64 key slots), padded to 32 (mod 64): conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][64 * KPB];     // [buffer][plane]
     __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][32 * VPB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

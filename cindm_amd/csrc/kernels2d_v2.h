@@ -43,13 +43,37 @@ namespace cindm {
 
 constexpr int V2Y = 8, V2X = 16, V2M = V2Y * V2X;          // output pixel tile
 constexpr int V2SW = 18, V2R = 10 * V2SW;                   // staged window 10 x 18 pixels
-constexpr int V2PITCH = 144, V2PLANE = V2R * V2PITCH;       // bytes per staged pixel and plane (64 halfs + 16 B pad)
+constexpr int V2PITCH = 160, V2PLANE = V2R * V2PITCH;       // bytes per staged pixel and plane: 64 halfs + 32 B pad.  A pitch of 32 (mod 64) bytes makes the
+                                                            // fragment reads (lane = pixel lq, 16-byte k-quarter lg) conflict-free under gfx950's ds_read_b128 lane groups
+                                                            // {0-3, 12-15, 20-27}, ...: round 2's 144 (odd in 16-byte units) was 2-way conflicted -- SQ_LDS_BANK_CONFLICT 45 %
+                                                            // of SQ_LDS_IDX_ACTIVE (profiles/r05_lds_conflicts_before.txt; tools/lds_bank_model.py)
 constexpr int V2LDT = 132;                                  // output tile [64 channels][128 pixels + 4]: pitch in floats
 constexpr int WS_GRID = 256;                                // one persistent workgroup per CU
 constexpr int WS_SPT = 4;                                   // GroupNorm partials per tile (one per memory wave, 32 pixels)
 constexpr int WS_MAXP = 128;                                // most GroupNorm partials per (image, group) the consumer side holds
 
-template <int KIND, int MODE>
+// In-kernel clocks of conv2d_ws_kernel -- profiling build only (CINDM_PHASE_PROF).  Workgroup WSP_WG's first matrix wave and first
+// memory wave add the time they spend in each phase (100 MHz wall clock) into g_ws_prof[category][role][phase]; category =
+// (GroupNorm-on-load source) + 2 * (more than one 64-channel chunk) + 4 * (input-gradient mode); role 0 = matrix wave (phases:
+// multiply, wait S1, reduce / tile write, wait S3, -, -, -, items), role 1 = memory wave (stage, issue loads, write tile, wait S1,
+// wait S2 / S3, -, -, items).  cindm_ws_prof_read() copies and clears it; tools/ws_prof.py prints it.
+constexpr int WSP_CAT = 8, WSP_NPH = 8, WSP_WG = 8;
+#ifdef CINDM_PHASE_PROF
+__device__ unsigned long long g_ws_prof[WSP_CAT][2][WSP_NPH];
+#define WSP_DECL unsigned long long wsp_[WSP_NPH] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; unsigned long long wsp_t_ = wall_clock64()
+#define WSP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); wsp_[i] += n_ - wsp_t_; wsp_t_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WSP_COUNT() do { wsp_[7] += 1; } while (0)
+#define WSP_FLUSH(role_) do { if (blockIdx.x == WSP_WG && lw == 0 && lane == 0) { \
+        const int cat_ = (MODE == SRC2_GN_SS_SILU ? 1 : 0) + (nch > 1 ? 2 : 0) + (MODE == SRC2_SCALED ? 4 : 0); \
+        _Pragma("unroll") for (int i_ = 0; i_ < WSP_NPH; ++i_) atomicAdd(&g_ws_prof[cat_][role_][i_], wsp_[i_]); } } while (0)
+#else
+#define WSP_DECL do { } while (0)
+#define WSP(i) do { } while (0)
+#define WSP_COUNT() do { } while (0)
+#define WSP_FLUSH(role_) do { } while (0)
+#endif
+
+template <int KIND, int MODE, bool KSPLIT = true>
 __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     // KIND CONV_3X3_PAIR (ForceUnet's 8 x 8 level): the images are 8 pixels wide and a tile is rows ty0 .. ty0 + 7 of images
     // 2j | 2j + 1 side by side (a.NI counts PAIRS).  Each half keeps its own zero columns: the window is 10 x 20 pixels,
@@ -84,8 +108,119 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     };
     auto nt_of = [&](int tl) { return (lo + wj + tl * wpx) % ntiles; };      // NSPLIT: the n-tile of this workgroup's unit tl
 
+    if (role == 0 && !KSPLIT) {
+        // ================================ matrix waves, K not split over the waves (round 5) ======================
+        // wave = (pixel half ph: pixel blocks 4 ph .. 4 ph + 3, column half nh), ALL 64 channels of the chunk: the k-group
+        // reduction of the variant below (kg = 1 parks its partial tile in LDS, barrier, kg = 0 adds, barrier: 1.75 us of a
+        // 7.3 us tile in the in-kernel clocks of profiles/r02_cfg5_phases.txt) does not exist; the price is that the two waves
+        // of a column half fetch the same weight fragments (8 instead of 4 16-byte loads per tap and wave).  Same weight pack:
+        // the fragments of k-group kh live at thread (kh + 2 nh) * 64 + lane.
+        const int ph = lw & 1, nh = lw >> 1;
+        if (MODE != SRC2_GN_SS_SILU) __builtin_amdgcn_s_setprio(3);
+        f32x4 accM[4][2], accL[4][2];
+        half8 breg[3][2][2][2];                               // [ring slot][k half][column block][plane]
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + nh * 128 + lane;
+        auto load_b = [&](int nt, int ch, int tap, int slot_) {
+            const uint4* wp = wbase + ((size_t)(nt * nch + ch) * 9 + tap) * 4 * 256;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) breg[slot_][kh][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256 + kh * 64]);
+        };
+        const int foff = ((lane & 15) + (PAIR && (lane & 15) >= 8 ? 2 : 0)) * V2PITCH + (lane >> 4) * 16;
+        // 72 steps (tap, k half, pixel block); fragments of step s + 2 are read while step s multiplies
+        auto compute = [&](const unsigned char* P0, int nt, int ch, int nt2, int ch2, auto FIRST_) {
+            constexpr bool FIRST = decltype(FIRST_)::value;
+            const unsigned char* P1 = P0 + PLANE;
+            half8 fh[3], fl[3];
+            auto read_frag = [&](int s, int slot_) {
+                const int tap = s >> 3, kh = (s >> 2) & 1, mb = s & 3;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const int o = ((4 * ph + mb + dy) * SW + dx) * V2PITCH + kh * 64;
+                fh[slot_] = *reinterpret_cast<const half8*>(P0 + o);
+                fl[slot_] = *reinterpret_cast<const half8*>(P1 + o);
+            };
+            read_frag(0, 0); read_frag(1, 1);
+#pragma unroll
+            for (int s = 0; s < 72; ++s) {
+                const int tap = s >> 3, kh = (s >> 2) & 1, mb = s & 3, bs = tap % 3, fs = s % 3;
+                if (s + 2 < 72) read_frag(s + 2, (s + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bool z = FIRST && tap == 0 && kh == 0;
+                accM[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][0][0], z ? zero : accM[mb][0], 0, 0, 0);
+                accL[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][0][1], z ? zero : accL[mb][0], 0, 0, 0);
+                accM[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][1][0], z ? zero : accM[mb][1], 0, 0, 0);
+                accL[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][1][1], z ? zero : accL[mb][1], 0, 0, 0);
+                accL[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][kh][0][0], accL[mb][0], 0, 0, 0);
+                accL[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][kh][1][0], accL[mb][1], 0, 0, 0);
+                if ((s & 7) == 7) {                          // this slot's next tap (of this or the next item), two taps ahead
+                    if (tap + 3 < 9) load_b(nt, ch, tap + 3, bs);
+                    else load_b(nt2, ch2, tap + 3 - 9, bs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
+        stress_delay(a.stress, 100u);
+        __syncthreads();                                     // S0: item 0 is staged
+        WSP_DECL;
+        int k = 0;
+        for (int tl = 0; tl < mine; ++tl)
+            for (int nt = NSPLIT ? nt_of(tl) : 0, nt_end = NSPLIT ? nt + 1 : ntiles; nt < nt_end; ++nt) {
+                const int nt_after = NSPLIT ? (tl + 1 < mine ? nt_of(tl + 1) : 0) : (nt + 1 < ntiles ? nt + 1 : 0);
+                {
+                    const int nt2 = nch > 1 ? nt : nt_after, ch2 = nch > 1 ? 1 : 0;
+                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, 0, nt2, ch2, std::true_type{});
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    }
+                    ++k;
+                    WSP(0); WSP_COUNT();
+                    stress_delay(a.stress, 101u + 8u * (unsigned)k);
+                    __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
+                    WSP(1);
+                }
+                for (int ch = 1; ch < nch; ++ch) {
+                    const int nt2 = ch + 1 < nch ? nt : nt_after, ch2 = ch + 1 < nch ? ch + 1 : 0;
+                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
+                    ++k;
+                    WSP(0); WSP_COUNT();
+                    stress_delay(a.stress, 102u + 8u * (unsigned)k);
+                    __syncthreads();                         // S1
+                    WSP(1);
+                }
+                // every wave writes its finished 64 pixels x 32 channels (+ bias) into the channel-major tile: one ds_write_b128
+                // per (pixel block, column block)
+                float* const trow = Tile + (nh * 32 + (lane & 15)) * V2LDT + (lane >> 4) * 4 + ph * 64;
+                float bias[2];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int gn = nt * T2N + nh * 32 + (lane & 15) + nb * 16;
+                    bias[nb] = (a.bias && gn < a.N) ? a.bias[gn] : 0.f;
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        float4 v;
+                        v.x = (accM[mb][nb][0] + accL[mb][nb][0] * H3_INV) + bias[nb]; v.y = (accM[mb][nb][1] + accL[mb][nb][1] * H3_INV) + bias[nb];
+                        v.z = (accM[mb][nb][2] + accL[mb][nb][2] * H3_INV) + bias[nb]; v.w = (accM[mb][nb][3] + accL[mb][nb][3] * H3_INV) + bias[nb];
+                        *reinterpret_cast<float4*>(trow + nb * 16 * V2LDT + mb * 16) = v;
+                    }
+                WSP(2);
+                stress_delay(a.stress, 104u + 8u * (unsigned)k);
+                __syncthreads();                             // S3: the finished tile is in LDS
+                WSP(3);
+            }
+        WSP_FLUSH(0);
+        return;
+    }
     if (role == 0) {
-        // =========================================== matrix waves ==================================================
+        // ===================================== matrix waves, K split over the waves ================================
         const int kg = lw & 1, nh = lw >> 1;
         if (MODE != SRC2_GN_SS_SILU) __builtin_amdgcn_s_setprio(3);   // plain source: the matrix pipe is the long pole -> it goes first
         f32x4 accM[8][2], accL[8][2];
@@ -134,6 +269,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
         stress_delay(a.stress, 100u);
         __syncthreads();                                     // S0: item 0 is staged
+        WSP_DECL;
         // tile -> n-tile -> chunk: the same item order as decode(); nested so that the accumulators are defined by the
         // first chunk's tap 0 (zero C operand), updated by the other chunks and consumed by the reduce below
         int k = 0;
@@ -151,15 +287,19 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                             for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                     }
                     ++k;
+                    WSP(0); WSP_COUNT();
                     stress_delay(a.stress, 101u + 8u * (unsigned)k);
                     __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
+                    WSP(1);
                 }
                 for (int ch = 1; ch < nch; ++ch) {
                     const int nt2 = ch + 1 < nch ? nt : nt_after, ch2 = ch + 1 < nch ? ch + 1 : 0;
                     if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
                     ++k;
+                    WSP(0); WSP_COUNT();
                     stress_delay(a.stress, 102u + 8u * (unsigned)k);
                     __syncthreads();                         // S1
+                    WSP(1);
                 }
                 // the accumulators' 4 row registers are 4 consecutive pixels of one channel: one ds_write_b128 per (pixel
                 // block, column block) into the channel-major tile (the pixel-major tile of the first version cost 64
@@ -198,9 +338,12 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                             *tp = v;
                         }
                 }
+                WSP(2);
                 stress_delay(a.stress, 104u + 8u * (unsigned)k);
                 __syncthreads();                             // S3: the finished tile is in LDS
+                WSP(3);
             }
+        WSP_FLUSH(0);
         return;
     }
 
@@ -482,9 +625,11 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     stress_delay(stress, 200u);
     __syncthreads();                                         // S0
     int pmt = -1, pnt = 0, pk = 0;                           // finished tile waiting in LDS (pk: its last item)
+    WSP_DECL;
     for (int k = 0; k < nitems; ++k) {
         if (stress > 0) stress_delay(stress, 204u + 8u * (unsigned)k);
         if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1, k + 1); }
+        WSP(0); WSP_COUNT();
         if (pmt >= 0) load_acc(pmt, pnt);
         if (k + 2 < nitems && dbg != 5) {
             decode(k + 2, mtn, ntn, chn);
@@ -492,19 +637,24 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             if (!staged_skip && dbg != 2) load_item(mtn, chn);
             else if constexpr (MODE == SRC2_SCALED) hist_set(k + 2, hist_get(k));      // (the same planes, the same image, the same scale)
         }
+        WSP(1);
         if (stress > 0) stress_delay(stress, 201u + 8u * (unsigned)k);
         if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt, pk); pmt = -1; }
+        WSP(2);
         if (stress > 0) stress_delay(stress, 202u + 8u * (unsigned)k);
         __syncthreads();                                     // S1
+        WSP(3);
         if (ch == nch - 1) {
-            __syncthreads();                                 // S2
+            if constexpr (KSPLIT) __syncthreads();           // S2
             if (stress > 0) stress_delay(stress, 203u + 8u * (unsigned)k);
             __syncthreads();                                 // S3
+            WSP(4);
             pmt = mt; pnt = nt; pk = k;
         }
         if (k + 1 < nitems) decode(k + 1, mt, nt, ch);
     }
     if (pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
+    WSP_FLUSH(1);
 }
 
 }  // namespace cindm

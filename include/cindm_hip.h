@@ -46,6 +46,11 @@ const char* cindm_last_error(void);
  * cindm_amd/build.py: the Python face refuses a library whose hash differs from the sources next to it. */
 const char* cindm_source_hash(void);
 
+/* In-kernel phase clocks of the persistent 2-D convolution kernel (cindm_amd/csrc/kernels2d_v2.h), profiling build only
+ * (libcindm_hip_prof.so): copies [8 categories][2 roles][8 phases] sums of 10 ns ticks (128 words) to dst and clears them.
+ * Returns 1 in the profiling build, 0 in the production build (zeros), -1 on error.  No reference counterpart (a tool). */
+int cindm_ws_prof_read(unsigned long long* dst);
+
 /* ------------------------------------------------------------------ TemporalUnet1D
  * Replaces TemporalUnet1D.__init__/forward, model/diffusion_1d.py:517-646, and the blocks it
  * is built from: SinusoidalPosEmb :146, Conv1dBlock :197, ResidualTemporalBlock :483,

@@ -168,6 +168,19 @@ def test_no_cpu_fallback():
     assert float(coefs[:, 2].abs().max()) == 0.0     # eta = 0: sigma = 0
 
 
+def test_package_never_imports_the_reference():
+    """No module of the product package imports the reference checkout (its top-level modules are utils, model, inference,
+    dataset, ...): `grep -rn "^ *from utils\|import utils" cindm_amd/` is empty, and so for the other reference packages."""
+    import re
+    pkg = os.path.join(ROOT, "cindm_amd")
+    pat = re.compile(r"^\s*(from|import)\s+(utils|model|inference|dataset|cindm)(\.|\s|$)", re.M)
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not pat.search(src), fn
+            assert "/root/reference" not in src, fn
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "cindm_amd")
     for fn in os.listdir(pkg):
@@ -329,8 +342,10 @@ def test_eval_simu_golden(gold_dir):
         assert pred.shape == (cond.shape[0], roll, nb * 4)
         assert torch.equal(pred, torch.from_numpy(g[f"{tag}.pred"])), tag
         assert float(obj) == float(g[f"{tag}.obj"]), tag
-    with pytest.raises(RuntimeError, match="pymunk"):
+    with pytest.raises(TypeError):                   # the simulator is a required keyword: no default, no import of the reference
         eval_simu(torch.zeros((1, 1, 8)), design_fn, 2, 3)
+    with pytest.raises(TypeError, match="pymunk"):
+        eval_simu(torch.zeros((1, 1, 8)), design_fn, 2, 3, simulation=None)
 
 
 def test_get_item_1d_matches_reference_formula():
@@ -438,31 +453,51 @@ def test_bench_spawns_one_rank_per_gpu(monkeypatch):
     assert not calls
 
 
-def test_bench_line_of_an_eight_rank_world(monkeypatch):
-    """The fields the driver reads from an N-rank line, computed exactly as bench.py computes them, from a mocked world of 8
-    (no GPU here): n_gpus = 8, designs_per_step = 8 x 256 = 2048, parallelism dp8, value = ALL ranks' designs / the slowest
-    rank's time, scaling weak; the compact per-workload record keeps them."""
+def test_bench_line_of_an_eight_rank_world():
+    """The N-rank line from bench.py's own line builder (a pure function of what was measured), for a world of 8 and -- config 4's
+    "1024 designs over 8 GPUs" -- 128 designs per rank: n_gpus, designs_per_step, parallelism, value = ALL ranks' designs / the
+    slowest rank's time, weak scaling; the compact per-workload record keeps them."""
     import importlib
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
-    world, B, steps, elapsed, S = 8, bench.BATCH, 20, 7.2, bench.TIMESTEPS
-    total = B * world
-    value = total * steps / elapsed
-    line = {"metric": "design samples/sec (1000-step DDPM, composed U-Nets); rel-err vs CPU ref", "value": round(value, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": steps, "warmup": 5, "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "config": {"workload": "w", "designs_per_step": total, "unet_evals_per_design": S, "reverse_steps_per_design": S,
-                       "parallelism": f"dp{world} (design-sharded, one all-gather of final designs)"},
-            "us_per_reverse_step": round(elapsed / (steps * S) * 1e6, 1), "roofline": None}
+    line = bench.bench_line_1d(8, bench.BATCH, 20, 5, 7.2, "w", bench.TIMESTEPS, (1, 0), None)
     assert line["n_gpus"] == 8 and line["config"]["designs_per_step"] == 2048 and line["config"]["parallelism"].startswith("dp8")
-    assert abs(line["value"] - 8 * 256 * 20 / 7.2) < 0.01
+    assert abs(line["value"] - 8 * 256 * 20 / 7.2) < 0.01 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert abs(line["ms_per_step"] - 360.0) < 1e-9 and abs(line["us_per_reverse_step"] - 360.0) < 1e-9
     c = bench.compact(line)
     assert c["value"] == line["value"] and c["designs_per_chain"] == 2048 and c["chains_timed"] == 20 and c["cpu_baseline"] is None
-    # the source computes these fields the same way (guards the formulas against edits)
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    for needle in ('total = B * world', 'value = total * chains / elapsed', '"n_gpus": world', '"designs_per_step": total',
-                   'f"dp{world} (design-sharded, one all-gather of final designs)"', 'dist.all_reduce(tmax, op=dist.ReduceOp.MAX)',
-                   'init_process_group("nccl"'):
-        assert needle in src, needle
+    one = bench.bench_line_1d(1, bench.BATCH, 20, 5, 7.2, "w", bench.TIMESTEPS, (1, 0), None)
+    assert abs(line["value"] / one["value"] - 8.0) < 1e-3           # same per-rank time: 8 x the designs
+    cfg4 = bench.bench_line_1d(8, 128, 3, 1, 5.0, "w", 400, (6, 4), None)
+    assert cfg4["config"]["designs_per_step"] == 1024 and cfg4["config"]["unet_evals_per_design"] == 4000
+
+
+def test_cpu_leg_is_self_consistent():
+    """bench.py's CPU leg (round 4: the timed leg was 2.1 x slower than the sweep's value at the same thread count, three times
+    over): every thread count of the sweep and the timed leg run in their own child process with the count fixed in the
+    environment, and the timed leg's per-step time must be within 1.3 x of the sweep's at the chosen count."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    sd = O.synth_state_dict(O.unet1d_param_shapes(24, 8, attention=True), seed=0)
+    spec = {"kind": "1d", "workload": "cfg2", "B": 8, "out_shape": (24, 8), "sd": sd}
+    ratio = None
+    for attempt in range(3):                      # (a shared 8-core container: a neighbour's burst can hit one measurement)
+        best, sweep, res = bench.run_cpu_leg(spec, budget_s=3.0, counts=(2, 4))
+        assert best in (2, 4) and set(sweep) == {2, 4} and res["threads_seen"] == best
+        assert len(res["per"]) == 3 and res["n"] == len(res["tape"]) and res["tape"][0][0] == 500
+        rec = bench.cpu_leg_record(8 / (res["dt"] * 1000), best, sweep, res, "test")
+        ratio = rec["timed_vs_sweep_at_cores"]
+        if 1 / 1.3 <= ratio <= 1.3:
+            break
+    assert 1 / 1.3 <= ratio <= 1.3, (ratio, sweep, res["per"])
+    # the tape replays: the same steps from x0 give the child's final state
+    x0, draw, step, t_first = bench.cpu_leg_make_step(dict(spec))
+    x = res["x0"].clone()
+    with torch.no_grad():
+        for k, (t, nz) in enumerate(res["tape"][:2]):
+            x = step(x, k, nz)
+    assert torch.equal(res["x0"], x0) and bool(torch.isfinite(x).all())
 
 
 def test_bench_cpu_leg_takes_the_best_of_three_repetitions():
