@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 _lib = None
-ABI_VERSION = 2          # == CINDM_ABI_VERSION of include/cindm_hip.h (tests/test_host_logic.py keeps the two in step)
+ABI_VERSION = 3          # == CINDM_ABI_VERSION of include/cindm_hip.h (tests/test_host_logic.py keeps the two in step)
 
 
 class CindmError(RuntimeError):
@@ -67,6 +67,13 @@ SIGNATURES = {
     "cindm_last_error": (C.c_char_p, []),
     "cindm_source_hash": (C.c_char_p, []),
     "cindm_ws_prof_read": (C.c_int, [_vp]),
+    "cindm_forceunet_status": (C.c_int, [_vp, _vp]),
+    "cindm_forceunet_recovered": (C.c_int, [_vp]),
+    "cindm_comm_unique_id": (C.c_int, [_vp]),
+    "cindm_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "cindm_comm_world": (C.c_int, [_vp]),
+    "cindm_all_gather_designs": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "cindm_comm_destroy": (None, [_vp]),
     "cindm_unet1d_status": (C.c_int, [_vp, _vp]),
     "cindm_unet1d_poll": (C.c_int, [_vp, _vp]),
     "cindm_unet1d_recovered": (C.c_int, [_vp]),

@@ -2556,3 +2556,71 @@ extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint
 // ============================================================================ 2-D airfoil path
 #include "unet2d_host.inc"
 #include "forceunet_host.inc"
+
+// ---- multi-GPU: the one all-gather of the path, on RCCL (include/cindm_hip.h) -----------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+};
+// One RCCL per process: the copy that is already mapped (PyTorch-ROCm ships its own librccl.so and torch.distributed's "nccl"
+// backend uses it), else the ROCm installation's.
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so", "librccl.so.1"}) { a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (a.lib) break; }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { if (a.lib) break; a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); }
+        if (!a.lib) { a.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return a; }
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
+        a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+        if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) a.why = "librccl.so lacks an expected symbol";
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+struct cindm_comm { ncclComm_t comm = nullptr; int world = 0, rank = 0; };
+#define RCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(std::string(#x) + ": " + rccl().GetErrorString(r_)); } while (0)
+
+extern "C" int cindm_comm_unique_id(unsigned char id[128]) {
+    REQUIRE(id, "null argument");
+    REQUIRE(rccl().why.empty(), rccl().why);
+    ncclUniqueId u;
+    RCCLCHK(rccl().GetUniqueId(&u));
+    static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id, &u, 128);
+    return 0;
+}
+extern "C" int cindm_comm_init(const unsigned char id[128], int32_t world, int32_t rank, cindm_comm** out) {
+    REQUIRE(id && out && world >= 1 && rank >= 0 && rank < world, "bad communicator arguments");
+    REQUIRE(rccl().why.empty(), rccl().why);
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    auto* c = new cindm_comm();
+    c->world = world; c->rank = rank;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r)); }
+    *out = c;
+    return 0;
+}
+extern "C" int cindm_comm_world(const cindm_comm* c) { return c ? c->world : 0; }
+extern "C" int cindm_all_gather_designs(const float* local, float* out, int64_t per_rank_elems, cindm_comm* c, void* stream) {
+    REQUIRE(local && out && c && c->comm && per_rank_elems > 0, "bad all-gather arguments");
+    RCCLCHK(rccl().AllGather(local, out, (size_t)per_rank_elems, ncclFloat, c->comm, (hipStream_t)stream));
+    return 0;
+}
+extern "C" void cindm_comm_destroy(cindm_comm* c) {
+    if (!c) return;
+    if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void fu_la_dctx_merge_kernel(const float* __re
 template <int C, int NPX, int MINB = 1>
 __global__ __launch_bounds__(256, MINB) void fu_la_bwd_a_kernel(const FuLaArgs a) {
     using LN = LnTile<C, NPX>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 32, APB = 2 * 128 + 32, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4, KC4 = C / 4;
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4, KC4 = C / 4;
     constexpr int QP = 33;                                   // pitch of the per-wave [pixel][32] fp32 tiles
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];       // y planes -> z -> dz (fp32 [pixel][ZP])
     __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NPX * APB];       // att planes -> dq (fp32 [128][NPX])
@@ -442,9 +442,9 @@ __global__ __launch_bounds__(256, MINB) void fu_la_bwd_a_kernel(const FuLaArgs a
 template <int C, int NPX, int MINB = 1>
 __global__ __launch_bounds__(256, MINB) void fu_la_bwd_b_kernel(const FuLaArgs a) {
     using LN = LnTile<C, NPX>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 32, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4;
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = NPX / 16, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];       // y planes -> dy (fp32 [pixel][ZP])
-    constexpr int GPB = 2 * 256 + 32;                        // bytes per pixel and plane of the [dk | dv] planes
+    constexpr int GPB = 2 * 256 + 16;                        // bytes per pixel and plane of the [dk | dv] planes
     __shared__ __attribute__((aligned(16))) unsigned char Gp[2][NPX * GPB];       // dk (channels 0..127) | dv (128..255) of every head, scaled split-fp16
     __shared__ float PM[4][NPX];                                                  // per-head max(|dk|, |dv|) of a pixel
     static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "dy aliases the y planes");

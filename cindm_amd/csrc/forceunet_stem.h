@@ -128,7 +128,7 @@ __device__ __forceinline__ float pow2_of_exp(int se) { return __builtin_bit_cast
 // accumulated in the MFMAs' own accumulators (one scale per 7-row window, accumulators rescaled when it moved) was no faster
 // and lost bits of a small row that follows a much larger one within six rows (`tools/micro/stem_bwd.hip --check`).
 __global__ __launch_bounds__(256) void fu_stem_bwd_h3_kernel(const FuStemBwdH3Args a) {
-    constexpr int WD = 64, RO = 16, NR = RO + 6, PB = 160, TP = 33;      // PB = 32 (mod 64) bytes: conflict-free ds_read_b128 fragments (kernels2d_v2.h, V2PITCH)
+    constexpr int WD = 64, RO = 16, NR = RO + 6, PB = 144, TP = 33;
     __shared__ __attribute__((aligned(16))) unsigned char Gp[2][2][WD * PB];       // [buffer][plane][pixel][64 halfs + pad]
     __shared__ float Ts[2][WD * TP];
     __shared__ float red[2][4];

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_h3_kernel(const Conv2dArgs a) {
 // over nh = w >> 1 -- the same (k-group, column half) structure and epilogue as conv2d_h3_kernel.
 constexpr int STEM3_NI = 25;             // tap slots per wave pair (the 25th of the odd pair is a zero pad)
 __global__ __launch_bounds__(256, 2) void conv2d_stem7_h3_kernel(const Conv2dArgs a) {
-    constexpr int SW = 22, SH = 10, R = SW * SH, PITCH = 96, PLANE = R * PITCH, NP = (R * 8 + 255) / 256;      // pitch = 32 (mod 64) bytes: conflict-free ds_read_b128 fragments (kernels2d_v2.h, V2PITCH)
+    constexpr int SW = 22, SH = 10, R = SW * SH, PITCH = 80, PLANE = R * PITCH, NP = (R * 8 + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned char planes[2 * PLANE];
     __shared__ __attribute__((aligned(16))) float Red[4][T2M * LDR2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256) void tail_identity_kernel(const Conv2dArgs a) 
 // Weights: [n-tile][k-step][plane][thread = wave * 64 + lane][8 halfs] = W[n = tile*64 + wave*16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e].
 template <int KT>
 __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArgs a) {
-    constexpr int KS = KT / 32, PITCH = KT * 2 + 32, F4 = KT / 4, NPASS = (64 * F4) / 256;      // pitch = 32 (mod 64) bytes: conflict-free ds_read_b128 fragments (kernels2d_v2.h, V2PITCH)
+    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
     static_assert((64 * F4) % 256 == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
     __shared__ float tabE[16];
@@ -1500,7 +1500,7 @@ constexpr int la2_px(int C) { return C == 64 ? LA2_PX : LA2_PX / 2; }
 // columns 4*lcol.. of rows r*RPP + lrow) -> (hi, scaled lo) fp16 planes
 template <int C, int NPX>
 struct LnTile {
-    static constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 32;
+    static constexpr int LPR = C / 4, RPP = 256 / LPR, NPASS = NPX / RPP, YPB = 2 * C + 16;
     __device__ static __forceinline__ void load(float4 (&xr)[NPASS], const float* __restrict__ x0, int ldx, int tid) {
         const int lrow = tid / LPR, lcol = tid % LPR;
 #pragma unroll
@@ -1534,7 +1534,7 @@ template <int C>
 __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
     constexpr int PX = la2_px(C);
     using LN = LnTile<C, PX>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 32, NTL = PX / 16;
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = PX / 16;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][PX * YPB];
     __shared__ float fac[4][32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict
 template <int C>
 __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
     using LN = LnTile<C, 64>;
-    constexpr int K32 = C / 32, YPB = 2 * C + 32, APB = 2 * 128 + 32, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
+    constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];
     __shared__ __attribute__((aligned(16))) unsigned char Ap[2][NPX * APB];
     static_assert(NPX * ZP * 4 <= 2 * NPX * YPB, "Z aliases the y planes");
@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 // accumulators hold the probabilities -- are contiguous: P goes from the accumulators into the second product with
 // no data movement.  The exponentials and the fp16 splits of P are now the dominant work (VALU), not the MFMAs.
 __global__ __launch_bounds__(256, 2) void attn_full_h3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
-    constexpr int KPB = 96, VPB = 160;                   // bytes per key row (32 d) / per d row (64 key slots), padded to 32 (mod 64): conflict-free ds_read_b128
+    constexpr int KPB = 80, VPB = 144;                   // bytes per key row (32 d) / per d row (64 key slots), padded
     __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][64 * KPB];     // [buffer][plane]
     __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][32 * VPB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2081,6 +2081,171 @@ __global__ __launch_bounds__(256, 2) void attn_full_h3_kernel(const float* __res
     }
 }
 
+// attn_full_h3b_kernel (round 5): attn_full_h3_kernel with 128 queries per workgroup (a wave owns TWO 16-query blocks) and the V tile
+// transposed through registers instead of through 2-byte LDS stores.  What the counters said about attn_full_h3_kernel
+// (profiles/r05_lds_conflicts_before.txt): SQ_LDS_IDX_ACTIVE = 98 M cycles per launch = 190 us of LDS time per CU in a 340 us launch,
+// 61 % of it bank conflicts -- the kernel is LDS-bound, and half of that is the sixteen ds_write_b16 per thread and chunk that
+// transpose V ([key][d] in memory, [d][key slot] for the MFMA).  Here (1) a slot quad of the second product is four CONSECUTIVE keys
+// (slot_of's inverse), so thread (d, slot quad) gathers V[key0 .. key0 + 3][d] with four 4-byte loads (a wave instruction still
+// covers whole 128-byte rows: d is the fastest lane index) and writes ONE 8-byte row segment per plane; (2) every K / V fragment
+// read from LDS feeds two query blocks, and a chunk is staged once per 128 queries instead of once per 64.
+__global__ __launch_bounds__(256, 2) void attn_full_h3b_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n) {
+    constexpr int KPB = 80, VPB = 144;                   // bytes per key row (32 d) / per d row (64 key slots), padded
+    __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][64 * KPB];     // [buffer][plane]
+    __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][32 * VPB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {                          // the query blocks of an (image, head) on one XCD: K / V come from its L2
+            const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const int j = (lin & 7) * (total >> 3) + (lin >> 3);
+            by = j / (int)gridDim.x; bx = j - by * (int)gridDim.x;
+        }
+    }
+    const int ih = by, img = ih >> 2, h = ih & 3;
+    const int q0 = bx * 128 + w * 32;
+    const float* base = qkv + (size_t)img * n * 384;
+    const int lq = lane & 15, lg = lane >> 4;
+    half8 qh[2], ql[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* qp = base + (size_t)(q0 + 16 * j + lq) * 384 + h * 32 + lg * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+        const float sc = 0.17677669529663687f * 1.4426950408889634f;
+        const float v[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qh[j][e] = (_Float16)v[e]; ql[j][e] = (_Float16)((v[e] - (float)qh[j][e]) * H3_SCALE); }
+    }
+    // K staging: keys sr, sr + 32; d = sc4*4 .. +3
+    const int sr = tid >> 3, sc4 = tid & 7;
+    // V staging: d = vd, slot quads vq and vq + 8 (slots 4 vq .. and 32 + 4 vq ..) = keys vk0 .. vk0 + 3 and vk0 + 32 ..
+    const int vd = tid & 31, vq = tid >> 5;
+    const int vk0 = (vq & 1) * 16 + (vq >> 1) * 4;
+    float4 kr0, kr1;
+    float vv[2][4];
+    auto load_kv = [&](int k0) {
+        const float* rp = base + (size_t)(k0 + sr) * 384 + h * 32 + sc4 * 4 + 128;
+        kr0 = *reinterpret_cast<const float4*>(rp);
+        kr1 = *reinterpret_cast<const float4*>(rp + 32 * 384);
+        const float* vp = base + (size_t)(k0 + vk0) * 384 + h * 32 + vd + 256;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vv[u][i] = vp[(size_t)(32 * u + i) * 384];
+    };
+    auto store_kv = [&](int buf) {
+        auto split4 = [](const float (&f)[4], half4v& hi, half4v& lo) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)f[i]; lo[i] = (_Float16)((f[i] - (float)hi[i]) * H3_SCALE); }
+        };
+        half4v hi, lo;
+        { const float f[4] = {kr0.x, kr0.y, kr0.z, kr0.w}; split4(f, hi, lo); }
+        *reinterpret_cast<half4v*>(&Kp[buf][0][sr * KPB + sc4 * 8]) = hi;
+        *reinterpret_cast<half4v*>(&Kp[buf][1][sr * KPB + sc4 * 8]) = lo;
+        { const float f[4] = {kr1.x, kr1.y, kr1.z, kr1.w}; split4(f, hi, lo); }
+        *reinterpret_cast<half4v*>(&Kp[buf][0][(sr + 32) * KPB + sc4 * 8]) = hi;
+        *reinterpret_cast<half4v*>(&Kp[buf][1][(sr + 32) * KPB + sc4 * 8]) = lo;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            split4(vv[u], hi, lo);
+            *reinterpret_cast<half4v*>(&Vp[buf][0][vd * VPB + (32 * u + 4 * vq) * 2]) = hi;
+            *reinterpret_cast<half4v*>(&Vp[buf][1][vd * VPB + (32 * u + 4 * vq) * 2]) = lo;
+        }
+    };
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    f32x4 oM[2][2], oL[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { oM[j][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; oL[j][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    const int nchunk = n >> 6;
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        load_kv(min(c + 1, nchunk - 1) << 6);
+        __builtin_amdgcn_sched_barrier(0);
+        // S^T tiles: rows = keys 16*mb + 4*lg + rg, cols = queries of block j
+        float pr[2][4][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int off = (mb * 16 + lq) * KPB + lg * 16;
+            const half8 kh = *reinterpret_cast<const half8*>(&Kp[buf][0][off]);
+            const half8 kl = *reinterpret_cast<const half8*>(&Kp[buf][1][off]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 sM = (f32x4){0.f, 0.f, 0.f, 0.f}, sL = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[j], sM, 0, 0, 0);
+                sL = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[j], sL, 0, 0, 0);
+                sL = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[j], sL, 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) pr[j][mb][rg] = sM[rg] + sL[rg] * H3_INV;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float mx = pr[j][0][0];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, pr[j][mb][rg]);
+            mx = xmax32(xmax16(mx));
+            const float mn = fmaxf(m[j], mx);
+            const float corr = __builtin_amdgcn_exp2f(m[j] - mn);
+            m[j] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) { pr[j][mb][rg] = __builtin_amdgcn_exp2f(pr[j][mb][rg] - mn); ps += pr[j][mb][rg]; }
+            l[j] = l[j] * corr + ps;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) { oM[j][db] *= corr; oL[j][db] *= corr; }
+        }
+        // O^T[d][q] += V^T[d][slots] P[slots][q], two k-steps of 32 key slots; a V fragment feeds both query blocks
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            half8 ph[2], pl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = pr[j][2 * st + (e >> 2)][e & 3];
+                    ph[j][e] = (_Float16)p;
+                    pl[j][e] = (_Float16)((p - (float)ph[j][e]) * H3_SCALE);
+                }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int off = (db * 16 + lq) * VPB + st * 64 + lg * 16;
+                const half8 vh = *reinterpret_cast<const half8*>(&Vp[buf][0][off]);
+                const half8 vl = *reinterpret_cast<const half8*>(&Vp[buf][1][off]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    oM[j][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[j], oM[j][db], 0, 0, 0);
+                    oL[j][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], oL[j][db], 0, 0, 0);
+                    oL[j][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[j], oL[j][db], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_kv(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float lt = xsum32(xsum16(l[j]));
+        const float inv = 1.0f / lt;
+        float* op = out + ((size_t)img * n + q0 + 16 * j + lq) * 128 + h * 32 + lg * 4;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const f32x4 o = (oM[j][db] + oL[j][db] * H3_INV) * inv;
+            *reinterpret_cast<float4*>(op + db * 16) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // DDPM update with boundary sharing (share_states_over_boundaries :712-725, p_mean_variance :757-773, p_sample
 // :804-808): one thread per state element of x [B*nb, HW, C] (channel-last).  The model output's state channels
@@ -2090,6 +2255,7 @@ struct Update2dArgs {
     const float* x; const float* eps; float* x_out; float* x0_out; float* mean_out;
     int B; int nb, HW, C, CP, use_avg, clip, add_noise;     // C logical channels (21), CP padded row pitch (24)
     const float* sqrt_recip; const float* sqrt_recipm1; const float* coef1; const float* coef2; const float* logvar;
+    const float* sqrt_ac; const float* sqrt_1mac;           // sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod): objective pred_v
     const int* t_ptr; int t_imm;
     const float* noise_state; int64_t ns_t_stride;      // [B, HW, C-3] (+ t * stride) or null
     const float* noise_bound; int64_t nb_t_stride;      // [B*nb, HW, 3]
@@ -2121,13 +2287,23 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
         const int b = bp / a.HW;
         const int c0 = 4 * g, Cs = a.C - 3;
         const float ra = a.sqrt_recip[t], rb = a.sqrt_recipm1[t], k1 = a.coef1[t], k2 = a.coef2[t];
+        // objective (bits 4-5 of use_avg; model_predictions :743-753): 0 = the model predicts the noise, 1 = x_start itself, 2 = v
+        // (x_start = sqrt(abar) x - sqrt(1 - abar) v).  For 1 and 2 the reference shares nothing inside model_predictions and
+        // ALWAYS re-derives the noise from the (clamped) x_start.
+        const int obj = (a.use_avg >> 4) & 3;
+        const float sa = obj == 2 ? a.sqrt_ac[t] : 0.f, sm = obj == 2 ? a.sqrt_1mac[t] : 0.f;
+        auto x0_of = [&](float xv, float e) -> float {
+            float x0 = obj == 0 ? __fsub_rn(__fmul_rn(ra, xv), __fmul_rn(rb, e)) : obj == 1 ? e : __fsub_rn(__fmul_rn(sa, xv), __fmul_rn(sm, e));
+            if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            return x0;
+        };
         const float sigma = (a.add_noise && t > 0) ? expf(0.5f * a.logvar[t]) : 0.f;
         const bool noisy = a.add_noise && t > 0;
         // shared prediction of the state channels: mean (or sum) over the boundary copies
         // use_avg bit 1 = share_noise False (p_mean_variance :757-773): the prediction is NOT shared; the clamped x_start of the
         // state channels is (x0s), and then the posterior mean computed from it (ms)
-        const bool nopred = (a.use_avg & 2) != 0, avg = (a.use_avg & 1) != 0;
-        const bool late = nopred && !a.predict;
+        const bool nopred = (a.use_avg & 2) != 0 || obj != 0, avg = (a.use_avg & 1) != 0;
+        const bool late = (a.use_avg & 2) != 0 && !a.predict;
         float es[4] = {0.f, 0.f, 0.f, 0.f}, x0s[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f};
         if (c0 < Cs) {
             const float inv = (float)a.nb;
@@ -2139,11 +2315,7 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
                 const float4 x4 = *reinterpret_cast<const float4*>(a.x + o);
                 const float ev[4] = {e.x, e.y, e.z, e.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x0 = __fsub_rn(__fmul_rn(ra, xv[j]), __fmul_rn(rb, ev[j]));
-                    if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                    x0s[j] += x0;
-                }
+                for (int j = 0; j < 4; ++j) x0s[j] += x0_of(xv[j], ev[j]);
             }
             if (!nopred && avg) { es[0] /= inv; es[1] /= inv; es[2] /= inv; es[3] /= inv; }
             if (late) {
@@ -2189,15 +2361,14 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + j;
                 const float e = (c < Cs && !nopred) ? es[j] : ev[j];
-                float x0 = __fsub_rn(__fmul_rn(ra, xv[j]), __fmul_rn(rb, e));
-                if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                float x0 = x0_of(xv[j], e);
                 float mean = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xv[j]));
                 if (late && c < Cs) { x0 = x0s[j]; mean = ms[j]; }
                 const float z = (c < Cs) ? zs[j] : zb[j];
                 const bool real = c < a.C;
                 r0[j] = real ? x0 : 0.f; rm[j] = real ? mean : 0.f;
                 rx[j] = real ? (noisy ? mean + sigma * z : mean) : 0.f;
-                re[j] = real ? (a.rederive ? __fsub_rn(__fmul_rn(ra, xv[j]), x0) / rb : e) : 0.f;
+                re[j] = real ? ((a.rederive || obj != 0) ? __fsub_rn(__fmul_rn(ra, xv[j]), x0) / rb : e) : 0.f;
             }
             if (a.eps_out) *reinterpret_cast<float4*>(a.eps_out + o) = make_float4(re[0], re[1], re[2], re[3]);
             if (a.x0_out) *reinterpret_cast<float4*>(a.x0_out + o) = make_float4(r0[0], r0[1], r0[2], r0[3]);

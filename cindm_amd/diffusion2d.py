@@ -8,8 +8,7 @@ What runs where
     step replayed per timestep), the state staying in the library's channel-last layout for the whole chain;
   * ``design_fn`` is a user Python callable returning a gradient tensor (:813); it is evaluated between library
     calls, exactly where the reference evaluates it.
-Training, DDIM, self-conditioning and objectives other than pred_noise are outside this build's scope and raise
-NotImplementedError.
+Training, DDIM and self-conditioning are outside this build's scope and raise NotImplementedError.
 """
 import ctypes as C
 from collections import namedtuple
@@ -57,8 +56,8 @@ class GaussianDiffusion(nn.Module):
         super().__init__()
         assert model.channels == model.out_dim
         assert not model.random_or_learned_sinusoidal_cond
-        if objective != "pred_noise":
-            raise NotImplementedError("only objective='pred_noise' is built (the airfoil checkpoints' objective)")
+        if objective not in _ffi.OBJECTIVES:
+            raise ValueError("objective must be either pred_noise (predict noise) or pred_x0 (predict image start) or pred_v (predict v)")
         if schedule_fn_kwargs or min_snr_loss_weight:
             raise NotImplementedError("schedule_fn_kwargs / min_snr_loss_weight only matter for training")
         self.model = model
@@ -102,8 +101,9 @@ class GaussianDiffusion(nn.Module):
 
     def _share_mode(self):
         """The library's ``use_average_share`` word: bit 0 = mean (1) / sum (0) over the boundary copies of a design, bit 1 =
-        share_noise False -- the clamped x_start and the posterior mean are shared instead of the prediction (:757-773)."""
-        return int(bool(self.use_average_share)) | (0 if self.share_noise else 2)
+        share_noise False -- the clamped x_start and the posterior mean are shared instead of the prediction (:757-773); bits 4-5 =
+        the objective (pred_noise / pred_x0 / pred_v, :743-753)."""
+        return int(bool(self.use_average_share)) | (0 if self.share_noise else 2) | (_ffi.OBJECTIVES[self.objective] << 4)
 
     # ------------------------------------------------------------------ library handle
     def _handle(self):
@@ -199,7 +199,7 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def model_predictions(self, shape, x, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, share_noise=True):
-        """:727-754 (objective pred_noise).  x [B*nb, C, H, W] -> ModelPrediction(pred_noise, pred_x_start): the Unet's output
+        """:727-754 (all three objectives).  x [B*nb, C, H, W] -> ModelPrediction(pred_noise, pred_x_start): the Unet's output
         with its state channels shared over the boundary copies of a design (``share_noise``; mean or sum by
         ``use_average_share``), x_start = predict_start_from_noise (clamped when ``clip_x_start``), and with
         ``clip_x_start and rederive_pred_noise`` the noise re-derived from the clamped x_start.  One library call
@@ -215,7 +215,8 @@ class GaussianDiffusion(nn.Module):
         eps, x0 = torch.zeros_like(xd), torch.zeros_like(xd)
         h, ws = self._prepare(B * nb, x.device)
         with torch.cuda.device(x.device):
-            _ffi.check(_ffi.lib().cindm_ddpm2d_predict(h, self.model._h, _ffi.ptr(xd), B, nb, int(bool(self.use_average_share)),
+            _ffi.check(_ffi.lib().cindm_ddpm2d_predict(h, self.model._h, _ffi.ptr(xd), B, nb,
+                                                       int(bool(self.use_average_share)) | (_ffi.OBJECTIVES[self.objective] << 4),
                                                        int(bool(share_noise)), int(bool(clip_x_start)), int(bool(rederive_pred_noise)),
                                                        ti, None, _ffi.ptr(eps), _ffi.ptr(x0), _ffi.ptr(ws), ws.numel(),
                                                        _ffi.current_stream(x.device)))

@@ -1,7 +1,8 @@
 """Multi-GPU sampling: the design batch is embarrassingly parallel (every design is an independent
 Markov chain), so it is partitioned into contiguous slices, one process per GPU, with
-NO communication inside the reverse loop and ONE all-gather (RCCL over xGMI; backend "nccl" on ROCm,
-"gloo" in the CPU tests) of the final designs.  Noise is keyed by the GLOBAL sample index
+NO communication inside the reverse loop and ONE all-gather of the final designs: the library's own
+``cindm_all_gather_designs`` (ncclAllGather of librccl over xGMI, include/cindm_hip.h) when the process group's backend is
+"nccl" (= RCCL on ROCm), ``torch.distributed`` over gloo in the CPU tests.  Noise is keyed by the GLOBAL sample index
 (``sample_offset``), so the gathered result does not depend on the number of ranks.
 The reference has no counterpart (its inference scripts are single-device)."""
 import torch
@@ -15,8 +16,63 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_designs(local, total, group=None):
-    """Gathers per-rank [B_r, L, F] slices (in rank order) into [total, L, F] on every rank."""
+_COMMS = {}          # process group -> RcclComm (the library's own communicator: one per group, made on first use)
+
+
+class RcclComm:
+    """The library's RCCL communicator (include/cindm_hip.h: cindm_comm_*): rank 0 makes the 128-byte unique id with
+    ``ncclGetUniqueId``, the id travels over the torch.distributed group the caller already has, every rank calls
+    ``ncclCommInitRank`` on its current device.  ``all_gather(local)`` is ONE ``ncclAllGather`` on the current stream."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _ffi
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _ffi.check(_ffi.lib().cindm_comm_unique_id(buf))
+        box = [bytes(buf)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().cindm_comm_init(idb, world, rank, C.byref(h)))
+        self._h, self.world, self.rank = h, world, rank
+
+    def all_gather(self, local):
+        """local: contiguous float32 CUDA tensor, the same shape on every rank -> [world, *local.shape]."""
+        from . import _ffi
+        assert local.is_cuda and local.dtype == torch.float32 and local.is_contiguous()
+        out = torch.empty((self.world,) + tuple(local.shape), device=local.device, dtype=torch.float32)
+        with torch.cuda.device(local.device):
+            _ffi.check(_ffi.lib().cindm_all_gather_designs(_ffi.ptr(local), _ffi.ptr(out), local.numel(), self._h,
+                                                           _ffi.current_stream(local.device)))
+        return out
+
+    def close(self):
+        from . import _ffi
+        if self._h is not None and self._h.value:
+            _ffi.lib().cindm_comm_destroy(self._h)
+        self._h = None
+
+
+def rccl_comm(group=None):
+    key = group if group is not None else "world"
+    if key not in _COMMS:
+        _COMMS[key] = RcclComm(group)
+    return _COMMS[key]
+
+
+def close_comms():
+    """Destroys the library's communicators (before ``dist.destroy_process_group``)."""
+    for c in _COMMS.values():
+        c.close()
+    _COMMS.clear()
+
+
+def all_gather_designs(local, total, group=None, use_library=True):
+    """Gathers per-rank [B_r, L, F] slices (in rank order) into [total, L, F] on every rank.  On the RCCL backend with device
+    tensors this is the library's own ``cindm_all_gather_designs`` (one ncclAllGather over xGMI, SURVEY.md section 8b);
+    ``use_library=False`` and the gloo backend (CPU tests; several ranks sharing one GPU) go through ``torch.distributed``."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
@@ -26,6 +82,9 @@ def all_gather_designs(local, total, group=None):
     if local.shape[0] < maxb:
         pad = torch.cat([local, local.new_zeros((maxb - local.shape[0],) + tuple(local.shape[1:]))], 0)
     pad = pad.contiguous()
+    if use_library and pad.is_cuda and pad.dtype == torch.float32 and dist.get_backend(group) == "nccl":
+        out = rccl_comm(group).all_gather(pad)
+        return torch.cat([out[r, :hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
     # gloo (CPU tests, or several ranks sharing one GPU) has no device all_gather: stage through the host
     via_host = pad.is_cuda and dist.get_backend(group) == "gloo"
     send = pad.cpu() if via_host else pad

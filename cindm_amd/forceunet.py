@@ -35,6 +35,7 @@ class ForceUnet(nn.Module):
         h = C.c_void_p()
         _ffi.check(L.cindm_forceunet_create(C.byref(d), C.byref(h)))
         self._h, self._sig, self._ws = h, None, None
+        self._py_recovered = 0
         name = C.create_string_buffer(256)
         shape = (C.c_int64 * 4)()
         nd = C.c_int()
@@ -84,8 +85,43 @@ class ForceUnet(nn.Module):
         input-gradient 3x3 convolutions on the exact fp32 MFMA kernel, ``auto_range`` = 0 skips the range rule's calibration
         forward.  Takes effect at the next call."""
         _ffi.check(_ffi.lib().cindm_forceunet_set_option(self._h, key.encode(), int(value)))
-        self._sig = None
+        if key not in ("no_exchange", "recover", "dbg", "stress"):       # (run-time options: the packed weights stay valid)
+            self._sig = None
         return self
+
+    @property
+    def recovered(self):
+        """How many gradient calls / guided chains of this model were re-run on the exchange-free GroupNorm derivative after an
+        in-kernel exchange timed out (foreign load on the device); 0 in normal operation."""
+        return int(_ffi.lib().cindm_forceunet_recovered(self._h)) + self._py_recovered
+
+    def _checked(self, call, device):
+        """Runs ``call()`` (one library gradient call on the current stream) and hands its result back only after the handle's
+        exchange flag has been read: a timed-out exchange (NaN gradients) is re-run once with ``no_exchange`` = 1 -- or raised,
+        with ``recover`` = 0.  Skipped under stream capture (a capture cannot synchronise; the chain entry points check)."""
+        out = call()
+        if torch.cuda.is_current_stream_capturing():
+            return out
+        L = _ffi.lib()
+        st = L.cindm_forceunet_status(self._h, _ffi.current_stream(device))
+        if st < 0:
+            _ffi.check(st)
+        if st == 0:
+            return out
+        v = C.c_int32()
+        _ffi.check(L.cindm_forceunet_get_option(self._h, b"recover", C.byref(v)))
+        if not v.value:
+            raise _ffi.CindmError("an in-kernel exchange of the surrogate's GroupNorm derivative timed out (foreign load on the device)")
+        _ffi.check(L.cindm_forceunet_set_option(self._h, b"no_exchange", 1))
+        try:
+            out = call()
+            st = L.cindm_forceunet_status(self._h, _ffi.current_stream(device))
+        finally:
+            _ffi.check(L.cindm_forceunet_set_option(self._h, b"no_exchange", 0))
+        if st != 0:
+            raise _ffi.CindmError("an exchange timed out during the exchange-free re-run (internal error)")
+        self._py_recovered += 1
+        return out
 
     def get_option(self, key):
         """Current option value; ``get_option("range_fallback")`` is 1 after the calibration forward left fp16's range."""
@@ -119,11 +155,11 @@ class ForceUnet(nn.Module):
             dx = torch.empty_like(xd)
             if dout is not None:
                 do = dout.detach().to(device=x.device, dtype=torch.float32).reshape(n, 2).contiguous()
-                _ffi.check(L.cindm_forceunet_vjp(self._h, _ffi.ptr(xd), _ffi.ptr(do), _ffi.ptr(out), _ffi.ptr(dx), n,
-                                                 _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+                self._checked(lambda: _ffi.check(L.cindm_forceunet_vjp(self._h, _ffi.ptr(xd), _ffi.ptr(do), _ffi.ptr(out), _ffi.ptr(dx), n,
+                                                                       _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device))), x.device)
             else:
-                _ffi.check(L.cindm_forceunet_grad(self._h, _ffi.ptr(xd), float(lambda_force), _ffi.ptr(out), _ffi.ptr(dx), n,
-                                                  _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device)))
+                self._checked(lambda: _ffi.check(L.cindm_forceunet_grad(self._h, _ffi.ptr(xd), float(lambda_force), _ffi.ptr(out), _ffi.ptr(dx), n,
+                                                                        _ffi.ptr(ws), ws.numel(), _ffi.current_stream(x.device))), x.device)
         return out, dx.reshape(n, hh, ww, c).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x, x_self_cond=None):
@@ -192,7 +228,8 @@ class ForceObjective:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            _ffi.check(L.cindm_airfoil_design_grad(m._h, _ffi.ptr(xd), self.B, self.nb, self.frames, cp, self.p_min, self.p_max,
-                                                   self.lambda_force, self.lambda_overlap, self.factor, int(self.sum_boundary), _ffi.ptr(g),
-                                                   _ffi.ptr(self._ws), self._ws.numel(), _ffi.current_stream(x.device)))
+            m._checked(lambda: _ffi.check(L.cindm_airfoil_design_grad(m._h, _ffi.ptr(xd), self.B, self.nb, self.frames, cp, self.p_min, self.p_max,
+                                                                      self.lambda_force, self.lambda_overlap, self.factor, int(self.sum_boundary),
+                                                                      _ffi.ptr(g), _ffi.ptr(self._ws), self._ws.numel(),
+                                                                      _ffi.current_stream(x.device))), x.device)
         return from_device_layout(g, c, hh, ww)

@@ -34,7 +34,7 @@ extern "C" {
  * positional sum_boundary argument of cindm_airfoil_design_grad / cindm_ddpm2d_sample_force, and round 4's additions
  * (cindm_unet1d_poll, cindm_ddpm2d_predict, cindm_unet1d_phase_prof_*, option "no_exchange", cindm_unet1d_recovered).
  * A caller compiled against another version must not bind: compare cindm_abi_version() with this constant. */
-#define CINDM_ABI_VERSION 2
+#define CINDM_ABI_VERSION 3
 
 typedef struct cindm_unet1d cindm_unet1d;
 typedef struct cindm_ddpm1d cindm_ddpm1d;
@@ -370,13 +370,17 @@ size_t cindm_ddpm2d_workspace_bytes(const cindm_unet2d* u, int64_t images);
  * with z shared over the boundaries for the state channels (sample_noise :775-785).  z comes
  * from noise_state [B, H*W, C-3] / noise_boundary [B*nb, H*W, 3] when given, else from the
  * counter-based generator (seed, sample_offset + b, t).  In place on x.  Optional outputs:
- * x0_out (clamped x_start), mean_out (posterior mean), both [B*nb, H*W, CP]. */
+ * x0_out (clamped x_start), mean_out (posterior mean), both [B*nb, H*W, CP].
+ * Bits 4-5 of use_average_share carry the diffusion's objective (CINDM_OBJ_*; :743-753): pred_x0 takes the model output as
+ * x_start, pred_v takes x_start = sqrt(abar_t) x - sqrt(1 - abar_t) v; for both the reference shares nothing inside
+ * model_predictions (share_noise False still shares x_start and the mean afterwards) and re-derives the noise from x_start.
+ * The same word is used by cindm_ddpm2d_predict, cindm_ddpm2d_sample and cindm_ddpm2d_sample_force. */
 int  cindm_ddpm2d_step(cindm_ddpm1d* sched, cindm_unet2d* u, float* x, int64_t B, int32_t nb,
                        int32_t use_average_share, int32_t clip_denoised,
                        const float* noise_state, const float* noise_boundary, uint64_t seed,
                        int64_t sample_offset, int32_t t, const int32_t* t_dev, float* x0_out,
                        float* mean_out, void* ws, size_t ws_bytes, void* stream);
-/* GaussianDiffusion.model_predictions (:727-754, objective pred_noise) for B designs of nb boundaries: Unet on all
+/* GaussianDiffusion.model_predictions (:727-754; objective in bits 4-5 of use_average_share, see above) for B designs of nb boundaries: Unet on all
  * B*nb images; share_noise != 0: the model output's state channels are averaged (use_average_share = 1) or summed (0)
  * over the boundaries of a design (:732-733); x_start = predict_start_from_noise(x, t, pred_noise), clamped to [-1, 1]
  * when clip_x_start; rederive_pred_noise (with clip_x_start, :738-739): pred_noise = predict_noise_from_start(x, t,
@@ -439,6 +443,14 @@ int  cindm_forceunet_grad(cindm_forceunet* h, const float* x, float lambda_force
  * runs against this model as written */
 int  cindm_forceunet_vjp(cindm_forceunet* h, const float* x, const float* dout, float* out, float* dx, int64_t images,
                          void* ws, size_t ws_bytes, void* stream);
+/* 1 when an in-kernel exchange between workgroups of this handle's kernels (the GroupNorm derivative on whole pixel rows, option
+ * gn_bwd_fused = 2) timed out since the last call -- the affected gradients are NaN, never finite and wrong --, 0 otherwise; clears
+ * the flag; synchronises `stream`.  cindm_ddpm2d_sample_force reads it at the end of the chain and re-runs ONCE from the kept x_T
+ * on the exchange-free derivative (option recover = 0: returns an error instead); after cindm_forceunet_grad / _vjp /
+ * cindm_airfoil_design_grad the caller polls it (the Python face does, and re-runs the call with option no_exchange = 1).
+ * cindm_forceunet_recovered: how many chains / calls were re-run that way.  No reference counterpart. */
+int  cindm_forceunet_status(cindm_forceunet* h, void* stream);
+int  cindm_forceunet_recovered(const cindm_forceunet* h);
 /* grad[B*nb, H*W, CP] = design_fn(x) = grad_force + lambda_overlap * grad_overlap (inverse_design_2d.py:208-214), the
  * tensor GaussianDiffusion.p_sample subtracts under "standard" / "standard-alpha" guidance (model/diffusion_2d.py:813-817).
  * frames = (real channels - 3) / 3; p_min / p_max: the pressure normalisation of the data set (:85-87). */
@@ -464,6 +476,24 @@ int  cindm_ddpm2d_sample_force(cindm_ddpm1d* sched, cindm_unet2d* u, cindm_force
                                const float* eta, float* grad, void* ws, size_t ws_bytes, void* ws_force,
                                size_t ws_force_bytes, void* stream, int32_t use_graph);
 
+/* ------------------------------------------------------------------ multi-GPU: the one collective of the path
+ * the design batch is sharded over the ranks with no communication inside the reverse loop;
+ * the final designs are all-gathered ONCE.  The reference has no counterpart (inference/inverse_design_diffusion_1d.py:161 is
+ * single-device).  These entry points call RCCL (librccl.so, resolved with dlopen at first use: the library itself has no link
+ * dependency on it) over xGMI:
+ *   cindm_comm_unique_id   ncclGetUniqueId: 128 opaque bytes made by rank 0 and handed to every rank by the caller's own
+ *                          rendezvous (the Python face broadcasts them over the torch.distributed group it already has);
+ *   cindm_comm_init        ncclCommInitRank on the CURRENT device -> an opaque communicator;
+ *   cindm_all_gather_designs   ncclAllGather(float): every rank contributes per_rank_elems floats at `local`, `out` receives
+ *                          world * per_rank_elems floats in rank order; asynchronous on `stream`;
+ *   cindm_comm_destroy     ncclCommDestroy.
+ * Ragged shards are padded to the largest one by the caller (cindm_amd/dist.py). */
+typedef struct cindm_comm cindm_comm;
+int  cindm_comm_unique_id(unsigned char id[128]);
+int  cindm_comm_init(const unsigned char id[128], int32_t world, int32_t rank, cindm_comm** out);
+int  cindm_comm_world(const cindm_comm* c);
+int  cindm_all_gather_designs(const float* local, float* out, int64_t per_rank_elems, cindm_comm* comm, void* stream);
+void cindm_comm_destroy(cindm_comm* c);
 
 #ifdef __cplusplus
 }

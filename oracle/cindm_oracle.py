@@ -1155,40 +1155,49 @@ def sample_noise_2d(state, boundary):
 
 
 def model_predictions_2d(d, shape, x, t, clip_x_start=False, rederive_pred_noise=False, share_noise=True):
-    """GaussianDiffusion.model_predictions, model/diffusion_2d.py:727-754 (objective pred_noise): the Unet's output with its
+    """GaussianDiffusion.model_predictions, model/diffusion_2d.py:727-754.  pred_noise (:729-739): the Unet's output with its
     state channels shared over the boundary copies (``share_noise``, :732-733), x_start = predict_start_from_noise
     (:735, clamped with ``clip_x_start``) and, with ``clip_x_start and rederive_pred_noise`` (:738-739), the noise
-    re-derived from the clamped x_start (predict_noise_from_start :691-695).  Returns (pred_noise, x_start)."""
-    assert d.objective == "pred_noise"
+    re-derived from the clamped x_start (predict_noise_from_start :691-695).  pred_x0 (:741-744): the output IS x_start;
+    pred_v (:746-750): x_start = predict_start_from_v (:703-707); both clamp with ``clip_x_start``, share nothing and always
+    re-derive the noise.  Returns (pred_noise, x_start)."""
     B, nb = shape[0], shape[1]
     T = d.tab
     tt = torch.full((x.shape[0],), t, dtype=torch.long)
-    eps = unet2d_forward(d.sd, x, tt)
-    if share_noise:
-        eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
-    x_start = T["sqrt_recip_alphas_cumprod"][t] * x - T["sqrt_recipm1_alphas_cumprod"][t] * eps
+    out = unet2d_forward(d.sd, x, tt)
+    if d.objective == "pred_noise":
+        eps = out
+        if share_noise:
+            eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
+        x_start = T["sqrt_recip_alphas_cumprod"][t] * x - T["sqrt_recipm1_alphas_cumprod"][t] * eps
+        if clip_x_start:
+            x_start = x_start.clamp(-1.0, 1.0)
+            if rederive_pred_noise:
+                eps = (T["sqrt_recip_alphas_cumprod"][t] * x - x_start) / T["sqrt_recipm1_alphas_cumprod"][t]
+        return eps, x_start
+    if d.objective == "pred_x0":
+        x_start = out
+    elif d.objective == "pred_v":
+        x_start = T["sqrt_alphas_cumprod"][t] * x - T["sqrt_one_minus_alphas_cumprod"][t] * out
+    else:
+        raise ValueError(d.objective)
     if clip_x_start:
         x_start = x_start.clamp(-1.0, 1.0)
-        if rederive_pred_noise:
-            eps = (T["sqrt_recip_alphas_cumprod"][t] * x - x_start) / T["sqrt_recipm1_alphas_cumprod"][t]
+    eps = (T["sqrt_recip_alphas_cumprod"][t] * x - x_start) / T["sqrt_recipm1_alphas_cumprod"][t]
     return eps, x_start
 
 
 def p_sample_2d(d, shape, x, t, noise, design_fn=None, design_guidance="standard", clip_denoised=True, recur_noise=None):
-    """GaussianDiffusion.p_sample, model/diffusion_2d.py:788-889 (objective pred_noise, share_noise True).
+    """GaussianDiffusion.p_sample, model/diffusion_2d.py:788-889 (any objective; share_noise either way).
     x [B*nb, C, H, W]; noise [B*nb, C, H, W] (= sample_noise(...).view) or None at t == 0; design_fn returns a GRADIENT
     tensor (:813).  "-recurrence-N" guidance (:846-889, needs design_fn) follows the reference literally: the posterior
     mean is computed ONCE, every iteration subtracts the raw design gradient taken at the current relaxed x
     (``model_mean - grad_design``, not the scaled ``grad_design_final``) and re-noises with ``recur_noise[r]``
     [B*nb, C, H, W].  Returns (x_{t-1}, x_start)."""
-    assert d.objective == "pred_noise"
     B, nb = shape[0], shape[1]
     T = d.tab
-    tt = torch.full((x.shape[0],), t, dtype=torch.long)
-    eps = unet2d_forward(d.sd, x, tt)
-    if d.share_noise:            # model_predictions :732-733
-        eps = share_states_over_boundaries(eps, B, nb, d.use_average_share)
-    x_start = T["sqrt_recip_alphas_cumprod"][t] * x - T["sqrt_recipm1_alphas_cumprod"][t] * eps
+    # p_mean_variance :758-761: model_predictions WITHOUT clip_x_start, then x_start.clamp_ (the same values)
+    _, x_start = model_predictions_2d(d, shape, x, t, clip_x_start=False, share_noise=d.share_noise)
     if clip_denoised:
         x_start = x_start.clamp(-1.0, 1.0)
     if not d.share_noise:        # p_mean_variance :762-763: the clamped x_start is shared instead ...

@@ -10,6 +10,8 @@ import socket
 import pytest
 import torch
 import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
@@ -231,3 +233,15 @@ def test_bench_two_ranks_end_to_end(device):
     assert line["value"] > 0 and abs(line["value"] - 64 / (line["ms_per_step"] / 1000.0)) < 1e-2 * line["value"]
     if torch.cuda.device_count() < 2:
         assert "shared_gpus" in line
+
+
+def test_rccl_one_rank_through_the_c_entry():
+    """RCCL is loaded and CALLED on this box: torch.distributed's "nccl" backend with one rank, and the library's own
+    communicator (cindm_comm_unique_id / cindm_comm_init -> ncclCommInitRank) + cindm_all_gather_designs (ncclAllGather) must
+    return the rank's own data.  (RCCL refuses two ranks on one GPU, so N > 1 needs a multi-GPU node; on one,
+    `torchrun --nproc-per-node N tools/nccl_selftest.py` is the same check with the gathered order.)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 200), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_selftest.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -344,3 +344,55 @@ def test_stem_input_gradient_adversarial_row_scales(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", src, "-o", exe], check=True)
     r = subprocess.run([exe, "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_surrogate_exchange_timeout_is_recovered(device):
+    """Round 4's advisor finding: a timed-out exchange of the whole-row GroupNorm derivative (fu_gn_silu_bwd_cluster_kernel: the
+    workgroups of an image swap partial sums) poisoned the gradient with NaN and NOTHING reported it.  Now the kernel raises the
+    handle's error word, every entry point that hands a gradient back reads it, and the call / the chain is re-run once on the
+    exchange-free derivative.  `dbg` = 39 forces the time-out (slab 1 of every image never publishes)."""
+    from test_gpu_parity_2d import _tape
+    sd = O.synth_state_dict_2d(O.force_unet_param_shapes(), 7)
+
+    def model():
+        m = cindm_amd.ForceUnet(dim=64, dim_mults=(1, 2, 4, 8), channels=4)
+        m.load_state_dict(sd, strict=True)
+        return m.to(device)
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((4, 4, 64, 64), generator=g).to(device)
+    ref = model().set_option("gn_bwd_fused", 1)                     # the exchange-free derivative, selected up front
+    out_r, dx_r = ref.input_grad(x, lambda_force=1.3)
+    m = model()
+    out_f, dx_f = m.input_grad(x, lambda_force=1.3)                 # the fast path, no time-out
+    assert m.recovered == 0 and bool(torch.isfinite(dx_f).all()) and rel(dx_f, dx_r) < 1e-5
+    m.set_option("dbg", 39)
+    out_t, dx_t = m.input_grad(x, lambda_force=1.3)                 # time-out -> flag -> re-run with no_exchange = 1
+    assert m.recovered == 1 and bool(torch.isfinite(dx_t).all())
+    assert torch.equal(dx_t, dx_r) and torch.equal(out_t, out_r)    # the recovered result IS the exchange-free result
+    # the objective call and autograd's backward go through the same check
+    fn = cindm_amd.ForceObjective(m, 1, 2, 2, p_min=-37.7, p_max=57.6)
+    xs = torch.randn((2, 9, 64, 64), generator=g).to(device)
+    gt = fn(xs)
+    assert m.recovered == 2 and bool(torch.isfinite(gt).all())
+    assert torch.equal(gt, cindm_amd.ForceObjective(ref, 1, 2, 2, p_min=-37.7, p_max=57.6)(xs))
+    # recover = 0: the time-out is an error, never a NaN gradient handed back
+    m.set_option("recover", 0)
+    with pytest.raises(cindm_amd.CindmError, match="timed out"):
+        m.input_grad(x, lambda_force=1.3)
+    m.set_option("recover", 1)
+    # the guided chain entry (cindm_ddpm2d_sample_force) keeps x_T and re-runs the whole chain
+    sd2 = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 0)
+    u = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21)
+    u.load_state_dict(sd2, strict=True)
+    d = cindm_amd.GaussianDiffusion(u, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000, loss_type="l2",
+                                    coeff_ratio=0.05).to(device)
+    B, nb = 1, 2
+    tape = _tape(31, B, nb, 21, 64, 64, 1000)
+    kw = dict(design_guidance="standard-alpha", noise=tape, t_stop=997, device=device, fused=True)
+    want = d.p_sample_loop((B, nb, 21, 64, 64), design_fn=cindm_amd.ForceObjective(ref, B, nb, 6, p_min=-37.7, p_max=57.6), **kw)
+    before = m.recovered
+    got = d.p_sample_loop((B, nb, 21, 64, 64), design_fn=cindm_amd.ForceObjective(m, B, nb, 6, p_min=-37.7, p_max=57.6), **kw)
+    assert m.recovered == before + 1 and bool(torch.isfinite(got).all()) and torch.equal(got, want)
+    m.set_option("dbg", 0)
+    assert torch.equal(m.input_grad(x, lambda_force=1.3)[1], dx_f) and m.recovered == before + 1

@@ -295,3 +295,30 @@ def test_model_predictions_2d_golden(gold_dir, device, unet2d, tag):
         if tag == "clip":
             _, _, _, x0 = d.p_mean_variance((1, 2, 21, 64, 64), xd, t, clip_denoised=True)
             assert torch.equal(x0, pr.pred_x_start)
+
+
+@pytest.mark.parametrize("obj", ["pred_x0", "pred_v"])
+def test_objectives_2d_golden(gold_dir, device, unet2d, obj):
+    """The 2-D GaussianDiffusion under objective pred_x0 / pred_v (model/diffusion_2d.py:741-753) through the C ABI against the
+    reference's own model_predictions (plain, clip_x_start) and p_sample (share_noise True / False; t = 500 with the recorded
+    noise, t = 0) -- round 4 raised NotImplementedError for them."""
+    from test_oracle_golden import OBJ_PRED_CASES, OBJ_STEP_CASES, check_objectives2d, objectives2d_inputs
+    g = np.load(os.path.join(gold_dir, "objectives_2d_r5.npz"))
+    D = objectives2d_inputs()
+    shape = (1, 2, 21, 64, 64)
+    for tag, clip in OBJ_PRED_CASES.items():
+        d = cindm_amd.GaussianDiffusion(unet2d[0], image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                        loss_type="l2", objective=obj).to(device)
+        for t in (500, 0):
+            x = D[(obj, "pred", tag, t)]
+            pr = d.model_predictions(shape, x.to(device), torch.full((2,), t, device=device), clip_x_start=clip)
+            check_objectives2d(g, f"{obj}.pred.{tag}.t{t}", x, (("pred_noise", pr.pred_noise), ("x_start", pr.pred_x_start)), TOL_STEP)
+    for tag, share in OBJ_STEP_CASES.items():
+        d = cindm_amd.GaussianDiffusion(unet2d[0], image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                        loss_type="l2", objective=obj, share_noise=share).to(device)
+        for t in (500, 0):
+            x, nz = D[(obj, "step", tag, t)]
+            xp, x0 = d.p_sample(shape, x.to(device), t, noise=nz.to(device))
+            check_objectives2d(g, f"{obj}.step.{tag}.t{t}", x, (("x_prev", xp), ("x_start", x0)), TOL_STEP)
+            if share is False:          # x_start's state channels are shared over the two boundary copies (:762-763)
+                assert torch.equal(x0[0, :-3], x0[1, :-3])

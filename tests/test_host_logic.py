@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     # the version the header declares, the library reports and the binding was written for are one number
     hv = int(re.search(r"#define\s+CINDM_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "cindm_hip.h")).read()).group(1))
-    assert L.cindm_abi_version() == hv == _ffi.ABI_VERSION == 2
+    assert L.cindm_abi_version() == hv == _ffi.ABI_VERSION == 3
 
 
 def test_descriptor_structs_match_header_layout():

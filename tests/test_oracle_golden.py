@@ -427,3 +427,60 @@ def test_pinning_report_round4(gold_dir):
     for tag in PREDICT_2D:
         assert rep["predict2d." + tag] <= 2e-6, (tag, rep)
     assert rep["eval_simu"] <= 2e-6, rep                     # the glue of utils.eval_simu around a stand-in simulator
+
+
+# ---- round 5: the 2-D objectives pred_x0 / pred_v (model/diffusion_2d.py:741-753) -------------------------------------------------
+OBJ_2D = ("pred_x0", "pred_v")
+OBJ_PRED_CASES = {"plain": False, "clip": True}
+OBJ_STEP_CASES = {"share": True, "noshare": False}
+
+
+def objectives2d_inputs():
+    """The inputs of tests/golden/objectives_2d_r5.npz, regenerated as oracle/make_golden_r5.py::draws drew them (seed 505)."""
+    g = torch.Generator().manual_seed(505)
+    d = {}
+    for obj in OBJ_2D:
+        for tag in OBJ_PRED_CASES:
+            for t in (500, 0):
+                d[(obj, "pred", tag, t)] = torch.randn((2, 21, 64, 64), generator=g) * (1.0 if t > 100 else 1.4)
+        for tag in OBJ_STEP_CASES:
+            for t in (500, 0):
+                x = torch.randn((2, 21, 64, 64), generator=g)
+                nz = O.sample_noise_2d(torch.randn((1, 1, 18, 64, 64), generator=g), torch.randn((1, 2, 3, 64, 64), generator=g)).reshape(2, 21, 64, 64)
+                d[(obj, "step", tag, t)] = (x, nz)
+    return d
+
+
+def check_objectives2d(gold, key, x, named, tol):
+    assert rel(x.mean(dim=(2, 3)), gold[key + ".x.cmean"]) < 1e-6, "regenerated input differs from the recorded one"
+    for name, v in named:
+        v = torch.as_tensor(v).detach().cpu()
+        assert rel(v[:, :, 24:40, 8:24], gold[f"{key}.{name}.crop"]) < tol, (key, name)
+        assert rel(v.mean(dim=(2, 3)), gold[f"{key}.{name}.cmean"]) < 50 * tol, (key, name)
+
+
+@pytest.mark.parametrize("obj", OBJ_2D)
+def test_objectives_2d(gold_dir, sd2d, obj):
+    """model_predictions and p_sample of the 2-D GaussianDiffusion under pred_x0 / pred_v against the reference's own outputs."""
+    g = np.load(os.path.join(gold_dir, "objectives_2d_r5.npz"))
+    D = objectives2d_inputs()
+    shape = (1, 2, 21, 64, 64)
+    for tag, clip in OBJ_PRED_CASES.items():
+        od = O.Diffusion2D(sd2d, image_size=64, frames=6, objective=obj)
+        for t in (500, 0):
+            x = D[(obj, "pred", tag, t)]
+            pn, x0 = O.model_predictions_2d(od, shape, x.clone(), t, clip_x_start=clip)
+            check_objectives2d(g, f"{obj}.pred.{tag}.t{t}", x, (("pred_noise", pn), ("x_start", x0)), TOL)
+    for tag, share in OBJ_STEP_CASES.items():
+        od = O.Diffusion2D(sd2d, image_size=64, frames=6, objective=obj, share_noise=share)
+        for t in (500, 0):
+            x, nz = D[(obj, "step", tag, t)]
+            xp, x0 = O.p_sample_2d(od, shape, x.clone(), t, nz if t > 0 else None)
+            check_objectives2d(g, f"{obj}.step.{tag}.t{t}", x, (("x_prev", xp), ("x_start", x0)), TOL)
+
+
+def test_pinning_report_round5(gold_dir):
+    with open(os.path.join(gold_dir, "PINNING_REPORT_R5.json")) as f:
+        rep = json.load(f)
+    keys = [k for k in rep if k != "seconds"]
+    assert len(keys) == 8 and all(rep[k] <= 2e-6 for k in keys), rep

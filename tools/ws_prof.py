@@ -1,4 +1,6 @@
-"""In-kernel phase clocks of conv2d_ws_kernel (profiling build): python tools/ws_prof.py [images] [reps] under CINDM_LIB_VARIANT=prof.
+"""In-kernel phase clocks of conv2d_ws_kernel (profiling build): python tools/ws_prof.py [images] [reps] [ws_nosplit values] [dbg2 values] under CINDM_LIB_VARIANT=prof
+(dbg2: 10 / 11 / 12 = no priority / matrix waves at priority 3 / memory waves at priority 3; 2 / 4 / 5 = no window loads / no tile stores /
+no staging and no tile writes -- wrong results, timing only).
 Prints, per launch category and option value of ws_nosplit, the first matrix wave's and the first memory wave's time per ITEM
 (pixel tile x 64-channel chunk x n-tile) in each phase, for workgroup 8 of the 256."""
 import ctypes as C, os, sys
@@ -17,15 +19,18 @@ t = torch.full((NI,), 500, device=dev, dtype=torch.long)
 buf = (C.c_ulonglong * 128)()
 CATS = ["plain, 1 chunk", "GroupNorm, 1 chunk", "plain, >1 chunk", "GroupNorm, >1 chunk"]
 PH = (("multiply", "wait S1", "reduce/tile", "wait S3"), ("stage", "issue loads", "write tile", "wait S1", "wait S2/S3"))
-for opt in ((0, 1) if len(sys.argv) <= 3 else (int(sys.argv[3]),)):
-    m.set_option("ws_nosplit", opt)
+opts = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
+dbgs = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
+for opt in opts:
+  for dbg in dbgs:
+    m.set_option("ws_nosplit", opt); m.set_option("dbg2", dbg)
     m(x, t); torch.cuda.synchronize()
     assert _ffi.lib().cindm_ws_prof_read(buf) == 1, "not the profiling build"
     for _ in range(reps):
         m(x, t)
     torch.cuda.synchronize()
     _ffi.lib().cindm_ws_prof_read(buf)
-    print(f"== ws_nosplit = {opt}: {NI} images, {reps} forwards; us per item (10 ns clock), workgroup 8")
+    print(f"== ws_nosplit = {opt}, dbg2 = {dbg}: {NI} images, {reps} forwards; us per item (10 ns clock), workgroup 8")
     for c, name in enumerate(CATS):
         for role in (0, 1):
             v = [buf[(c * 2 + role) * 8 + i] for i in range(8)]
