@@ -67,6 +67,7 @@ SIGNATURES = {
     "cindm_last_error": (C.c_char_p, []),
     "cindm_source_hash": (C.c_char_p, []),
     "cindm_ws_prof_read": (C.c_int, [_vp]),
+    "cindm_ddpm1d_last_chain_info": (C.c_int, [_vp, C.POINTER(_i32)]),
     "cindm_forceunet_status": (C.c_int, [_vp, _vp]),
     "cindm_forceunet_recovered": (C.c_int, [_vp]),
     "cindm_comm_unique_id": (C.c_int, [_vp]),

@@ -219,6 +219,7 @@ static const OptDef kUnet1dOpts[] = {
     {"fuse_gather", 1, nullptr},       // time composition of two-body states: level0_down_kernel reads the state's windows in place (no compose_gather_kernel launch)
     {"fuse_update", 1, "CINDM_FUSE_UPDATE"},   // plain single-model steps: the reverse-step update inside ups_last_kernel (no update launch)
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
+    {"recover", 1, nullptr},                   // run-time: 0 = a chain whose exchange timed out is an error instead of an exchange-free re-run
     {"no_exchange", 0, "CINDM_NO_EXCHANGE"},   // 1: only kernels without an in-launch exchange between workgroups (run-time option: does not un-finalize)
     {"tune", 0, "CINDM_TUNE"},         // experiment switches for same-box A/B runs (run-time; 0 = the shipped choices)
     {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
@@ -243,7 +244,7 @@ extern "C" int cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t
     if (it->second != value) {
         it->second = value;
         // "no_exchange" only selects among kernels whose operands are all packed already: the handle stays finalized
-        if (std::strcmp(key, "no_exchange") != 0 && std::strcmp(key, "tune") != 0) h->finalized = false;
+        if (std::strcmp(key, "no_exchange") != 0 && std::strcmp(key, "tune") != 0 && std::strcmp(key, "recover") != 0) h->finalized = false;
         else h->generation = ++g_generation;         // (captured steps embed the switch: never replay an older capture)
     }
     return 0;
@@ -1986,6 +1987,7 @@ struct cindm_ddpm1d {
     std::vector<unsigned char> gkey; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     int last_step_launches = 0, last_step_fused = 0;     // what the last emitted reverse step consisted of (cindm_ddpm1d_last_step_info)
     float* xT = nullptr; size_t xT_cap = 0;              // the chain's initial state, kept for the exchange-free re-run after a time-out
+    int last_chain_recovered = 0, last_chain_crowded = 0, last_chain_in_flight = 0;     // cindm_ddpm1d_last_chain_info
     hipGraph_t graph1 = nullptr; hipGraphExec_t gexec1 = nullptr;      // ping-pong loops: the one-step graph that ends an odd count
     void drop_graph() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -2359,10 +2361,36 @@ static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, 
 // chain is re-run ONCE with both U-Nets in exchange-free mode (per-layer kernels, nothing to time out); the handles go back
 // to the fast kernels afterwards.  The counter-based noise is a function of (seed, sample, step), tapes are read-only: the
 // re-run draws what the first run drew.
+// One sampling chain per device at a time is the rule of the exchange kernels (their workgroups wait for partners that must be
+// co-resident: a second chain on another stream keeps them off the chip).  The registry counts the chains in flight
+// per device IN THIS PROCESS: a chain that starts while another is running takes the exchange-free plan up front -- correct, about
+// 10 % slower, no time-out, no re-run -- and the Python face warns once.  (Other processes on the device cannot be seen from here;
+// against them the bounded spin + recovery below remains.)  Concurrent chains need their own U-Net handles.
+static std::atomic<int> g_chains_in_flight[64];
+struct ChainInFlight {
+    std::atomic<int>* c = nullptr; int prev = 0;
+    ChainInFlight() { int dev = 0; if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) { c = &g_chains_in_flight[dev]; prev = c->fetch_add(1); } }
+    ~ChainInFlight() { if (c) c->fetch_sub(1); }
+};
+
 template <typename Body>
 static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, float* x, size_t n_floats,
                                    hipStream_t stream, Body body) {
-    const bool guard = !pair->NX();           // (already exchange-free: nothing can time out, nothing to keep)
+    ChainInFlight inflight;
+    h->last_chain_recovered = 0; h->last_chain_crowded = 0; h->last_chain_in_flight = inflight.prev + 1;
+    // (already exchange-free: nothing can time out, nothing to keep -- BOTH models of a multibody step count)
+    const bool guard = !pair->NX() || (uncond && !uncond->NX());
+    if (guard && inflight.prev > 0) {
+        h->last_chain_crowded = 1;
+        const int f0 = pair->no_xchg_force, f1 = uncond ? uncond->no_xchg_force : 0;
+        pair->no_xchg_force = 1; if (uncond) uncond->no_xchg_force = 1;
+        h->drop_graph();
+        const int rc = body();
+        pair->no_xchg_force = f0; if (uncond) uncond->no_xchg_force = f1;
+        h->drop_graph();
+        if (rc == 1) return fail("an in-kernel exchange timed out in exchange-free mode (internal error)");
+        return rc;
+    }
     if (guard) {
         if (h->xT_cap < n_floats) {
             if (h->xT) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(h->xT); h->xT = nullptr; h->xT_cap = 0; }
@@ -2374,9 +2402,13 @@ static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     int rc = body();
     if (rc != 1) return rc;
     if (!guard) return fail("an in-kernel exchange timed out in exchange-free mode (internal error)");
+    if (!pair->O("recover") || (uncond && !uncond->O("recover")))
+        return fail("an in-kernel exchange between workgroups timed out (foreign load on the device kept a partner workgroup from becoming "
+                    "resident); option recover = 0: the chain is not re-run");
     HIPCHK(hipMemcpyAsync(x, h->xT, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
     pair->no_xchg_force = 1; ++pair->recovered;
     if (uncond) { uncond->no_xchg_force = 1; ++uncond->recovered; }
+    h->last_chain_recovered = 1;
     h->drop_graph();
     rc = body();
     pair->no_xchg_force = 0;
@@ -2384,6 +2416,15 @@ static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     h->drop_graph();
     if (rc == 1) return fail("an in-kernel exchange timed out again during the exchange-free re-run (internal error)");
     return rc;
+}
+
+// what the last chain of this handle did: info[0] = 1 when it was re-run on the exchange-free plan after a time-out, info[1] = 1 when
+// it ran on the exchange-free plan from the start because another chain was in flight on the device, info[2] = chains in flight on
+// the device when it started (itself included), info[3] = reserved
+extern "C" int cindm_ddpm1d_last_chain_info(const cindm_ddpm1d* h, int32_t info[4]) {
+    REQUIRE(h && info, "null argument");
+    info[0] = h->last_chain_recovered; info[1] = h->last_chain_crowded; info[2] = h->last_chain_in_flight; info[3] = 0;
+    return 0;
 }
 
 static void key_common(KeyBuilder& K, int kind, const cindm_unet1d* pair, const cindm_unet1d* uncond, const cindm_compose_desc* c, const StepIO& io,

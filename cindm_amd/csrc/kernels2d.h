@@ -1297,6 +1297,122 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
     }
 }
 
+// conv1x1_tail_h3p_kernel<KT> (round 5): the ResnetBlock tail with a res_conv -- out = res_conv(cat(x0, x1)) + bias + SiLU(GN(y1)) -- as a
+// PIPELINED loop over 64-pixel tiles.  conv1x1_tail_h3_kernel is one short-lived workgroup per tile whose phases follow each other
+// (x rows -> split -> barrier -> 48 MFMAs -> y1 rows -> stores): 172 us for 536 MB at 64 x 64 / 128 images = 3.1 TB/s, where the
+// element-wise tail (tail_identity_kernel) moves 4.8 TB/s; five attempts to re-order its epilogue did not change that.  Here a
+// workgroup owns a CONTIGUOUS run of tiles (same image for all or most of them: the GroupNorm statistics are merged once per image,
+// the weights are fetched once per workgroup) and every iteration issues the NEXT tile's x rows and THIS tile's y1 rows before the
+// products, so both arrive under the MFMAs and the stores of the previous tile; vmcnt retires in order: the wait for the x rows
+// (issued first) never covers the younger y1 loads or stores.  Same staging, product, accumulator layout and epilogue arithmetic as
+// conv1x1_tail_h3_kernel (bit-identical output).  Cout = 64 (one n-tile); e_y required, no residual / LayerNorm-out operand.
+template <int KT>
+__global__ __launch_bounds__(256, 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
+    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
+    static_assert((64 * F4) % 256 == 0, "whole passes");
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
+    __shared__ float tabE[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lq = lane & 15, lg = lane >> 4;
+    const int HWo = a.Hout * a.Wout;
+    const int ntl = (int)(a.rows_total >> 6);                    // tiles in the tensor (host: whole tiles)
+    const int t_lo = (int)(((long long)blockIdx.x * ntl) / gridDim.x), t_hi = (int)(((long long)(blockIdx.x + 1) * ntl) / gridDim.x);
+    if (t_lo >= t_hi) return;
+    const Src& s0 = a.src[0];
+    const int col = w * 16 + lg * 4;                             // this lane's 4 consecutive output channels
+    half8 wv[KS][2];
+    {
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + tid;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[((size_t)ks * 2 + pl) * 256]);
+    }
+    const bool nok = col < a.N;
+    const int colc = nok ? col : 0;
+    const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 eg = *reinterpret_cast<const float4*>(a.e_gamma + colc), eb = *reinterpret_cast<const float4*>(a.e_beta + colc);
+    const int g = colc >> (31 - __builtin_clz(a.e_gw));
+    float4 sv[NPASS];
+    auto load_x = [&](int t) {
+        const size_t row0 = (size_t)t * 64;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int i = tid + 256 * p;
+            const int r = i / F4, c4 = i - r * F4;
+            const int cl = c4 * 4;
+            const bool first = cl < s0.C || a.nsrc == 1;
+            const float* sp = first ? a.src[0].p : a.src[1].p;
+            const int sld = first ? a.src[0].ld : a.src[1].ld;
+            const int cs = first ? cl : cl - s0.C;
+            sv[p] = *reinterpret_cast<const float4*>(sp + (row0 + r) * sld + cs);
+        }
+    };
+    auto split_x = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int i = tid + 256 * p;
+            const int r = i / F4, c4 = i - r * F4;
+            const float4 v = sv[p];
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&Xs[0][r * PITCH + c4 * 8]) = hi;
+            *reinterpret_cast<half4v*>(&Xs[1][r * PITCH + c4 * 8]) = lo;
+        }
+    };
+    const unsigned char* xh0 = &Xs[0][lq * PITCH + lg * 16];
+    const unsigned char* xl0 = &Xs[1][lq * PITCH + lg * 16];
+    int img_have = -1;
+    load_x(t_lo);
+    for (int t = t_lo; t < t_hi; ++t) {
+        const size_t row0 = (size_t)t * 64;
+        const int img = (int)(row0 / HWo);
+        if (img != img_have && w == 1) {                         // (wave-uniform: img is a function of t)
+            float m, r;
+            merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
+            if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
+        }
+        img_have = img;
+        split_x();                                               // tile t: registers -> planes
+        __syncthreads();
+        if (t + 1 < t_hi) load_x(t + 1);                         // the next tile's rows, then this tile's y1 rows: both under the products
+        float4 yv[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + (row0 + pb * 16 + lq) * a.e_ld + colc);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 accM[4], accL[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) { accM[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const half8 xh = *reinterpret_cast<const half8*>(xh0 + pb * 16 * PITCH + ks * 64);
+                const half8 xl = *reinterpret_cast<const half8*>(xl0 + pb * 16 * PITCH + ks * 64);
+                accM[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xh, accM[pb], 0, 0, 0);
+                accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
+                accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
+            }
+        const float em = tabE[2 * g], er = tabE[2 * g + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        if (nok) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const size_t prow = row0 + pb * 16 + lq;
+                float4 v = make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
+                                       (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
+                const float4 y = yv[pb];
+                v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
+                v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
+                *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
+            }
+        }
+        __syncthreads();                                         // every wave has read the planes (and tabE) of tile t
+    }
+}
+
 // y = LayerNorm_channels(x) * g from the row partials [rows][P][2] (the PreNorm of the bottleneck attention,
 // model/diffusion_2d.py:82-97 / :256): one thread per float4.  A separate 20 us pass so that the qkv projection can run
 // as a plain-source GEMM on conv1x1_tail_h3_kernel (the LayerNorm-on-load variant of that kernel was not reliable).

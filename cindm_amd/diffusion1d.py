@@ -166,6 +166,27 @@ class GaussianDiffusion1D(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return h, un, self._ws
 
+    _warned_crowded = False
+
+    def last_chain_info(self):
+        """What the last library chain (``sample`` / ``ddim_sample`` / the built-in guided loop) of this object did:
+        ``recovered`` -- an in-kernel exchange timed out and the chain was re-run once on the exchange-free plan;
+        ``exchange_free_up_front`` -- another chain was already in flight on this device in this process, so this one ran on the
+        exchange-free plan from the start (correct, about 10 % slower); ``chains_in_flight`` when it started, itself included."""
+        info = (C.c_int32 * 4)()
+        _ffi.check(_ffi.lib().cindm_ddpm1d_last_chain_info(self._handle(), info))
+        return {"recovered": bool(info[0]), "exchange_free_up_front": bool(info[1]), "chains_in_flight": int(info[2])}
+
+    def _note_chain(self):
+        info = self.last_chain_info()
+        if info["exchange_free_up_front"] and not GaussianDiffusion1D._warned_crowded:
+            GaussianDiffusion1D._warned_crowded = True
+            import warnings
+            warnings.warn("cindm_amd: a sampling chain started while another was in flight on the same device; the fast kernels exchange "
+                          "data between co-resident workgroups and are built for ONE chain per device, so this chain ran on the "
+                          "exchange-free plan (correct, slower).  Run chains one after the other, or one process per GPU.", RuntimeWarning)
+        return info
+
     def last_step_info(self):
         """(kernel launches, update fused into the U-Net's last kernel?) of the reverse step emitted last -- as launched
         by the library, not a model of it (``cindm_ddpm1d_last_step_info``)."""
@@ -203,9 +224,13 @@ class GaussianDiffusion1D(nn.Module):
     def _timed_out(self, desc, device):
         """True when an in-kernel exchange of the U-Nets a step with ``desc`` runs timed out since the last poll (every
         model's flag is read and cleared); synchronises.  Raises instead when the model opted out of the recovery."""
-        hit = False
-        for m in self._models(desc):
-            hit = m.poll_status(device) or hit
+        hit, opted_out = False, False
+        for m in self._models(desc):                 # every model's flag is read (and cleared) before anything is raised
+            rc = m.poll_raw(device)
+            hit = hit or rc
+            opted_out = opted_out or (rc and not m.recover_exchange_timeouts)
+        if opted_out:
+            raise _ffi.CindmError(self.model.TIMEOUT_TEXT)
         return hit
 
     def _rerun_exchange_free(self, fn, desc, device):
@@ -389,6 +414,7 @@ class GaussianDiffusion1D(nn.Module):
                 C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
                 _ffi.ptr(inpaint_noise_steps), t_start, t_end, B, _ffi.ptr(ws), ws.numel(),
                 _ffi.current_stream(img.device), int(use_graph)))
+        self._note_chain()
         return img
 
     @torch.no_grad()
@@ -408,6 +434,7 @@ class GaussianDiffusion1D(nn.Module):
                 C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
                 _ffi.ptr(None if noise is None else noise.cond), _ffi.ptr(iso), 0 if iso is None else iso.shape[1],
                 int(t_start), int(t_end), B, _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+        self._note_chain()
         return img
 
     def _init_state(self, shape, device, noise, seed, sample_offset, tag):
@@ -602,6 +629,7 @@ class GaussianDiffusion1D(nn.Module):
                     _ffi.ptr(None if noise is None else noise.step), C.c_uint64(seed), sample_offset, _ffi.ptr(inp),
                     0 if inp is None else inp.shape[1], _ffi.ptr(None if noise is None else noise.cond), B,
                     _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+            self._note_chain()
             return img
         if "recurrence" not in design_guidance:
             raise NotImplementedError("DDIM with design_fn needs a '-recurrence-N' guidance (the reference's other branch "

@@ -72,7 +72,7 @@ class TemporalUnet1D(nn.Module):
         self._ws_rows = 0
         # An in-kernel exchange between workgroups that timed out (foreign load on the device kept a partner workgroup from
         # becoming resident) is recovered by re-running the work once on the exchange-free kernels; False: raise CindmError
-        self.recover_exchange_timeouts = True
+        self._recover = True
         # parameters under the reference's key names, PyTorch-default initialisation
         name = C.create_string_buffer(256)
         shape = (C.c_int64 * 4)()
@@ -206,6 +206,26 @@ class TemporalUnet1D(nn.Module):
 
     TIMEOUT_TEXT = ("an in-kernel exchange between workgroups timed out (GroupNorm pair / attention head exchange): "
                     "the results of that forward are invalid")
+
+    @property
+    def recover_exchange_timeouts(self):
+        return self._recover
+
+    @recover_exchange_timeouts.setter
+    def recover_exchange_timeouts(self, on):
+        """Also tells the library (run-time option ``recover``): its chain entry points (sample / ddim_sample / the built-in guided
+        loop) return an error instead of re-running a timed-out chain."""
+        self._recover = bool(on)
+        _ffi.check(_ffi.lib().cindm_unet1d_set_option(self._h, b"recover", int(self._recover)))
+
+    def poll_raw(self, device):
+        """True when an exchange of a forward issued so far timed out (the flag is cleared); synchronises; never raises for a
+        time-out."""
+        with torch.cuda.device(device):
+            rc = _ffi.lib().cindm_unet1d_poll(self._h, _ffi.current_stream(device))
+        if rc < 0:
+            _ffi.check(rc)
+        return rc == 1
 
     def check_status(self, device):
         """Raises CindmError when an in-kernel exchange between workgroups of a forward issued so far timed out (its

@@ -303,6 +303,11 @@ int  cindm_ddpm1d_launches_per_step(const cindm_ddpm1d* h, const cindm_unet1d* p
  * launched, not modelled; `fused_update` = 1 when the reverse-step update (:1033-1044, :1281) ran inside the
  * U-Net's last kernel instead of compose_update_kernel.  Tests assert the fused path through this. */
 int  cindm_ddpm1d_last_step_info(const cindm_ddpm1d* h, int32_t* launches, int32_t* fused_update);
+/* What the last sampling chain of this handle did: info[0] = 1 when it was re-run once on the exchange-free plan after an in-kernel
+ * exchange timed out; info[1] = 1 when it ran on the exchange-free plan from the start because another chain was already in flight
+ * on the device in this process (one chain per device is the rule of the exchange kernels; the registry is per process);
+ * info[2] = chains in flight on the device when it started, itself included.  No reference counterpart. */
+int  cindm_ddpm1d_last_chain_info(const cindm_ddpm1d* h, int32_t info[4]);
 
 /* ===================================================================== 2-D airfoil path
  * Replaces Unet.forward (model/diffusion_2d.py:369-408) and GaussianDiffusion.p_sample /

@@ -337,7 +337,11 @@ def test_exchange_timeout_is_recovered(device):
         m(x, t)
     with pytest.raises(cindm_amd.CindmError, match="exchange"):
         d.p_sample_compose_outside(x, None, 500, noise=nz, **kw)
+    with pytest.raises(cindm_amd.CindmError, match="recover = 0"):          # the library's chain loops honour the opt-out too
+        d.sample(batch_size=32, n_composed=0, compose_n_bodies=2, seed=1, t_stop=997)
+    m.poll_raw(device)                                                        # (the failed chain left its flag raised)
     m.recover_exchange_timeouts = True
+    assert d.last_chain_info()["chains_in_flight"] == 1
     m.set_option("dbg", 0)
     m.set_option("auto_range", 1)
     n0 = m.recovered
@@ -659,3 +663,48 @@ def test_fused_update_other_state_widths(device, F):
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b) and bool(torch.isfinite(a).all())
     assert float(res[1][0].abs().max()) > 0
+
+
+def test_second_chain_on_a_device_goes_exchange_free_up_front(device):
+    """One sampling chain per device is the rule of the exchange kernels.  Two host threads run a chain each, at the same time, on
+    their own streams and their own models: the library's per-device registry sees the second chain start while the first is in
+    flight and puts it on the exchange-free plan UP FRONT -- no time-out fires, nothing is recovered, both results are right (the
+    late chain bit-equal to what `no_exchange` computes by itself), last_chain_info() says which was which and the Python face
+    warns once."""
+    import threading
+    import warnings
+    models = [build_unet(device)[0] for _ in range(2)]
+    diffs = [cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device) for m in models]
+    kw = dict(batch_size=64, n_composed=0, compose_n_bodies=2, seed=4, t_stop=940)
+    fast = diffs[0].sample(**kw).clone()                     # alone on the device: the fast plan
+    models[1].exchange_free(True)
+    slow = diffs[1].sample(**kw).clone()
+    models[1].exchange_free(False)
+    assert rel(fast, slow) < 1e-5
+    cindm_amd.GaussianDiffusion1D._warned_crowded = False
+    out, infos, errs = [None, None], [None, None], []
+    gate = threading.Barrier(2)
+
+    def run(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                gate.wait()
+                out[i] = diffs[i].sample(**kw).clone()
+                infos[i] = diffs[i].last_chain_info()
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    assert not errs, errs
+    assert all(m.recovered == 0 for m in models), "a time-out fired: the registry did not demote the second chain"
+    assert not any(i["recovered"] for i in infos)
+    crowded = [i["exchange_free_up_front"] for i in infos]
+    if any(crowded):                     # the chains overlapped (the usual case: a chain is 60 x 330 us)
+        assert sum(crowded) == 1 and max(i["chains_in_flight"] for i in infos) == 2
+        assert any("ONE chain per device" in str(x.message) for x in w)
+    for i in range(2):
+        assert torch.equal(out[i], slow if crowded[i] else fast)
