@@ -1646,7 +1646,14 @@ struct LnTile {
 // One workgroup = a.spw consecutive 128-pixel slices of one image (the next slice's rows are in flight while the
 // current one is processed); running maximum / sum / context are rescaled slice by slice (online softmax), one record
 // per workgroup.
-template <int C>
+// H16 (round 5): the per-head product ctx += k^T v on the split-fp16 MFMA instead of the exact fp32 one.  The fp32 form was 128
+// v_mfma_f32_16x16x4_f32 per 128-pixel slice and wave = 4096 matrix-pipe cycles next to the 3264 of the whole k | v projection (192
+// v_mfma_f32_16x16x32_f16): 55 % of the kernel's matrix time for 7 % of its FLOPs.  Two pixel tiles of the softmaxed k (v)
+// accumulators ARE one A (B) operand of a 16x16x32 step -- lane (channel lr, pixels 8 lq + e) holds eight of its channel's 32 pixels,
+// the same pixel order on both sides -- so the product is 48 MFMAs (3 per (pixel-tile pair, d tile, e tile)): 816 cycles, plus the
+// hi / lo splits of k and v (VALU).  exp(k - max) is in (0, 1] and v is a projection of LayerNorm output: both inside the range
+// rule of the split; two fp32 accumulator sets as everywhere.
+template <int C, bool H16 = true>
 __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
     constexpr int PX = la2_px(C);
     using LN = LnTile<C, PX>;
@@ -1673,37 +1680,40 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
     }
     float run_m[2] = {-INFINITY, -INFINITY}, run_s[2] = {0.f, 0.f};       // per channel d = dt*16 + lr
     f32x4 ctx[2][2];                                                       // rows d = dt*16 + lq*4 + i, cols e = et*16 + lr
+    f32x4 ctxL[2][2];                                                      // H16: the low-order accumulator set (x 2^11)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int et = 0; et < 2; ++et) ctx[dt][et] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int et = 0; et < 2; ++et) { ctx[dt][et] = f32x4{0.f, 0.f, 0.f, 0.f}; ctxL[dt][et] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 #pragma unroll 1
     for (int sl = 0; sl < a.spw; ++sl) {
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();
         if (sl + 1 < a.spw) LN::load(xr, x0 + (size_t)(sl + 1) * PX * a.ldx, a.ldx, tid);
-        // k, v: rows = pixels (8 tiles of 16), cols = the head's 32 channels
-        f32x4 kk[NTL][2], vv[NTL][2];
+        // k, v: rows = pixels (8 tiles of 16), cols = the head's 32 channels.  H16: only k here -- v is projected pair of tiles by
+        // pair of tiles where the context product consumes it (below), so that 2 instead of NTL v tiles are live
+        f32x4 kk[NTL][2], vv[H16 ? 2 : NTL][2];
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
-            f32x4 M[4], Lo[4];
+            constexpr int NS = H16 ? 2 : 4;
+            f32x4 M[NS], Lo[NS];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int s = 0; s < NS; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int k = 0; k < K32; ++k) {
                 const int off = (nt * 16 + lr) * YPB + k * 64 + lq * 16;
                 const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
                 const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < NS; ++s) {
                     M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[s][k], M[s], 0, 0, 0);
                     Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[s][k], Lo[s], 0, 0, 0);
                     Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[s][k], Lo[s], 0, 0, 0);
                 }
             }
             kk[nt][0] = M[0] + Lo[0] * H3_INV; kk[nt][1] = M[1] + Lo[1] * H3_INV;
-            vv[nt][0] = M[2] + Lo[2] * H3_INV; vv[nt][1] = M[3] + Lo[3] * H3_INV;
+            if constexpr (!H16) { vv[nt][0] = M[2] + Lo[2] * H3_INV; vv[nt][1] = M[3] + Lo[3] * H3_INV; }
         }
         // online softmax of k over pixels, per channel d = dt*16 + lr (pixels: rows nt*16 + lq*4 + i)
 #pragma unroll
@@ -1730,8 +1740,62 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
             run_m[dt] = mnew;
             if (lq == 0) fac[w][dt * 16 + lr] = f;
         }
-        __syncthreads();                                  // fac visible; every wave is done reading the planes
+        if constexpr (!H16) __syncthreads();              // fac visible; every wave is done reading the planes
+        // (H16: fac[w] is written and read by wave w alone -- LDS operations of one wave complete in order -- and the planes are read
+        // again by the v projection below: the workgroup barrier sits at the end of the iteration)
         // ctx = ctx * f[d] + sum_pixels e^(k - m) v
+        if constexpr (H16) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float4 f4 = *reinterpret_cast<const float4*>(&fac[w][dt * 16 + lq * 4]);
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    ctx[dt][et][0] *= f4.x; ctx[dt][et][1] *= f4.y; ctx[dt][et][2] *= f4.z; ctx[dt][et][3] *= f4.w;
+                    ctxL[dt][et][0] *= f4.x; ctxL[dt][et][1] *= f4.y; ctxL[dt][et][2] *= f4.z; ctxL[dt][et][3] *= f4.w;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTL; nt += 2) {
+                // v of pixel tiles nt, nt + 1
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 M[2], Lo[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) { M[s] = f32x4{0.f, 0.f, 0.f, 0.f}; Lo[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int k = 0; k < K32; ++k) {
+                        const int off = ((nt + u) * 16 + lr) * YPB + k * 64 + lq * 16;
+                        const half8 yh = *reinterpret_cast<const half8*>(&Yp[0][off]);
+                        const half8 yl = *reinterpret_cast<const half8*>(&Yp[1][off]);
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            M[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wh[2 + s][k], M[s], 0, 0, 0);
+                            Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, wl[2 + s][k], Lo[s], 0, 0, 0);
+                            Lo[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, wh[2 + s][k], Lo[s], 0, 0, 0);
+                        }
+                    }
+                    vv[u][0] = M[0] + Lo[0] * H3_INV; vv[u][1] = M[1] + Lo[1] * H3_INV;
+                }
+                half8 kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float kv = kk[nt + (e >> 2)][t][e & 3], v_ = vv[e >> 2][t][e & 3];
+                        kh[t][e] = (_Float16)kv; kl[t][e] = (_Float16)((kv - (float)kh[t][e]) * H3_SCALE);
+                        vh[t][e] = (_Float16)v_; vl[t][e] = (_Float16)((v_ - (float)vh[t][e]) * H3_SCALE);
+                    }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) {
+                        ctx[dt][et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[dt], vh[et], ctx[dt][et], 0, 0, 0);
+                        ctxL[dt][et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[dt], vl[et], ctxL[dt][et], 0, 0, 0);
+                        ctxL[dt][et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[dt], vh[et], ctxL[dt][et], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                              // every wave is done reading the planes
+        } else
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const float4 f4 = *reinterpret_cast<const float4*>(&fac[w][dt * 16 + lq * 4]);
@@ -1757,7 +1821,7 @@ __global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
 #pragma unroll
         for (int et = 0; et < 2; ++et)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rec[64 + (dt * 16 + lq * 4 + i) * 32 + et * 16 + lr] = ctx[dt][et][i];
+            for (int i = 0; i < 4; ++i) rec[64 + (dt * 16 + lq * 4 + i) * 32 + et * 16 + lr] = H16 ? ctx[dt][et][i] + ctxL[dt][et][i] * H3_INV : ctx[dt][et][i];
     }
 }
 
@@ -1790,7 +1854,10 @@ __global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict
 
 // One workgroup = a.tpw consecutive 64-pixel tiles of one image; weights and the head contexts stay in registers, the
 // next tile's rows are in flight while the current one is processed.
-template <int C>
+// H16 (round 5): att = ctx^T q on the split-fp16 MFMA: the contraction runs over the head's 32 channels = ONE 16x16x32 step, the
+// context fragments (times h w, a power of two: the merged context carries v / (h w) and would sit in fp16's subnormals) are split
+// once per workgroup, q per pixel tile: 24 MFMAs per 64-pixel tile instead of 64 fp32 ones (2048 -> 408 matrix-pipe cycles).
+template <int C, bool H16 = true>
 __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
     using LN = LnTile<C, 64>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
@@ -1839,6 +1906,17 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cf[dt][et][i] = cp[(dt * 16 + lq * 4 + i) * 32 + et * 16 + lr];
     }
+    // H16: A fragments of att = ctx^T q: lane (row e = lr of tile et, k-slots 8 lq + 4 dt + i <-> d = dt*16 + lq*4 + i)
+    const bool pow2 = (a.HW & (a.HW - 1)) == 0;
+    const float csc = pow2 ? (float)a.HW : 1.0f, cinv = 1.0f / csc;       // exact power of two
+    half8 ch[2], cl[2];
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v_ = cf[e >> 2][et][e & 3] * csc;
+            ch[et][e] = (_Float16)v_; cl[et][e] = (_Float16)((v_ - (float)ch[et][e]) * H3_SCALE);
+        }
 #pragma unroll 1
     for (int tt = 0; tt < a.tpw; ++tt) {
         const size_t row0 = row00 + (size_t)tt * NPX;
@@ -1887,13 +1965,29 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) q[dt] = (q[dt] * inv) * 0.17677669529663687f;
+            half8 qhh, qll;
+            if constexpr (H16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v_ = q[e >> 2][e & 3];
+                    qhh[e] = (_Float16)v_; qll[e] = (_Float16)((v_ - (float)qhh[e]) * H3_SCALE);
+                }
+            }
 #pragma unroll
             for (int et = 0; et < 2; ++et) {
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (H16) {
+                    f32x4 oL = f32x4{0.f, 0.f, 0.f, 0.f};
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[et], qhh, o, 0, 0, 0);
+                    oL = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[et], qll, oL, 0, 0, 0);
+                    oL = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[et], qhh, oL, 0, 0, 0);
+                    o = (o + oL * H3_INV) * cinv;
+                } else {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[dt][et][i], q[dt][i], o, 0, 0, 0);
+                }
                 half4v hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { hi[i] = (_Float16)o[i]; lo[i] = (_Float16)((o[i] - (float)hi[i]) * H3_SCALE); }
