@@ -1305,11 +1305,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
 // the weights are fetched once per workgroup) and every iteration issues the NEXT tile's x rows and THIS tile's y1 rows before the
 // products, so both arrive under the MFMAs and the stores of the previous tile; vmcnt retires in order: the wait for the x rows
 // (issued first) never covers the younger y1 loads or stores.  Same staging, product, accumulator layout and epilogue arithmetic as
-// conv1x1_tail_h3_kernel (bit-identical output).  Cout = 64 (one n-tile); e_y required, no residual / LayerNorm-out operand.
-template <int KT>
-__global__ __launch_bounds__(256, 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
-    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NPASS = (64 * F4) / 256;
-    static_assert((64 * F4) % 256 == 0, "whole passes");
+// conv1x1_tail_h3_kernel (bit-identical output).  e_y required, no residual / LayerNorm-out operand.
+// NW = waves per workgroup = output channels / 16: 4 (64 channels, two workgroups per CU) or 8 (128 channels: the 32 x 32 level's
+// 192 -> 128 blocks; one 512-thread workgroup per CU, every wave keeps the weights of its own 16 channels).
+template <int KT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
+    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NTH = 64 * NW, NPASS = (64 * F4) / NTH;
+    static_assert((64 * F4) % NTH == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
     __shared__ float tabE[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1322,7 +1324,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3p_kernel(const Conv2dAr
     const int col = w * 16 + lg * 4;                             // this lane's 4 consecutive output channels
     half8 wv[KS][2];
     {
-        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + tid;
+        // [n-tile of 64 channels][k-step][plane][thread within the n-tile = (wave & 3) * 64 + lane]
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)(w >> 2) * KS * 2 * 256 + (tid & 255);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1338,7 +1341,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3p_kernel(const Conv2dAr
         const size_t row0 = (size_t)t * 64;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const int i = tid + 256 * p;
+            const int i = tid + NTH * p;
             const int r = i / F4, c4 = i - r * F4;
             const int cl = c4 * 4;
             const bool first = cl < s0.C || a.nsrc == 1;
@@ -1351,7 +1354,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3p_kernel(const Conv2dAr
     auto split_x = [&]() {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const int i = tid + 256 * p;
+            const int i = tid + NTH * p;
             const int r = i / F4, c4 = i - r * F4;
             const float4 v = sv[p];
             half4v hi, lo;

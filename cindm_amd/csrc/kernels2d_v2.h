@@ -108,6 +108,20 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         else { nt = rem / nch; ch = rem - nt * nch; mt = lo + wj + tl * wpx; }
     };
     auto nt_of = [&](int tl) { return (lo + wj + tl * wpx) % ntiles; };      // NSPLIT: the n-tile of this workgroup's unit tl
+    // The memory waves walk the items in order: a cursor that steps (chunk -> n-tile -> unit) replaces decode(k)'s divisions
+    // (round 5: load_item + decode were 127 scalar and 27 vector instructions per item, most of them integer divisions by run-time
+    // values, in a wave whose time goes to instruction issue -- one wave per SIMD beside the matrix wave).
+    struct ItemCur { int tl, mt, nt, ch; };
+    auto cur_first = [&](ItemCur& c) { decode(0, c.mt, c.nt, c.ch); c.tl = 0; };
+    auto cur_next = [&](ItemCur& c) {
+        if (++c.ch < nch) return;
+        c.ch = 0;
+        if constexpr (NSPLIT) { ++c.tl; const int u = lo + wj + c.tl * wpx; c.mt = u / ntiles; c.nt = u - c.mt * ntiles; }
+        else { if (++c.nt < ntiles) return; c.nt = 0; ++c.tl; c.mt += wpx; }
+    };
+    // image / tile coordinates of a unit: shifts when the tile counts are powers of two (they are for power-of-two images)
+    const int tpi_sh = (a.tpi & (a.tpi - 1)) == 0 ? 31 - __builtin_clz(a.tpi) : -1;
+    const int tx_sh = (a.tiles_x & (a.tiles_x - 1)) == 0 ? 31 - __builtin_clz(a.tiles_x) : -1;
 
     if (role == 0 && !KSPLIT) {
         // ================================ matrix waves, K not split over the waves (round 5) ======================
@@ -426,8 +440,8 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     bool cok = true;
     // issue the global loads of item (mt, ch): its window and, GroupNorm mode, the image's statistics partials
     auto load_item = [&](int mt, int ch) {
-        const int img = mt / tpi, ti = mt - img * tpi;
-        const int tyi = ti / tiles_x;
+        const int img = tpi_sh >= 0 ? mt >> tpi_sh : mt / tpi, ti = mt - img * tpi;
+        const int tyi = tx_sh >= 0 ? ti >> tx_sh : ti / tiles_x;
         const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
         const bool first = (ch < nch0) || (nsrc == 1);
         const int cl = (first ? ch : ch - nch0) * KC + c4 * 4;
@@ -533,8 +547,8 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     auto load_acc = [&](int mt, int nt) {
         if constexpr (MODE == SRC2_SCALED) {
             if (!resp) return;
-            const int img = mt / tpi, ti = mt - img * tpi;
-            const int tyi = ti / tiles_x;
+            const int img = tpi_sh >= 0 ? mt >> tpi_sh : mt / tpi, ti = mt - img * tpi;
+            const int tyi = tx_sh >= 0 ? ti >> tx_sh : ti / tiles_x;
             const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
             const int oc4 = lane & 15, q = lane >> 4;
             const int col = nt * T2N + oc4 * 4;
@@ -547,8 +561,8 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     };
     // the finished tile (mt, nt): wave lw stores tile pixels 32 lw .. 32 lw + 31 (two pixel rows) and their GroupNorm partial
     auto write_tile = [&](int mt, int nt, int item) {
-        const int img = mt / tpi, ti = mt - img * tpi;
-        const int tyi = ti / tiles_x;
+        const int img = tpi_sh >= 0 ? mt >> tpi_sh : mt / tpi, ti = mt - img * tpi;
+        const int tyi = tx_sh >= 0 ? ti >> tx_sh : ti / tiles_x;
         const int ty0 = tyi * V2Y, tx0 = (ti - tyi * tiles_x) * V2X;
         const int oc4 = lane & 15, q = lane >> 4;
         const int col = nt * T2N + oc4 * 4;
@@ -616,13 +630,16 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     // vmcnt retires in order: with the tile's stores issued after the loads, no wait for a load ever covers a store.
     // An item whose planes (pixel tile, chunk) are the ones its buffer already holds -- the second n-tile of a
     // two-chunk layer: items c0, c1, c0, c1 alternate buffers 0, 1, 0, 1 -- is neither loaded nor staged again.
-    int mt, nt, ch, mtn, ntn, chn;
-    decode(0, mt, nt, ch);
+    ItemCur c0, c1, c2;                                      // items k, k + 1, k + 2
+    cur_first(c0);
+    c1 = c0; cur_next(c1);
+    c2 = c1; cur_next(c2);
+    int mt = c0.mt, nt = c0.nt, ch = c0.ch, mtn, chn;
     load_item(mt, ch);
     finish_stats();
     store_item(0, 0);
     bool staged_skip = false;                                // the item waiting for its staging needs none
-    if (nitems > 1) { decode(1, mtn, ntn, chn); load_item(mtn, chn); }
+    if (nitems > 1) load_item(c1.mt, c1.ch);
     stress_delay(stress, 200u);
     __syncthreads();                                         // S0
     int pmt = -1, pnt = 0, pk = 0;                           // finished tile waiting in LDS (pk: its last item)
@@ -633,7 +650,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         WSP(0); WSP_COUNT();
         if (pmt >= 0) load_acc(pmt, pnt);
         if (k + 2 < nitems && dbg != 5) {
-            decode(k + 2, mtn, ntn, chn);
+            mtn = c2.mt; chn = c2.ch;
             staged_skip = (mtn == mt && chn == ch);                // its buffer, (k + 2) & 1, holds item k's planes: these
             if (!staged_skip && dbg != 2) load_item(mtn, chn);
             else if constexpr (MODE == SRC2_SCALED) hist_set(k + 2, hist_get(k));      // (the same planes, the same image, the same scale)
@@ -652,7 +669,8 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             WSP(4);
             pmt = mt; pnt = nt; pk = k;
         }
-        if (k + 1 < nitems) decode(k + 1, mt, nt, ch);
+        c0 = c1; c1 = c2; cur_next(c2);
+        mt = c0.mt; nt = c0.nt; ch = c0.ch;
     }
     if (pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
     WSP_FLUSH(1);
