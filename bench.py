@@ -63,7 +63,7 @@ def pmc_step_traffic(fname):
     want = rec.get("source_hash")
     if want != have:
         return None, (f"profiles/{fname} was measured on library {str(want)[:12]}, the loaded library is {have[:12]}: "
-                      "PMC-derived fields dropped (re-run tools/r3_measure.sh)")
+                      "PMC-derived fields dropped (re-run tools/r5_measure.sh)")
     return int(rec["bytes_per_step"]), f"profiles/{fname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on library {have[:12]}"
 
 
@@ -127,7 +127,7 @@ def rank_device():
 
 
 FLOP_PER_IMAGE_2D = 10.467e9       # per Unet evaluation of one 64x64 image
-PMC_CFG5_FILE = "r04_pmc_traffic_cfg5.json"
+PMC_CFG5_FILE = "r05_pmc_traffic_cfg5.json"
 
 
 def pmc_surrogate_traffic(fname):
@@ -179,7 +179,7 @@ def pmc_traffic(fname, substr):
     return int(b / n) if n else None
 
 
-PMC_PREFIX = "r04_pmc_traffic_"        # profiles/<prefix><workload>.json, written by tools/r4_measure.sh (hash-checked)
+PMC_PREFIX = "r05_pmc_traffic_"        # profiles/<prefix><workload>.json, written by tools/r5_measure.sh (hash-checked)
 
 
 def timed_cpu_steps(step_once, budget_s, reps=3, max_steps=100):
@@ -426,7 +426,7 @@ def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=
                 roof = {"bound": "mfma", "kernel": "conv2d_tile_kernel<3x3 / upsampled 3x3> (fp32 MFMA)", "achieved": round(achieved, 2),
                         "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4)}
             roof.update({"traffic": pmc_traffic(pmc_file, "conv2d_ws_kernel<0, 0" if h3 else "conv2d_tile_kernel<0") if pmc else None,
-                         "pmc_provenance": pmc_note,
+                         "pmc_provenance": pmc_note, "pmc_measured_in_this_run": False,
                          "launches_per_forward": k3[0] // reps, "avg_launch_us": round(k3[1] / k3[0] * 1e3, 2),
                          "timing": f"HIP events around every launch on the launch stream (cindm_unet2d_profile), {reps} forwards",
                          "share_of_forward_time": round(k3[1] / tot_ms, 3),
@@ -468,7 +468,7 @@ def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=
                 line["config"]["sampled"] = (f"step-bounded sample: {steps} x the first {nsteps} reverse steps of the chain (t = 999 .. {t_stop}); "
                                              f"value and ms_per_step are extrapolated x{TIMESTEPS / nsteps:g} (every reverse step is the same work)")
             if guided:
-                line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r04_force_kernel_stats*.txt"
+                line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r05_kernel_stats_force.txt"
             if not args.no_cpu_baseline and world == 1:
                 # cpu_baseline + rel_err: the oracle's reverse steps on a few designs, then the same steps, inputs and explicit noise
                 # through the HIP path.  Guided: 1 design (the surrogate's autograd on the CPU is ~4 s per design and step).
@@ -711,7 +711,7 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
             pmc, pmc_note = pmc_step_traffic(pmc_file)
             roof = {"bound": "latency",
                     "bound_note": f"neither roofline binds: the reverse step is a chain of {step_launches} dependent launches; the per-launch phase "
-                                  "clocks (profiles/r04_phase_table_*.txt) split each into dispatch, first loads, weight streaming / MFMA, "
+                                  "clocks (profiles/r04_phase_table_*.txt, the 1-D kernels are unchanged since) split each into dispatch, first loads, weight streaming / MFMA, "
                                   "reductions, exchanges between workgroups and the store drain",
                     "kernel": kname,
                     # priced against the pipe that EXECUTES: every fp32 product is 3 fp16 MFMAs (f32 path: the fp32 MFMA itself)
@@ -732,6 +732,8 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
                 roof["hbm_gbps_whole_step"] = round(pmc / step_s / 1e9, 1)
                 roof["frac_of_hbm_peak"] = round(pmc / step_s / 1e9 / PEAK_HBM_GBPS, 4)
             roof["pmc_provenance"] = pmc_note
+            # traffic / hbm_* come from the committed PMC passes (hash-checked against the loaded library), not from this run
+            roof["pmc_measured_in_this_run"] = False
 
         line = None
         if rank == 0:
@@ -754,7 +756,7 @@ def compact(line):
            "rel_err": line.get("rel_err"),
            "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_forward", "traffic")},
            "hbm_bytes_per_step": r.get("hbm_bytes_per_step"), "frac_of_hbm_peak": r.get("frac_of_hbm_peak"),
-           "pmc_provenance": r.get("pmc_provenance"),
+           "pmc_provenance": r.get("pmc_provenance"), "pmc_measured_in_this_run": False,
            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
            "workload": line["config"]["workload"]}
     for k in ("rel_err_ddim_teacher_forced", "launches_per_reverse_step", "exchange_timeouts_recovered"):

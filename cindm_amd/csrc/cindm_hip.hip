@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -119,6 +120,8 @@ struct cindm_unet1d {
     int no_xchg_force = 0;
     int recovered = 0;                     // chains / forwards re-run in exchange-free mode after a time-out (cindm_unet1d_recovered)
     bool NX() const { return no_xchg_force || O("no_exchange"); }
+    // cindm_unet1d_workspace_bytes' cache (one entry: a sampling loop asks for the same row count over and over)
+    mutable std::mutex wsb_mu; int wsb_gen = -1, wsb_nx = -1; int64_t wsb_rows = -1; size_t wsb_val = 0;
     int plan_nx = -1;                      // the mode h->launches / pf_table were planned for
     // phase clocks (profiling builds): [slot][PH_MAXWG][PH_MAXWAVE][PH_NST] uint64, armed by cindm_unet1d_phase_prof_enable
     unsigned long long* ph_buf = nullptr; int ph_on = 0;
@@ -1787,6 +1790,12 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
 extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h_, int64_t rows) {
     cindm_unet1d* h = const_cast<cindm_unet1d*>(h_);
     if (!h || !h->finalized || rows <= 0) return 0;
+    // cached per (pack generation, rows, the run-time "no_exchange" option): the eager entry points ask on every call
+    // (cindm_unet1d_forward, twice more per run_step through step_layout) and the answer is two dry emissions of the forward
+    {
+        std::lock_guard<std::mutex> lk(h->wsb_mu);
+        if (h->wsb_gen == h->generation && h->wsb_rows == rows && h->wsb_nx == h->O("no_exchange") && h->wsb_val) return h->wsb_val;
+    }
     size_t need = 0;
     const int keep = h->no_xchg_force;
     for (int nx = 0; nx < 2; ++nx) {
@@ -1797,6 +1806,10 @@ extern "C" size_t cindm_unet1d_workspace_bytes(const cindm_unet1d* h_, int64_t r
         need = std::max(need, D.ws_off);
     }
     h->no_xchg_force = keep;
+    {
+        std::lock_guard<std::mutex> lk(h->wsb_mu);
+        h->wsb_gen = h->generation; h->wsb_rows = rows; h->wsb_nx = h->O("no_exchange"); h->wsb_val = need + 256;
+    }
     return need + 256;
 }
 

@@ -74,8 +74,14 @@ __device__ unsigned long long g_ws_prof[WSP_CAT][2][WSP_NPH];
 #define WSP_FLUSH(role_) do { } while (0)
 #endif
 
-template <int KIND, int MODE, bool KSPLIT = true>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// VAR: how the matrix waves divide an item.  0 = round 2's k-groups (wave = k half x column half, reduction through LDS per tile);
+// 1 = no split, v_mfma_f32_16x16x32_f16 (wave = pixel half x column half); 2 = no split on v_mfma_f32_32x32x16_f16: half as many
+// matrix instructions per item (216 x 32 cycles instead of 432 x 16-17: the 32 x 32 shape reaches the pipe's full rate,
+// MI355X_MICROARCH.md, and every MFMA boundary is a place where the co-resident memory wave's VALU issue can delay the next one).
+template <int KIND, int MODE, int VAR = 0>
 __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
+    constexpr bool KSPLIT = VAR == 0;
     // KIND CONV_3X3_PAIR (ForceUnet's 8 x 8 level): the images are 8 pixels wide and a tile is rows ty0 .. ty0 + 7 of images
     // 2j | 2j + 1 side by side (a.NI counts PAIRS).  Each half keeps its own zero columns: the window is 10 x 20 pixels,
     // [pad A0..A7 pad | pad B0..B7 pad], and the right half's fragment / staging addresses are shifted by two pixels.
@@ -123,7 +129,120 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const int tpi_sh = (a.tpi & (a.tpi - 1)) == 0 ? 31 - __builtin_clz(a.tpi) : -1;
     const int tx_sh = (a.tiles_x & (a.tiles_x - 1)) == 0 ? 31 - __builtin_clz(a.tiles_x) : -1;
 
-    if (role == 0 && !KSPLIT) {
+    if (role == 0 && VAR == 2) {
+        // =========================== matrix waves, K not split, 32 x 32 x 16 MFMAs (round 5) =======================
+        // wave = (pixel half ph: tile rows 4 ph .. 4 ph + 3 = two 32-pixel blocks, column half nh: 32 channels).  A fragment of a
+        // 32-pixel block: lane l = pixel (tile row (l >> 4) & 1, x = l & 15), channels 16 ks + 8 (l >> 5) + e; B fragment: lane l =
+        // column l & 31, the same k -- read from the k-group pack of the other variants at a per-lane offset (the 16 bytes of
+        // (k half kg = ks >> 1, column block (l >> 4) & 1, k quarter 2 (ks & 1) + (l >> 5), column l & 15)), so no second weight layout.
+        // Accumulator i of a 32 x 32 tile: column l & 31, row 8 (i >> 2) + 4 (l >> 5) + (i & 3): four consecutive pixels per quad.
+        const int ph = lw & 1, nh = lw >> 1;
+        if (a.dbg == 11 || (a.dbg != 10 && a.dbg != 12 && MODE != SRC2_GN_SS_SILU)) __builtin_amdgcn_s_setprio(3);
+        f32x16 accM[2], accL[2];
+        half8 breg[3][4][2];                                  // [ring slot][k-step of 16][plane]
+        const int l15 = lane & 15, lb4 = (lane >> 4) & 1, l5 = lane >> 5;
+        // uint4 index inside a (n-tile, chunk, tap) block of 4 q-blocks x 256 threads: q = 2 * column block + plane
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (2 * lb4) * 256 + (2 * nh) * 64 + l5 * 16 + l15;
+        auto load_b = [&](int nt, int ch, int tap, int slot_) {
+            const uint4* wp = wbase + ((size_t)(nt * nch + ch) * 9 + tap) * 4 * 256;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) breg[slot_][ks][pl] = __builtin_bit_cast(half8, wp[pl * 256 + (ks >> 1) * 64 + (ks & 1) * 32]);
+        };
+        const int foff = (lb4 * SW + l15 + (PAIR && l15 >= 8 ? 2 : 0)) * V2PITCH + l5 * 16;
+        // 36 steps (tap, k-step of 16): both 32-pixel blocks per step, fragments of step s + 2 read while step s multiplies
+        auto compute = [&](const unsigned char* P0, int nt, int ch, int nt2, int ch2, auto FIRST_) {
+            constexpr bool FIRST = decltype(FIRST_)::value;
+            const unsigned char* P1 = P0 + PLANE;
+            half8 fh[3][2], fl[3][2];
+            auto read_frag = [&](int s, int slot_) {
+                const int tap = s >> 2, ks = s & 3;
+                const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const int o = ((4 * ph + 2 * pb + dy) * SW + dx) * V2PITCH + ks * 32;
+                    fh[slot_][pb] = *reinterpret_cast<const half8*>(P0 + o);
+                    fl[slot_][pb] = *reinterpret_cast<const half8*>(P1 + o);
+                }
+            };
+            read_frag(0, 0); read_frag(1, 1);
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                const int tap = s >> 2, ks = s & 3, bs = tap % 3, fs = s % 3;
+                if (s + 2 < 36) read_frag(s + 2, (s + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const bool z = FIRST && s == 0;
+                f32x16 zero;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+                accM[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][0], breg[bs][ks][0], z ? zero : accM[0], 0, 0, 0);
+                accM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][1], breg[bs][ks][0], z ? zero : accM[1], 0, 0, 0);
+                accL[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][0], breg[bs][ks][1], z ? zero : accL[0], 0, 0, 0);
+                accL[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][1], breg[bs][ks][1], z ? zero : accL[1], 0, 0, 0);
+                accL[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[fs][0], breg[bs][ks][0], accL[0], 0, 0, 0);
+                accL[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[fs][1], breg[bs][ks][0], accL[1], 0, 0, 0);
+                if (ks == 3) {                               // this slot's next tap (of this or the next item), two taps ahead
+                    if (tap + 3 < 9) load_b(nt, ch, tap + 3, bs);
+                    else load_b(nt2, ch2, tap + 3 - 9, bs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
+        stress_delay(a.stress, 100u);
+        __syncthreads();                                     // S0: item 0 is staged
+        WSP_DECL;
+        int k = 0;
+        for (int tl = 0; tl < mine; ++tl)
+            for (int nt = NSPLIT ? nt_of(tl) : 0, nt_end = NSPLIT ? nt + 1 : ntiles; nt < nt_end; ++nt) {
+                const int nt_after = NSPLIT ? (tl + 1 < mine ? nt_of(tl + 1) : 0) : (nt + 1 < ntiles ? nt + 1 : 0);
+                {
+                    const int nt2 = nch > 1 ? nt : nt_after, ch2 = nch > 1 ? 1 : 0;
+                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, 0, nt2, ch2, std::true_type{});
+                    else {
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { accM[pb][i] = 0.f; accL[pb][i] = 0.f; }
+                    }
+                    ++k;
+                    WSP(0); WSP_COUNT();
+                    stress_delay(a.stress, 101u + 8u * (unsigned)k);
+                    __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
+                    WSP(1);
+                }
+                for (int ch = 1; ch < nch; ++ch) {
+                    const int nt2 = ch + 1 < nch ? nt : nt_after, ch2 = ch + 1 < nch ? ch + 1 : 0;
+                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
+                    ++k;
+                    WSP(0); WSP_COUNT();
+                    stress_delay(a.stress, 102u + 8u * (unsigned)k);
+                    __syncthreads();                         // S1
+                    WSP(1);
+                }
+                // channel nh * 32 + (lane & 31); pixels 64 ph + 32 pb + 8 j + 4 (lane >> 5) .. + 3: one ds_write_b128 per (pb, j)
+                const int gn = nt * T2N + nh * 32 + (lane & 31);
+                const float bias = (a.bias && gn < a.N) ? a.bias[gn] : 0.f;
+                float* const trow = Tile + (nh * 32 + (lane & 31)) * V2LDT + ph * 64 + l5 * 4;
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float4 v;
+                        v.x = (accM[pb][4 * j + 0] + accL[pb][4 * j + 0] * H3_INV) + bias; v.y = (accM[pb][4 * j + 1] + accL[pb][4 * j + 1] * H3_INV) + bias;
+                        v.z = (accM[pb][4 * j + 2] + accL[pb][4 * j + 2] * H3_INV) + bias; v.w = (accM[pb][4 * j + 3] + accL[pb][4 * j + 3] * H3_INV) + bias;
+                        *reinterpret_cast<float4*>(trow + pb * 32 + j * 8) = v;
+                    }
+                WSP(2);
+                stress_delay(a.stress, 104u + 8u * (unsigned)k);
+                __syncthreads();                             // S3: the finished tile is in LDS
+                WSP(3);
+            }
+        WSP_FLUSH(0);
+        return;
+    }
+    if (role == 0 && VAR == 1) {
         // ================================ matrix waves, K not split over the waves (round 5) ======================
         // wave = (pixel half ph: pixel blocks 4 ph .. 4 ph + 3, column half nh), ALL 64 channels of the chunk: the k-group
         // reduction of the variant below (kg = 1 parks its partial tile in LDS, barrier, kg = 0 adds, barrier: 1.75 us of a
