@@ -75,7 +75,9 @@ __device__ unsigned long long g_ws_prof[WSP_CAT][2][WSP_NPH];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// VAR: how the matrix waves divide an item.  0 = round 2's k-groups (wave = k half x column half, reduction through LDS per tile);
+// VAR: how the matrix waves divide an item.  3 = as 1 with the TRANSPOSED product and the store path (bias, float4 rows, GroupNorm
+// partials) inside the matrix waves: no output tile in LDS, no write_tile in the memory waves, ONE barrier per item (plain and
+// GroupNorm sources of the 3x3 / upsampled kinds; the input-gradient mode and the paired kind keep the tile path).  0 = round 2's k-groups (wave = k half x column half, reduction through LDS per tile);
 // 1 = no split, v_mfma_f32_16x16x32_f16 (wave = pixel half x column half); 2 = no split on v_mfma_f32_32x32x16_f16: half as many
 // matrix instructions per item (216 x 32 cycles instead of 432 x 16-17: the 32 x 32 shape reaches the pipe's full rate,
 // MI355X_MICROARCH.md, and every MFMA boundary is a place where the co-resident memory wave's VALU issue can delay the next one).
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         WSP_FLUSH(0);
         return;
     }
-    if (role == 0 && VAR == 1) {
+    if (role == 0 && (VAR == 1 || VAR == 3)) {
         // ================================ matrix waves, K not split over the waves (round 5) ======================
         // wave = (pixel half ph: pixel blocks 4 ph .. 4 ph + 3, column half nh), ALL 64 channels of the chunk: the k-group
         // reduction of the variant below (kg = 1 parks its partial tile in LDS, barrier, kg = 0 adds, barrier: 1.75 us of a
@@ -282,17 +284,79 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const bool z = FIRST && tap == 0 && kh == 0;
-                accM[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][0][0], z ? zero : accM[mb][0], 0, 0, 0);
-                accL[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][0][1], z ? zero : accL[mb][0], 0, 0, 0);
-                accM[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][1][0], z ? zero : accM[mb][1], 0, 0, 0);
-                accL[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][kh][1][1], z ? zero : accL[mb][1], 0, 0, 0);
-                accL[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][kh][0][0], accL[mb][0], 0, 0, 0);
-                accL[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][kh][1][0], accL[mb][1], 0, 0, 0);
+                // VAR 3: the TRANSPOSED product (A = weights, B = pixels): an accumulator's four registers are four consecutive output
+                // CHANNELS of pixel (lane & 15), i.e. one float4 of the channel-last output row -- the matrix waves store the tile
+                // themselves (below) and no tile goes through LDS
+#define WS_MMA(X_, W_, C_) (VAR == 3 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(W_, X_, C_, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(X_, W_, C_, 0, 0, 0))
+                accM[mb][0] = WS_MMA(fh[fs], breg[bs][kh][0][0], z ? zero : accM[mb][0]);
+                accL[mb][0] = WS_MMA(fh[fs], breg[bs][kh][0][1], z ? zero : accL[mb][0]);
+                accM[mb][1] = WS_MMA(fh[fs], breg[bs][kh][1][0], z ? zero : accM[mb][1]);
+                accL[mb][1] = WS_MMA(fh[fs], breg[bs][kh][1][1], z ? zero : accL[mb][1]);
+                accL[mb][0] = WS_MMA(fl[fs], breg[bs][kh][0][0], accL[mb][0]);
+                accL[mb][1] = WS_MMA(fl[fs], breg[bs][kh][1][0], accL[mb][1]);
+#undef WS_MMA
                 if ((s & 7) == 7) {                          // this slot's next tap (of this or the next item), two taps ahead
                     if (tap + 3 < 9) load_b(nt, ch, tap + 3, bs);
                     else load_b(nt2, ch2, tap + 3 - 9, bs);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // ---- VAR 3: store path of the matrix waves (bias, float4 row stores, GroupNorm partials), called BEFORE the barrier that ends
+        // the tile's last chunk: in GroupNorm mode the matrix waves would otherwise wait there for the staging
+        auto store_tile3 = [&](int tl, int nt) {
+            const int mt = lo + wj + tl * wpx;
+            const int img = tpi_sh >= 0 ? mt >> tpi_sh : mt / a.tpi, ti = mt - img * a.tpi;
+            const int tyi = tx_sh >= 0 ? ti >> tx_sh : ti / a.tiles_x;
+            const int ty0 = tyi * V2Y, tx0 = (ti - tyi * a.tiles_x) * V2X;
+            const int lr_ = lane & 15, lq_ = lane >> 4;
+            const int gw = a.so_gw;               // 8 or 16 channels per GroupNorm group
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int col = nt * T2N + nh * 32 + nb * 16 + lq_ * 4;
+                const bool nok = col < a.N;               // N is a multiple of 4 (host)
+                // (pointer selected, load unconditional: a load under a branch makes the join wait vmcnt(0) and drains the weight ring)
+                const float4 braw = *reinterpret_cast<const float4*>((a.bias ? a.bias : a.W) + (nok ? col : 0));
+                const float4 b4 = (a.bias && nok) ? braw : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    v[mb].x = (accM[mb][nb][0] + accL[mb][nb][0] * H3_INV) + b4.x; v[mb].y = (accM[mb][nb][1] + accL[mb][nb][1] * H3_INV) + b4.y;
+                    v[mb].z = (accM[mb][nb][2] + accL[mb][nb][2] * H3_INV) + b4.z; v[mb].w = (accM[mb][nb][3] + accL[mb][nb][3] * H3_INV) + b4.w;
+                    if (nok && a.dbg != 4)
+                        *reinterpret_cast<float4*>(a.out + ((size_t)(img * a.Hout + ty0 + 4 * ph + mb) * a.Wout + tx0 + lr_) * a.ldo + col) = v[mb];
+                }
+                if (a.stats_out) {
+                    // one partial per 32 pixels (tile rows 4 ph + 2 mp, + 1) and group: shifted sums about the group's first
+                    // channel at the pair's first pixel -- lane (lr = 0, first lq of the group), register x of block 2 mp
+#pragma unroll
+                    for (int mp = 0; mp < 2; ++mp) {
+                        const int kb = __builtin_bit_cast(int, v[2 * mp].x);
+                        const float K0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kb, 0));
+                        const float K2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kb, 32));
+                        const float K = (gw == 8 && lq_ >= 2) ? K2 : K0;
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float4 x = v[2 * mp + u];
+                            const float d0 = x.x - K, d1 = x.y - K, d2 = x.z - K, d3 = x.w - K;
+                            s1 += (d0 + d1) + (d2 + d3);
+                            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                        }
+                        s1 = row16_sum(s1); s2 = row16_sum(s2);            // the 16 pixels of a tile row (lanes lr)
+                        s1 = xsum16(s1); s2 = xsum16(s2);                  // the lq pair: 8 channels
+                        if (gw >= 16) { s1 = xsum32(s1); s2 = xsum32(s2); }        // all four lq: 16 channels
+                        const bool writer = lr_ == 0 && (gw == 8 ? (lq_ & 1) == 0 : lq_ == 0);
+                        if (writer && nok) {
+                            const int g = col >> (31 - __builtin_clz(gw));
+                            const float ine = 1.0f / (float)(32 * gw);             // a power of two
+                            float* o = a.stats_out + (((size_t)img * 8 + g) * (a.tpi * WS_SPT) + ti * WS_SPT + 2 * ph + mp) * 2;
+                            const float mean_d = s1 * ine;
+                            o[0] = K + mean_d;
+                            o[1] = fmaxf(s2 - s1 * mean_d, 0.f);
+                        }
+                    }
+                }
             }
         };
         { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
@@ -314,6 +378,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     }
                     ++k;
                     WSP(0); WSP_COUNT();
+                    if constexpr (VAR == 3) { if (nch == 1) store_tile3(tl, nt); }
                     stress_delay(a.stress, 101u + 8u * (unsigned)k);
                     __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
                     WSP(1);
@@ -323,10 +388,12 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
                     ++k;
                     WSP(0); WSP_COUNT();
+                    if constexpr (VAR == 3) { if (ch == nch - 1) store_tile3(tl, nt); }
                     stress_delay(a.stress, 102u + 8u * (unsigned)k);
                     __syncthreads();                         // S1
                     WSP(1);
                 }
+                if constexpr (VAR == 3) { WSP(2); continue; }      // (stored before the last chunk's barrier, above)
                 // every wave writes its finished 64 pixels x 32 channels (+ bias) into the channel-major tile: one ds_write_b128
                 // per (pixel block, column block)
                 float* const trow = Tile + (nh * 32 + (lane & 15)) * V2LDT + (lane >> 4) * 4 + ph * 64;
@@ -775,7 +842,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         if (stress > 0) stress_delay(stress, 204u + 8u * (unsigned)k);
         if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1, k + 1); }
         WSP(0); WSP_COUNT();
-        if (pmt >= 0) load_acc(pmt, pnt);
+        if (VAR != 3 && pmt >= 0) load_acc(pmt, pnt);
         if (k + 2 < nitems && dbg != 5) {
             mtn = c2.mt; chn = c2.ch;
             staged_skip = (mtn == mt && chn == ch);                // its buffer, (k + 2) & 1, holds item k's planes: these
@@ -784,12 +851,12 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         }
         WSP(1);
         if (stress > 0) stress_delay(stress, 201u + 8u * (unsigned)k);
-        if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt, pk); pmt = -1; }
+        if (VAR != 3 && pmt >= 0 && dbg != 5) { write_tile(pmt, pnt, pk); pmt = -1; }
         WSP(2);
         if (stress > 0) stress_delay(stress, 202u + 8u * (unsigned)k);
         __syncthreads();                                     // S1
         WSP(3);
-        if (ch == nch - 1) {
+        if (VAR != 3 && ch == nch - 1) {                     // (VAR 3: the matrix waves store the tile themselves: one barrier per item)
             if constexpr (KSPLIT) __syncthreads();           // S2
             if (stress > 0) stress_delay(stress, 203u + 8u * (unsigned)k);
             __syncthreads();                                 // S3
@@ -799,7 +866,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         c0 = c1; c1 = c2; cur_next(c2);
         mt = c0.mt; nt = c0.nt; ch = c0.ch;
     }
-    if (pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
+    if (VAR != 3 && pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
     WSP_FLUSH(1);
 }
 
