@@ -13,6 +13,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "stress_gate: hand-over protocols under skew / foreign load (-m 'gpu and stress_gate')")
 
 
 @pytest.fixture(scope="session")

@@ -177,6 +177,7 @@ def _concurrent_worker(rank, q, go, batch, t_stop):
     q.put(("done", rank, outs, d.model.recovered))
 
 
+@pytest.mark.stress_gate
 def test_two_processes_sampling_concurrently_on_one_device(device):
     """Two independent processes sample on the SAME device at the same time, full-size launches (256 designs: one workgroup per
     CU each, so the two processes' launches compete for every CU).  Co-residency of a launch's workgroups is then not given;

@@ -233,6 +233,7 @@ def test_forceunet_autograd_runs_the_references_force_fn(device, force):
         assert not m(x.to(device).requires_grad_(True)).requires_grad
 
 
+@pytest.mark.stress_gate
 @pytest.mark.parametrize("seed", [1, 7919])
 def test_forceunet_stress_mode(device, force, seed):
     """768 images (config 5's surrogate pass) with pseudo-random pauses before every hand-over of the persistent 3x3 kernel:

@@ -373,6 +373,7 @@ def test_forward_check_opt_out(device):
         assert m.poll_status(device) is False and torch.equal(y, ref)
 
 
+@pytest.mark.stress_gate
 @pytest.mark.parametrize("seed", [1, 7919])
 def test_stress_mode_1d(device, seed):
     """Pseudo-random pauses in front of every in-kernel hand-over (option "stress" = seed: dconv_kernel's GroupNorm pair
@@ -391,6 +392,7 @@ def test_stress_mode_1d(device, seed):
     m.set_option("stress", 0)
 
 
+@pytest.mark.stress_gate
 @pytest.mark.parametrize("seed", [1, 7919])
 def test_stress_mode_2d(device, seed):
     """The same for conv2d_ws_kernel's matrix / memory wave pipeline at the 128-image bench shape: pauses before each of

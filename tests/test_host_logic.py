@@ -528,3 +528,39 @@ def test_isa_audit_counts_exposed_loads(tmp_path):
     asm.write_text("_ZN5cindm6kernelEv:\n" + "\n".join("\t" + l for l in body) + "\n")
     names = [n for n, _ in ia.kernels(asm.read_text().split("\n"))]
     assert names == ["_ZN5cindm6kernelEv"]
+
+
+def test_isa_handover_order_check_on_fragments():
+    """tools/isa_audit.py::handover_order on hand-written fragments: payload loads behind the poll loop pass, a payload load hoisted
+    into / above the loop fails, a granule-only kernel has nothing to check."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    ia = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ia)
+    poll = [".LBB0_1:", "global_load_dword v6, v[2:3], off sc1", "global_load_dword v7, v[2:3], off offset:32 sc1", "s_waitcnt vmcnt(0)",
+            "v_cmp_ne_u32_e32 vcc, v6, v1", "s_cbranch_vccnz .LBB0_1"]
+    good = ["s_nop 0"] + poll + ["buffer_load_dwordx4 v[26:29], v2, s[24:27], 0 offen sc1", "buffer_load_dwordx4 v[30:33], v2, s[24:27], 0 offen offset:1024 sc1"]
+    ok, flags, end, first = ia.handover_order(good)
+    assert ok and len(flags) == 2 and first > end
+    hoisted = ["s_nop 0"] + poll[:3] + ["buffer_load_dwordx4 v[26:29], v2, s[24:27], 0 offen sc1"] + poll[3:] + ["buffer_load_dwordx4 v[30:33], v2, s[24:27], 0 offen sc1"]
+    assert ia.handover_order(hoisted)[0] is False
+    assert ia.handover_order(["global_load_dwordx2 v[16:17], v[22:23], off sc1", "s_waitcnt vmcnt(0)"]) is None
+
+
+def test_isa_handover_order_of_the_built_kernels(tmp_path):
+    """The regression guard round 4's review asked for: the cross-workgroup hand-over of dconv2_kernel orders its acquire side by the
+    compiler only (relaxed flag loads, a compiler barrier, sc1 payload loads -- the agent-scope fence costs 1.7 us x 9 launches); a
+    hipcc update that moved a payload load above the poll loop would be a silent race.  The ISA of the library as built here must
+    show every 16-byte sc1 payload load behind the end of the flag poll loop, in every dconv2_kernel instantiation."""
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "cindm.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", '-DCINDM_SRC_HASH="audit"', "--cuda-device-only",
+                        "-S", "-o", str(out), os.path.join(ROOT, "cindm_amd", "csrc", "cindm_hip.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), str(out), "--handover"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout
+    lines = [ln for ln in a.stdout.splitlines() if "dconv2_kernel" in ln]
+    assert len(lines) >= 7 and all(" OK " in ln for ln in lines), a.stdout
