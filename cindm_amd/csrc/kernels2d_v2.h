@@ -642,15 +642,12 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         const int origin = (KIND == CONV_UP2) ? img * HWi + (ty0 >> 1) * Win + (tx0 >> 1) : (PAIR ? 2 * img : img) * HWi + ty0 * Win + tx0;
         const int t4 = (origin * ld + clc) * 4;               // byte offset of the tile origin's float4 of this thread
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, first ? src_bytes0 : src_bytes1, 0x00020000);
-        // Plain / scaled sources: a window pixel outside the image (or a channel quad beyond the source) is requested at an offset
-        // beyond the buffer, which a raw-buffer load answers with zeros -- one select per pixel here instead of four per pixel on
-        // the staged values (store_item); GroupNorm mode masks after the SiLU (SiLU(GN(0)) is not 0).
-        constexpr bool OOB_MASK = MODE != SRC2_GN_SS_SILU;
+        // (Round 5 tried to mask here instead of in store_item -- a window pixel outside the image requested at an offset beyond the
+        // buffer, which a raw-buffer load answers with zeros: one select per pixel instead of four.  Same-box against the round's first
+        // commit the plain-source launches were 4 - 7 % SLOWER with it (profiles/r05_round_ratio.txt, first column pair): removed.)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            int off = dpix4[p] * ld + t4;
-            if constexpr (OOB_MASK) off = (((okmask >> p) & 1u) && cok) ? off : 0x7ffffff0;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, dpix4[p] * ld + t4, 0, 0);
             areg[p] = __builtin_bit_cast(float4, v);
         }
         if constexpr (MODE == SRC2_GN_SS_SILU) {
@@ -717,10 +714,8 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                 v.w = silu_f(__builtin_fmaf(v.w, fa.w, fb.w));
             }
             if constexpr (MODE == SRC2_SCALED) { v.x *= in_s; v.y *= in_s; v.z *= in_s; v.w *= in_s; }
-            if constexpr (MODE == SRC2_GN_SS_SILU) {          // (the other modes loaded zeros for these pixels: load_item)
-                const bool ok = ((okmask >> p) & 1u) && cok;
-                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            }
+            const bool ok = ((okmask >> p) & 1u) && cok;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
             half4v hi, lo;
             hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
             lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
