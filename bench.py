@@ -207,7 +207,7 @@ def timed_cpu_steps(step_once, budget_s, reps=3, max_steps=100):
 # one child per swept count, one child for the timed leg at the winner.  The parent only reads their result files (the tape
 # the rel_err leg replays comes back that way too).  tests/test_host_logic.py::test_cpu_leg_is_self_consistent holds the timed
 # leg to 1.3 x the sweep's value at the same count.
-def cpu_leg_make_step(spec):
+def cpu_baseline_leg_step(spec):
     """(x0, draw(k) -> noise of step k, step(x, k, noise) -> x', label) of a CPU-leg spec; runs in the child."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cindm_oracle as O
@@ -254,7 +254,7 @@ def cpu_leg_child(spec_path):
     """`python bench.py --cpu-leg-child SPEC`: one measurement at the thread count the parent fixed in this process's environment."""
     spec = torch.load(spec_path, weights_only=False)
     torch.set_num_threads(int(spec["threads"]))          # (the environment already says so; this pins ATen's own count as well)
-    x0, draw, step, t_first = cpu_leg_make_step(spec)
+    x0, draw, step, t_first = cpu_baseline_leg_step(spec)
     with torch.no_grad():
         if spec["mode"] == "sweep":
             # SUSTAINED rate: at least 3 steps and `sweep_seconds` of them.  (Round 5, first try: one step after a warm-up -- 46.7 ms at

@@ -1,4 +1,4 @@
-"""debug: run one U-Net variant against the oracle (python tools/debug/variants.py hz F att B)"""
+"""debug: run one U-Net variant against the oracle (python tests/manual/variants.py hz F att B)"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
