@@ -1564,6 +1564,98 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
     }
 }
 
+// conv_unshuf_h3p_kernel (round 5): Downsample (:105-109) = pixel-unshuffle + 1x1 convolution (4 C -> Cout) for C = 64, Cout = 64 in the
+// pipelined form of conv1x1_tail_h3p_kernel: out[oy][ox][n] = b[n] + sum_{p1, p2, c} W[n][c * 4 + p1 * 2 + p2] x[2 oy + p1][2 ox + p2][c].
+// It ran on conv2d_tile_kernel<CONV_UNSHUF> -- exact fp32 MFMA, 180 + 96 registers and 107 KB of LDS: one short-lived workgroup per CU,
+// 88 us for 168 MB.  Here: K = 256 = 4 taps x 64 channels as 8 k-steps of the split-fp16 product, a workgroup of 8 waves loops over
+// 64-pixel output tiles (wave = 16 output channels x 32 pixels), the next tile's 64 x 4 input pixels are requested before the products.
+// Weights: [k-step 8][plane][thread = (wave & 3) * 64 + lane][8 halfs] = W'[n = (wave & 3) * 16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e],
+// k = tap * 64 + c.
+__global__ __launch_bounds__(512, 2) void conv_unshuf_h3p_kernel(const Conv2dArgs a) {
+    constexpr int KT = 256, KS = 8, PITCH = KT * 2 + 16, F4 = KT / 4, NTH = 512, NPASS = (64 * F4) / NTH;
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lq = lane & 15, lg = lane >> 4;
+    const int HWo = a.Hout * a.Wout;
+    const int ntl = (int)(a.rows_total >> 6);
+    const int t_lo = (int)(((long long)blockIdx.x * ntl) / gridDim.x), t_hi = (int)(((long long)(blockIdx.x + 1) * ntl) / gridDim.x);
+    if (t_lo >= t_hi) return;
+    const int ct = w & 3, ph = w >> 2;                       // channel tile of 16, pixel half of the tile
+    const int col = ct * 16 + lg * 4;
+    half8 wv[KS][2];
+    {
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + ct * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[((size_t)ks * 2 + pl) * 256]);
+    }
+    const bool nok = col < a.N;
+    const float4 braw = *reinterpret_cast<const float4*>((a.bias ? a.bias : a.W) + (nok ? col : 0));
+    const float4 bias = (a.bias && nok) ? braw : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = a.src[0].p;
+    const int ld = a.src[0].ld, Win = a.Win, HWi = a.Hin * a.Win, Wout = a.Wout;
+    float4 sv[NPASS];
+    auto load_x = [&](int t) {
+        const int p0 = t * 64;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int i = tid + NTH * p;
+            const int r = i >> 6, c4 = i & 63;              // output pixel of the tile, float4 of its 256 inputs
+            const int tap = c4 >> 4, ch = (c4 & 15) * 4;
+            const int pix = p0 + r, img = pix / HWo, q = pix - img * HWo;
+            const int oy = q / Wout, ox = q - oy * Wout;
+            sv[p] = *reinterpret_cast<const float4*>(src + ((size_t)img * HWi + (size_t)(2 * oy + (tap >> 1)) * Win + 2 * ox + (tap & 1)) * ld + ch);
+        }
+    };
+    auto split_x = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int i = tid + NTH * p;
+            const int r = i >> 6, c4 = i & 63;
+            const float4 v = sv[p];
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            *reinterpret_cast<half4v*>(&Xs[0][r * PITCH + c4 * 8]) = hi;
+            *reinterpret_cast<half4v*>(&Xs[1][r * PITCH + c4 * 8]) = lo;
+        }
+    };
+    const unsigned char* xh0 = &Xs[0][(ph * 32 + lq) * PITCH + lg * 16];
+    const unsigned char* xl0 = &Xs[1][(ph * 32 + lq) * PITCH + lg * 16];
+    load_x(t_lo);
+    for (int t = t_lo; t < t_hi; ++t) {
+        split_x();
+        __syncthreads();
+        if (t + 1 < t_hi) load_x(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 accM[2], accL[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) { accM[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[pb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const half8 xh = *reinterpret_cast<const half8*>(xh0 + pb * 16 * PITCH + ks * 64);
+                const half8 xl = *reinterpret_cast<const half8*>(xl0 + pb * 16 * PITCH + ks * 64);
+                accM[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xh, accM[pb], 0, 0, 0);
+                accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
+                accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
+            }
+        if (nok) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const size_t prow = (size_t)t * 64 + ph * 32 + pb * 16 + lq;
+                *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) =
+                    make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
+                                (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // y = LayerNorm_channels(x) * g from the row partials [rows][P][2] (the PreNorm of the bottleneck attention,
 // model/diffusion_2d.py:82-97 / :256): one thread per float4.  A separate 20 us pass so that the qkv projection can run
 // as a plain-source GEMM on conv1x1_tail_h3_kernel (the LayerNorm-on-load variant of that kernel was not reliable).
@@ -1759,9 +1851,11 @@ struct La2dArgs {
     int spw, tpw;                  // 128-pixel slices per context workgroup ; 64-pixel tiles per apply workgroup
     int dbg;                       // timing ablations (wrong results)
 };
-constexpr int LA2_PX = 128;        // pixels per context slice at C = 64; C = 128 uses 64 (la2_px): half the k|v registers, measured 108 -> 61 us
+constexpr int LA2_PX = 128;        // pixels per context slice in rounds 2 - 4 at C = 64; C = 128 used 64 (half the k|v registers, measured 108 -> 61 us).
+                                   // Round 5: 64 pixels at C = 64 too -- with the split-fp16 context product (H16) the kernel then fits 244 registers,
+                                   // i.e. TWO workgroups per CU: one's LayerNorm / softmax VALU phases run under the other's products
 constexpr int LA2_REC = 64 + 1024;
-constexpr int la2_px(int C) { return C == 64 ? LA2_PX : LA2_PX / 2; }
+constexpr int la2_px(int C) { return LA2_PX / 2; }
 
 // LayerNorm over C channels (biased variance, eps 1e-5) * g of the NPX tile rows held in xr (thread (lrow, lcol) owns
 // columns 4*lcol.. of rows r*RPP + lrow) -> (hi, scaled lo) fp16 planes
@@ -1805,7 +1899,7 @@ struct LnTile {
 // hi / lo splits of k and v (VALU).  exp(k - max) is in (0, 1] and v is a projection of LayerNorm output: both inside the range
 // rule of the split; two fp32 accumulator sets as everywhere.
 template <int C, bool H16 = true>
-__global__ __launch_bounds__(256) void la2d_context_kernel(const La2dArgs a) {
+__global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la2d_context_kernel(const La2dArgs a) {
     constexpr int PX = la2_px(C);
     using LN = LnTile<C, PX>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, NTL = PX / 16;
