@@ -784,6 +784,126 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem7_h3_kernel(const Conv2dArg
     conv2d_h3_epilogue(a, acc, Red, img, ti, ty0, tx0);
 }
 
+// conv2d_stem7_h3d_kernel (round 5): the stem with a DENSE reduction axis and TWICE the pixels per weight fragment.
+// What bounds conv2d_stem7_h3_kernel is neither its 600 MFMAs per wave nor its stores but the WEIGHT STREAM: every 64-pixel workgroup
+// reads the whole 410 KB pack from L2 -- 3.4 GB per launch, 16 TB/s at 206 us, every CU asking for the same lines (ablations of
+// tools/r5_exp_stem2.py: three slots of products instead of all: the launch all but disappears; 25 % fewer MFMAs at the same bytes
+// per product, three workgroups per CU, a deeper weight prefetch: each neutral or slower).  So: (1) a pixel is 24 halfs = 48 B in
+// the LDS planes and the seven taps of one kernel ROW of an output pixel are 168 CONTIGUOUS halfs starting at its window pixel: five
+// k-steps cover 160 of them (lane group lg reads halfs 32 s + 8 lg .. + 7 -- any 16-byte-aligned address is a legal fragment), and
+// the seven rows' last 8 halfs (tap column 6, channels 16 - 23) are gathered into two more k-steps (lane group lg = kernel row
+// lg + 4 j): 37 k-steps instead of one per tap = 49, a pack of 311 KB; (2) a workgroup owns 8 x 16 pixels: a weight fragment feeds
+// eight pixel blocks, 155 KB of weights per 64 pixels instead of 410.  Slots: k-step 2 i + kg for the wave pair kg, 19 slots (the
+// 38th k-step is a zero pad).  K-group reduction and epilogue of conv2d_stem7_h3_kernel, once per half of the tile.
+constexpr int STEMD_NI = 19, STEMD_KS = 37, STEMD_TY = 8;
+__global__ __launch_bounds__(256, 2) void conv2d_stem7_h3d_kernel(const Conv2dArgs a) {
+    constexpr int SW = 22, SH = STEMD_TY + 6, R = SW * SH, PITCH = 48, PLANE = R * PITCH, NP = (R * 6 + 255) / 256;
+    // the reduction / store tile of the epilogue lives in the planes' bytes (barrier in between)
+    constexpr int RED_BYTES = 4 * T2M * LDR2 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RED_BYTES > 2 * PLANE ? RED_BYTES : 2 * PLANE];
+    unsigned char* planes = smem;
+    float (*Red)[T2M * LDR2] = reinterpret_cast<float (*)[T2M * LDR2]>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int kg = w & 1;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int tpi8 = (a.Hout / STEMD_TY) * a.tiles_x;
+    const int img = mt / tpi8, ti = mt - img * tpi8;
+    const int tyi = ti / a.tiles_x;
+    const int ty0 = tyi * STEMD_TY, tx0 = (ti - tyi * a.tiles_x) * T2X;
+    const int HWi = a.Hin * a.Win;
+
+    f32x4 accM[8][2], accL[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    half8 bs[2][2][2];
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)nt * STEMD_NI * 4 * 256 + tid;
+    auto load_b = [&](int i, half8 (&b)[2][2]) {
+        const uint4* wp = wbase + (size_t)i * 4 * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+    };
+    load_b(0, bs[0]);
+    const float* src = a.src[0].p;
+    const int ld = a.src[0].ld;
+    {
+        float4 sv[NP];
+        bool okv[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = tid + 256 * p;
+            const int r = i / 6, c4 = i - r * 6;
+            const int hy = r / SW, hx = r - hy * SW;
+            const int y = ty0 - 3 + hy, x = tx0 - 3 + hx;
+            okv[p] = (r < R) && (c4 * 4 < ld) && (y >= 0) && (y < a.Hin) && (x >= 0) && (x < a.Win);
+            const size_t off = okv[p] ? ((size_t)img * HWi + (size_t)y * a.Win + x) * ld + c4 * 4 : (size_t)img * HWi * ld;
+            sv[p] = *reinterpret_cast<const float4*>(src + off);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = tid + 256 * p;
+            const int r = i / 6, c4 = i - r * 6;
+            const float4 v = okv[p] ? sv[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            half4v hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
+            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
+            if (r < R) {
+                *reinterpret_cast<half4v*>(planes + r * PITCH + c4 * 8) = hi;
+                *reinterpret_cast<half4v*>(planes + PLANE + r * PITCH + c4 * 8) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    const int lq = lane & 15, lg = lane >> 4;
+    const unsigned char* P0 = planes + lq * PITCH + lg * 16;
+    // the gathered k-steps: lane group lg reads kernel row min(lg + 4 j, 6), tap column 6, channels 16 - 23 (row 7 of j = 1: zero weights)
+    const unsigned char* PB[2] = {planes + (lg * SW + lq + 6) * PITCH + 32, planes + (min(lg + 4, 6) * SW + lq + 6) * PITCH + 32};
+#pragma unroll 1
+    for (int i = 0; i < (a.dbg == 22 ? 2 : STEMD_NI + 1); i += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ii = i + u;
+            if (ii < STEMD_NI) {
+                if (a.dbg != 21) load_b(min(ii + 1, STEMD_NI - 1), bs[(u + 1) & 1]);
+                const int ks = min(2 * ii + kg, STEMD_KS - 1);            // wave-uniform; the pad slot carries zero weights
+                const int dy = ks / 5, st = ks - dy * 5;
+                const unsigned char* pa = ks < 35 ? P0 + dy * SW * PITCH + st * 64 : PB[ks - 35];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    half8 ah[4], al[4];
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        ah[mb] = *reinterpret_cast<const half8*>(pa + (hf * 4 + mb) * SW * PITCH);
+                        al[mb] = *reinterpret_cast<const half8*>(pa + PLANE + (hf * 4 + mb) * SW * PITCH);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (without it: 0.95 x instead of 0.92 x of the per-tap kernel)
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            accM[hf * 4 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bs[u][nb][0], accM[hf * 4 + mb][nb], 0, 0, 0);
+                            accL[hf * 4 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bs[u][nb][1], accL[hf * 4 + mb][nb], 0, 0, 0);
+                            accL[hf * 4 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], bs[u][nb][0], accL[hf * 4 + mb][nb], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = accM[hf * 4 + mb][nb] + accL[hf * 4 + mb][nb] * H3_INV;
+        if (a.dbg == 23) { if (acc[0][0][0] == 123.456f) a.out[0] = 1.f; continue; }
+        __syncthreads();                      // every wave is done with the planes / with the other half's tile
+        conv2d_h3_epilogue(a, acc, Red, img, 0, ty0 + 4 * hf, tx0);        // (no GroupNorm partials on this path: the host checks)
+    }
+}
+
 // conv2d_stem7_h3p_kernel (round 5): conv2d_stem7_h3_kernel as a pipelined loop over pixel tiles with a row-wise store path.
 // The one-tile-per-workgroup form ran 237 us at 128 images against ~150 us of matrix time: (1) its phases follow each other (window
 // loads -> split -> 600 MFMAs per wave -> reduce -> stores); (2) its epilogue (conv2d_h3_epilogue) sends every accumulator through LDS
@@ -1564,15 +1684,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
     }
 }
 
-// conv_unshuf_h3p_kernel (round 5): Downsample (:105-109) = pixel-unshuffle + 1x1 convolution (4 C -> Cout) for C = 64, Cout = 64 in the
-// pipelined form of conv1x1_tail_h3p_kernel: out[oy][ox][n] = b[n] + sum_{p1, p2, c} W[n][c * 4 + p1 * 2 + p2] x[2 oy + p1][2 ox + p2][c].
-// It ran on conv2d_tile_kernel<CONV_UNSHUF> -- exact fp32 MFMA, 180 + 96 registers and 107 KB of LDS: one short-lived workgroup per CU,
-// 88 us for 168 MB.  Here: K = 256 = 4 taps x 64 channels as 8 k-steps of the split-fp16 product, a workgroup of 8 waves loops over
-// 64-pixel output tiles (wave = 16 output channels x 32 pixels), the next tile's 64 x 4 input pixels are requested before the products.
-// Weights: [k-step 8][plane][thread = (wave & 3) * 64 + lane][8 halfs] = W'[n = (wave & 3) * 16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e],
-// k = tap * 64 + c.
-__global__ __launch_bounds__(512, 2) void conv_unshuf_h3p_kernel(const Conv2dArgs a) {
-    constexpr int KT = 256, KS = 8, PITCH = KT * 2 + 16, F4 = KT / 4, NTH = 512, NPASS = (64 * F4) / NTH;
+// conv1x1_h3p_kernel<KT, NCT, UNSHUF> (round 5): bias-only 1x1 convolutions in the pipelined form of conv1x1_tail_h3p_kernel -- a
+// workgroup of 2 NCT waves loops over a contiguous run of 64-pixel output tiles (wave = 16 output channels x 32 pixels; its weights
+// stay in registers), the next tile's inputs are requested before the products of the current one.
+//   UNSHUF (KT = 256, NCT = 4): Downsample (:105-109) = pixel-unshuffle + 1x1 convolution (4 C -> Cout) for C = 64, Cout = 64:
+//     out[oy][ox][n] = b[n] + sum_{p1, p2, c} W[n][c * 4 + p1 * 2 + p2] x[2 oy + p1][2 ox + p2][c], k = tap * 64 + c.  It ran on
+//     conv2d_tile_kernel<CONV_UNSHUF> -- exact fp32 MFMA, 180 + 96 registers and 107 KB of LDS: one short-lived workgroup per CU, 88 us
+//     for 168 MB; this one: ~ 40 us.
+//   plain (KT = 64, NCT = 2): final_conv (64 -> channels <= 32; the pad columns of the state's row pitch are written as zeros).
+// Weights: [k-step KT / 32][plane][thread = ct * 64 + lane][8 halfs] = W'[n = ct * 16 + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e].
+template <int KT, int NCT, bool UNSHUF>
+__global__ __launch_bounds__(128 * NCT, 2) void conv1x1_h3p_kernel(const Conv2dArgs a) {
+    constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NTH = 128 * NCT, NPASS = (64 * F4) / NTH;
+    static_assert((64 * F4) % NTH == 0, "whole staging passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lq = lane & 15, lg = lane >> 4;
@@ -1580,7 +1704,7 @@ __global__ __launch_bounds__(512, 2) void conv_unshuf_h3p_kernel(const Conv2dArg
     const int ntl = (int)(a.rows_total >> 6);
     const int t_lo = (int)(((long long)blockIdx.x * ntl) / gridDim.x), t_hi = (int)(((long long)(blockIdx.x + 1) * ntl) / gridDim.x);
     if (t_lo >= t_hi) return;
-    const int ct = w & 3, ph = w >> 2;                       // channel tile of 16, pixel half of the tile
+    const int ct = w % NCT, ph = w / NCT;                    // channel tile of 16, pixel half of the tile
     const int col = ct * 16 + lg * 4;
     half8 wv[KS][2];
     {
@@ -1588,11 +1712,15 @@ __global__ __launch_bounds__(512, 2) void conv_unshuf_h3p_kernel(const Conv2dArg
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[((size_t)ks * 2 + pl) * 256]);
+            for (int pl = 0; pl < 2; ++pl) wv[ks][pl] = __builtin_bit_cast(half8, wbase[((size_t)ks * 2 + pl) * (NCT * 64)]);
     }
-    const bool nok = col < a.N;
+    const bool sok = col < a.ldo;                            // columns N .. ldo - 1 (the pitch's pad): zero weights, zero bias
+    const bool nok = col < a.N;                              // (N % 4 == 0, or the pad columns belong to this buffer: the host checks)
     const float4 braw = *reinterpret_cast<const float4*>((a.bias ? a.bias : a.W) + (nok ? col : 0));
-    const float4 bias = (a.bias && nok) ? braw : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias = (a.bias && nok) ? braw : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col + 1 >= a.N) bias.y = 0.f;
+    if (col + 2 >= a.N) bias.z = 0.f;
+    if (col + 3 >= a.N) bias.w = 0.f;
     const float* src = a.src[0].p;
     const int ld = a.src[0].ld, Win = a.Win, HWi = a.Hin * a.Win, Wout = a.Wout;
     float4 sv[NPASS];
@@ -1601,18 +1729,22 @@ __global__ __launch_bounds__(512, 2) void conv_unshuf_h3p_kernel(const Conv2dArg
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int i = tid + NTH * p;
-            const int r = i >> 6, c4 = i & 63;              // output pixel of the tile, float4 of its 256 inputs
-            const int tap = c4 >> 4, ch = (c4 & 15) * 4;
-            const int pix = p0 + r, img = pix / HWo, q = pix - img * HWo;
-            const int oy = q / Wout, ox = q - oy * Wout;
-            sv[p] = *reinterpret_cast<const float4*>(src + ((size_t)img * HWi + (size_t)(2 * oy + (tap >> 1)) * Win + 2 * ox + (tap & 1)) * ld + ch);
+            const int r = i / F4, c4 = i % F4;              // output pixel of the tile, float4 of its KT inputs
+            if constexpr (UNSHUF) {
+                const int tap = c4 >> 4, ch = (c4 & 15) * 4;
+                const int pix = p0 + r, img = pix / HWo, q = pix - img * HWo;
+                const int oy = q / Wout, ox = q - oy * Wout;
+                sv[p] = *reinterpret_cast<const float4*>(src + ((size_t)img * HWi + (size_t)(2 * oy + (tap >> 1)) * Win + 2 * ox + (tap & 1)) * ld + ch);
+            } else {
+                sv[p] = *reinterpret_cast<const float4*>(src + (size_t)(p0 + r) * ld + c4 * 4);
+            }
         }
     };
     auto split_x = [&]() {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int i = tid + NTH * p;
-            const int r = i >> 6, c4 = i & 63;
+            const int r = i / F4, c4 = i % F4;
             const float4 v = sv[p];
             half4v hi, lo;
             hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
@@ -1643,7 +1775,7 @@ __global__ __launch_bounds__(512, 2) void conv_unshuf_h3p_kernel(const Conv2dArg
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
             }
-        if (nok) {
+        if (sok) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
                 const size_t prow = (size_t)t * 64 + ph * 32 + pb * 16 + lq;
