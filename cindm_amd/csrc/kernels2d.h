@@ -2235,7 +2235,7 @@ __global__ __launch_bounds__(256) void la2d_merge_kernel(const float* __restrict
 // context fragments (times h w, a power of two: the merged context carries v / (h w) and would sit in fp16's subnormals) are split
 // once per workgroup, q per pixel tile: 24 MFMAs per 64-pixel tile instead of 64 fp32 ones (2048 -> 408 matrix-pipe cycles).
 template <int C, bool H16 = true>
-__global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
+__global__ __launch_bounds__(256, C == 64 ? 3 : 1) void la2d_apply_out_kernel(const La2dArgs a) {
     using LN = LnTile<C, 64>;
     constexpr int K32 = C / 32, YPB = 2 * C + 16, APB = 2 * 128 + 16, NPX = 64, NTL = 4, CT = C / 16, TPW = CT / 4, ZP = C + 4;
     __shared__ __attribute__((aligned(16))) unsigned char Yp[2][NPX * YPB];
@@ -2297,9 +2297,14 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
 #pragma unroll 1
     for (int tt = 0; tt < a.tpw; ++tt) {
         const size_t row0 = row00 + (size_t)tt * NPX;
-        float4 xres[LN::NPASS];                           // the tile's own rows, for the residual
+        // the tile's own rows, for the residual.  C = 64: NOT kept -- read again at the end (an L2 hit a few microseconds after the
+        // first read): 16 registers less, which is what lets THREE workgroups share a CU (168 registers, 3 x 52 KB of LDS)
+        constexpr bool RELOAD = C == 64;
+        float4 xres[RELOAD ? 1 : LN::NPASS];
+        if constexpr (!RELOAD) {
 #pragma unroll
-        for (int r = 0; r < LN::NPASS; ++r) xres[r] = xr[r];
+            for (int r = 0; r < LN::NPASS; ++r) xres[r] = xr[r];
+        }
         LN::to_planes(xr, gv, Yp[0], Yp[1], tid);
         __syncthreads();
         if (tt + 1 < a.tpw) LN::load(xr, a.x + (row0 + NPX) * a.ldx, a.ldx, tid);
@@ -2396,9 +2401,12 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
         }
         __syncthreads();
         // out = LayerNorm(z) g2 + x
+        float4 xrl[RELOAD ? LN::NPASS : 1];
+        if constexpr (RELOAD) LN::load(xrl, a.x + row0 * a.ldx, a.ldx, tid);
 #pragma unroll
         for (int r = 0; r < LN::NPASS; ++r) {
             const int n = r * LN::RPP + lrow;
+            const float4 xv = RELOAD ? xrl[RELOAD ? r : 0] : xres[RELOAD ? 0 : r];
             const float4 zv = *reinterpret_cast<const float4*>(&Z[n * ZP + 4 * lcol]);
             const float s1 = rowgroup_sum<LN::LPR>((zv.x + zv.y) + (zv.z + zv.w));
             const float mean = s1 * (1.0f / C);
@@ -2406,8 +2414,8 @@ __global__ __launch_bounds__(256) void la2d_apply_out_kernel(const La2dArgs a) {
             const float s2 = rowgroup_sum<LN::LPR>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
             float4 o4;
-            o4.x = d0 * rstd * gv2.x + xres[r].x; o4.y = d1 * rstd * gv2.y + xres[r].y;
-            o4.z = d2 * rstd * gv2.z + xres[r].z; o4.w = d3 * rstd * gv2.w + xres[r].w;
+            o4.x = d0 * rstd * gv2.x + xv.x; o4.y = d1 * rstd * gv2.y + xv.y;
+            o4.z = d2 * rstd * gv2.z + xv.z; o4.w = d3 * rstd * gv2.w + xv.w;
             *reinterpret_cast<float4*>(a.out + (row0 + n) * a.ldo + 4 * lcol) = o4;
         }
         __syncthreads();                                  // Z (= the y planes) is rewritten by the next tile
