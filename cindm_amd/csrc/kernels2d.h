@@ -1576,8 +1576,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
 // conv1x1_tail_h3_kernel (bit-identical output).  e_y required, no residual / LayerNorm-out operand.
 // NW = waves per workgroup = output channels / 16: 4 (64 channels, two workgroups per CU) or 8 (128 channels: the 32 x 32 level's
 // 192 -> 128 blocks; one 512-thread workgroup per CU, every wave keeps the weights of its own 16 channels).
-template <int KT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
+// EPI: 0 = the tail proper (+ SiLU(GN(y1)), e_y required); 1 = + residual (a.res: the bottleneck attention's to_out); 2 = bias only (its
+// to_qkv).  blockIdx.y selects a group of 16 NW output channels (to_qkv: 384 = 3 groups of 128).
+template <int KT, int NW, int EPI = 0>
+__global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
     constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NTH = 64 * NW, NPASS = (64 * F4) / NTH;
     static_assert((64 * F4) % NTH == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
@@ -1589,11 +1591,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
     const int t_lo = (int)(((long long)blockIdx.x * ntl) / gridDim.x), t_hi = (int)(((long long)(blockIdx.x + 1) * ntl) / gridDim.x);
     if (t_lo >= t_hi) return;
     const Src& s0 = a.src[0];
-    const int col = w * 16 + lg * 4;                             // this lane's 4 consecutive output channels
+    const int wg = blockIdx.y * NW + w;                          // this wave's 16-channel tile of the layer
+    const int col = wg * 16 + lg * 4;                            // this lane's 4 consecutive output channels
     half8 wv[KS][2];
     {
         // [n-tile of 64 channels][k-step][plane][thread within the n-tile = (wave & 3) * 64 + lane]
-        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)(w >> 2) * KS * 2 * 256 + (tid & 255);
+        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (size_t)(wg >> 2) * KS * 2 * 256 + (tid & 255);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1602,8 +1605,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
     const bool nok = col < a.N;
     const int colc = nok ? col : 0;
     const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 eg = *reinterpret_cast<const float4*>(a.e_gamma + colc), eb = *reinterpret_cast<const float4*>(a.e_beta + colc);
-    const int g = colc >> (31 - __builtin_clz(a.e_gw));
+    float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int g = 0;
+    if constexpr (EPI == 0) {
+        eg = *reinterpret_cast<const float4*>(a.e_gamma + colc); eb = *reinterpret_cast<const float4*>(a.e_beta + colc);
+        g = colc >> (31 - __builtin_clz(a.e_gw));
+    }
     float4 sv[NPASS];
     auto load_x = [&](int t) {
         const size_t row0 = (size_t)t * 64;
@@ -1640,7 +1647,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
     for (int t = t_lo; t < t_hi; ++t) {
         const size_t row0 = (size_t)t * 64;
         const int img = (int)(row0 / HWo);
-        if (img != img_have && w == 1) {                         // (wave-uniform: img is a function of t)
+        if (EPI == 0 && img != img_have && w == 1) {             // (wave-uniform: img is a function of t)
             float m, r;
             merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
             if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
@@ -1650,8 +1657,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
         __syncthreads();
         if (t + 1 < t_hi) load_x(t + 1);                         // the next tile's rows, then this tile's y1 rows: both under the products
         float4 yv[4];
+        if constexpr (EPI == 0) {
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + (row0 + pb * 16 + lq) * a.e_ld + colc);
+            for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + (row0 + pb * 16 + lq) * a.e_ld + colc);
+        } else if constexpr (EPI == 1) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.res + (row0 + pb * 16 + lq) * a.ldres + colc);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 accM[4], accL[4];
 #pragma unroll
@@ -1666,7 +1678,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
             }
-        const float em = tabE[2 * g], er = tabE[2 * g + 1];
+        const float em = EPI == 0 ? tabE[2 * g] : 0.f, er = EPI == 0 ? tabE[2 * g + 1] : 1.f;
         __builtin_amdgcn_sched_barrier(0);
         if (nok) {
 #pragma unroll
@@ -1674,9 +1686,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void conv1x1_tail_h3p_ker
                 const size_t prow = row0 + pb * 16 + lq;
                 float4 v = make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
                                        (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
-                const float4 y = yv[pb];
-                v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
-                v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
+                if constexpr (EPI == 0) {
+                    const float4 y = yv[pb];
+                    v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
+                    v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
+                } else if constexpr (EPI == 1) {
+                    v.x += yv[pb].x; v.y += yv[pb].y; v.z += yv[pb].z; v.w += yv[pb].w;
+                }
                 *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
             }
         }
@@ -1793,19 +1809,30 @@ __global__ __launch_bounds__(128 * NCT, 2) void conv1x1_h3p_kernel(const Conv2dA
 // as a plain-source GEMM on conv1x1_tail_h3_kernel (the LayerNorm-on-load variant of that kernel was not reliable).
 __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, int P, float cnt,
                                                        const float* __restrict__ g, float* __restrict__ y, int C, int64_t n4) {
+    // a thread owns FOUR float4 of one row (C / 16 threads per row, 128 contiguous bytes per group of 8 lanes and instruction), all
+    // requested before the row's partials are merged -- one merge per four float4 (round 5: one float4 and one merge per thread,
+    // the x load behind the merge's dependent loads, ran at 2.7 TB/s)
+    const int f4 = C >> 2, lpr = f4 >> 2;                 // float4 per row, threads per row (C % 16 == 0: the host checks)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const int f4 = C >> 2;
-    const int64_t row = i / f4;
-    const int c4 = (int)(i - row * f4);
+    const int64_t row = i / lpr;
+    if (row * f4 >= n4) return;
+    const int l = (int)(i - row * lpr);
+    const float4* xp = reinterpret_cast<const float4*>(x) + row * f4 + l;
+    float4 v[4], pg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = xp[j * lpr];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pg[j] = *reinterpret_cast<const float4*>(g + (l + j * lpr) * 4);
     float mean, rstd;
     merge_stats(stats + row * P * 2, P, cnt, 1e-5f, mean, rstd);
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 pg = *reinterpret_cast<const float4*>(g + c4 * 4);
-    float4 o;
-    o.x = (v.x - mean) * rstd * pg.x; o.y = (v.y - mean) * rstd * pg.y;
-    o.z = (v.z - mean) * rstd * pg.z; o.w = (v.w - mean) * rstd * pg.w;
-    reinterpret_cast<float4*>(y)[i] = o;
+    float4* yp = reinterpret_cast<float4*>(y) + row * f4 + l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 o;
+        o.x = (v[j].x - mean) * rstd * pg[j].x; o.y = (v[j].y - mean) * rstd * pg[j].y;
+        o.z = (v[j].z - mean) * rstd * pg[j].z; o.w = (v[j].w - mean) * rstd * pg[j].w;
+        yp[j * lpr] = o;
+    }
 }
 
 // Merge the per-tile GroupNorm partials of an image: [NI][8][tpi][2] -> [NI][8][2] = (mean, M2) over the whole
