@@ -81,9 +81,9 @@ def test_unet1d_paths_chain_and_ragged(gold_dir, device, opts):
 
 
 @pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}, {"tail_h3": 0}, {"tail_ew": 0},
-                                  {"ws_nosplit": 0}, {"ws_nosplit": 1}, {"ws_m32": 1, "ws_nosplit": 1}, {"ws_store3": 1, "ws_nosplit": 1}, {"stem_pipe": 1}, {"attn_q128": 0}, {"tail_pipe": 0}, {"la_h16": 0}, {"unshuf_h3": 0}, {"stem_dense": 0}, {"final_h3": 0}],
+                                  {"ws_nosplit": 0}, {"ws_nosplit": 1}, {"ws_m32": 1, "ws_nosplit": 1}, {"ws_store3": 1, "ws_nosplit": 1}, {"stem_pipe": 1}, {"attn_q128": 0}, {"tail_pipe": 0}, {"la_h16": 0}, {"unshuf_h3": 0}, {"stem_dense": 0}, {"final_h3": 0}, {"tail_pipe": 3}, {"la_wpi": 4, "la_nsplit": 4}],
                          ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0", "tail_h3_0", "tail_ew_0",
-                              "ws_kgroups", "ws_nosplit_all", "ws_m32", "ws_store3", "stem_pipelined", "attn_q64", "tail_pipe_0", "la_f32_heads", "unshuf_tile", "stem_per_tap", "final_f32"])
+                              "ws_kgroups", "ws_nosplit_all", "ws_m32", "ws_store3", "stem_pipelined", "attn_q64", "tail_pipe_0", "la_f32_heads", "unshuf_tile", "stem_per_tap", "final_f32", "attn_proj_pipe", "la_4_per_image"])
 def test_unet2d_paths_golden(gold_dir, device, opts):
     from test_gpu_parity_2d import build_unet2d
     g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
