@@ -172,6 +172,68 @@ __global__ __launch_bounds__(256) void ss_kernel(const Args a) {
     }
 }
 
+// The MFMA stream alone in another division of the item: wave = (pixel half, K half) with ALL 64 output channels (128 accumulator
+// registers): an A fragment feeds 12 MFMAs instead of 6 -- 4 KB of LDS fragments per 192 clocks and wave instead of per 96 -- the weight
+// fragments per wave and tap stay 8 KB.  (The k-group reduction this needs per finished tile is not in the probe.)
+template <int RING, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void mm64_kernel(const Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ph = w & 1, kg = w >> 1;
+    for (int i = tid; i < 2 * 2 * PLANE / 16; i += 256) reinterpret_cast<uint4*>(&smem[0][0])[i] = make_uint4(0x2c002c00u, 0x2c002c00u, 0x2c002c00u, 0x2c002c00u);
+    __syncthreads();
+    f32x4 accM[4][4], accL[4][4];
+    half8 breg[RING][4][2];                                   // [ring slot][column block][plane]
+    const uint4* wbase = a.W + kg * 64 + lane;
+    auto load_b = [&](int tap, int slot_) __attribute__((always_inline)) {
+        const uint4* wp = wbase + (size_t)tap * 4 * 256;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) breg[slot_][2 * nh + (q >> 1)][q & 1] = __builtin_bit_cast(half8, wp[q * 256 + nh * 128]);
+    };
+    const int foff = (lane & 15) * PITCH + (lane >> 4) * 16 + kg * 64;
+    load_b(0, 0); load_b(1, 1); if (RING == 3) load_b(2, 2);
+    for (int k = 0; k < a.items; ++k) {
+        const unsigned char* P0 = &smem[k & 1][0] + foff;
+        const unsigned char* P1 = P0 + PLANE;
+        half8 fh[3], fl[3];
+        auto read_frag = [&](int s, int slot_) __attribute__((always_inline)) {
+            const int tap = s >> 2, mb = s & 3;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int o = ((4 * ph + mb + dy) * SW + dx) * PITCH;
+            fh[slot_] = *reinterpret_cast<const half8*>(P0 + o);
+            fl[slot_] = *reinterpret_cast<const half8*>(P1 + o);
+        };
+        read_frag(0, 0); read_frag(1, 1);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            const int tap = s >> 2, mb = s & 3, bs = tap % RING, fs = s % 3;
+            if (s + 2 < 36) read_frag(s + 2, (s + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool z = tap == 0;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][nb][0], z ? zero : accM[mb][nb], 0, 0, 0);
+                accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[fs], breg[bs][nb][1], z ? zero : accL[mb][nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[fs], breg[bs][nb][0], accL[mb][nb], 0, 0, 0);
+            if ((s & 3) == 3) load_b((tap + RING) % 9, bs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t += accM[i][j][e] + accL[i][j][e];
+    if (t == 123.456f) a.out[0] = 1.f;
+}
+
 template <int FLAGS>
 static float run(const Args& a, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -205,6 +267,18 @@ int main() {
     printf("  plain staging              : %7.1f us per launch = %.2f us per item   (conv2d_ws_kernel: ~110 us, 6.4 us per item)\n", t0, t0 / items);
     printf("  fma + SiLU while staging   : %7.1f us per launch = %.2f us per item   (conv2d_ws_kernel: ~135 us, 7.4 us per item)\n", t1, t1 / items);
     printf("  MFMA stream alone          : %7.1f us per launch = %.2f us per item\n", t2, t2 / items);
+    auto time64 = [&](auto kern, const char* what) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, a); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+        printf("  MFMA stream alone, wave = 64 pixels x 64 channels x half K, %s: %7.1f us per launch = %.2f us per item\n", what, ms * 1e3f / reps, ms * 1e3f / reps / items);
+    };
+    time64(mm64_kernel<3>, "weights two taps ahead");
+    time64(mm64_kernel<2>, "weights one tap ahead ");
+    time64(mm64_kernel<2, 2>, "one tap ahead, 256 registers");
     printf("  staging / store alone      : %7.1f us per launch = %.2f us per item (plain), %.2f (fma + SiLU)\n", t4, t4 / items, t5 / items);
     return 0;
 }
