@@ -42,6 +42,16 @@ PEAK_HBM_GBPS = 8000.0             # HBM3E, same guide
 PEAK_F16_MFMA_TF = 2500.0          # dense fp16/bf16 MFMA (same guide); the split-fp16 kernels execute 3 fp16 MFMA FLOPs per fp32 FLOP
 BATCH = 256
 TIMESTEPS = 1000
+WEIGHT_BYTES_1D = 20_762_824 * 4   # TemporalUnet1D(dim=64, F=8): 20 762 824 fp32 parameters = 83.05 MB streamed per forward
+# designs per GPU of the workloads that do not use BATCH.  cfg2-b1024 = SURVEY section 7.1a (the throughput asymptote: four residency
+# waves per launch); cfg1-gpu = BASELINE configs[0] on the GPU (batch 4: the weight-streaming regime, the only one where north_star's
+# "% of HBM roofline" binds -- bound = 8 TB/s / 83.05 MB = 96 k steps/s = 385 designs/s)
+WL_BATCH = {"cfg4": 128, "cfg2-b1024": 1024, "cfg1-gpu": 4}
+CFG2_LIKE = ("cfg2", "cfg2-ddim250", "cfg2-b1024", "cfg1-gpu", "cfg2-f32mfma")
+
+
+def default_batch(wl):
+    return WL_BATCH.get(wl, BATCH)
 
 
 def cpu_state_dict(model):
@@ -127,7 +137,7 @@ def rank_device():
 
 
 FLOP_PER_IMAGE_2D = 10.467e9       # per Unet evaluation of one 64x64 image
-PMC_CFG5_FILE = "r05_pmc_traffic_cfg5.json"
+PMC_CFG5_FILE = "r06_pmc_traffic_cfg5.json"
 
 
 def pmc_surrogate_traffic(fname):
@@ -179,7 +189,7 @@ def pmc_traffic(fname, substr):
     return int(b / n) if n else None
 
 
-PMC_PREFIX = "r05_pmc_traffic_"        # profiles/<prefix><workload>.json, written by tools/r5_measure.sh (hash-checked)
+PMC_PREFIX = "r06_pmc_traffic_"        # profiles/<prefix><workload>.json, written by tools/r6_measure.sh (hash-checked)
 
 
 def timed_cpu_steps(step_once, budget_s, reps=3, max_steps=100):
@@ -491,7 +501,7 @@ def measure_2d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None, t_stop=
                 line["config"]["sampled"] = (f"step-bounded sample: {steps} x the first {nsteps} reverse steps of the chain (t = 999 .. {t_stop}); "
                                              f"value and ms_per_step are extrapolated x{TIMESTEPS / nsteps:g} (every reverse step is the same work)")
             if guided:
-                line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r05_kernel_stats_force.txt"
+                line["roofline"]["note"] = "per_kind_us / launches are the diffusion U-Net's; the surrogate's kernel table is profiles/r06_kernel_stats_force.txt"
             if not args.no_cpu_baseline and world == 1:
                 # cpu_baseline + rel_err: the oracle's reverse steps on a few designs, then the same steps, inputs and explicit noise
                 # through the HIP path.  Guided: 1 design (the surrogate's autograd on the CPU is ~4 s per design and step).
@@ -532,6 +542,8 @@ def main_cfg5(args):
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
+        from cindm_amd import dist as cdist
+        cdist.close_comms()                 # the library's own RCCL communicators (if the C entry was opted into) go first
         dist.destroy_process_group()
 
 
@@ -547,14 +559,22 @@ def build_1d(workload, B, dev):
     pair = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64,
                                                     dim_mults=(1, 2, 4, 8), attention=True), seed=0)
     w = {"pair": pair, "single": None, "steps_per_design": TIMESTEPS}
-    if workload in ("cfg2", "cfg2-ddim250"):
+    if workload in CFG2_LIKE:
         S = 250 if workload == "cfg2-ddim250" else TIMESTEPS
         d = cindm_amd.GaussianDiffusion1D(pair, image_size=24, conditioned_steps=0, timesteps=TIMESTEPS, sampling_timesteps=S,
                                           loss_type="l1").to(dev)
+        if workload == "cfg2-f32mfma":
+            # the kernels the range rule falls back to when a checkpoint leaves the split-fp16 window: every product on the
+            # exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
+            pair.set_option("mfma_f32", 1)
         w.update(diffusion=d, out_shape=(24, 8), rows=(B, 0), evals=(1, 0), steps_per_design=S,
                  chain=lambda i, off: d.sample(batch_size=B, cond=None, n_composed=0, compose_n_bodies=2, seed=1234 + i, sample_offset=off),
                  text=(f"nbody-2 TemporalUnet1D dim=64 horizon=24 attention, single model, batch {B}/GPU, {TIMESTEPS} DDPM steps per design "
-                       "(BASELINE configs[1])") if S == TIMESTEPS else
+                       + {"cfg2": "(BASELINE configs[1])",
+                          "cfg2-b1024": "(BASELINE configs[1]'s model at 1024 designs per GPU: SURVEY section 7.1a, the throughput asymptote)",
+                          "cfg1-gpu": "(BASELINE configs[0] on the GPU: the weight-streaming regime, bound 8 TB/s / 83.05 MB per step = 385 designs/s)",
+                          "cfg2-f32mfma": "(BASELINE configs[1] on the exact fp32-MFMA kernels, option mfma_f32 = 1: what the range rule of "
+                                          "DESIGN 4.8 falls back to)"}.get(workload, "")) if S == TIMESTEPS else
                       (f"nbody-2 TemporalUnet1D dim=64 horizon=24 attention, single model, batch {B}/GPU, DDIM with sampling_timesteps=250 "
                        "(the inference scripts' default, inference_1d_composing_multibodies.py:38; eta = 0) of the 1000-step schedule"))
     elif workload == "cfg3":
@@ -674,7 +694,7 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
     dev = rank_device()[0]
     import torch.distributed as dist
     from cindm_amd import dist as cdist
-    B = args.batch or (128 if wl == "cfg4" else BATCH)
+    B = args.batch or default_batch(wl)
     total = B * world
     w = build_1d(wl, B, dev)
     model, diffusion = w["pair"], w["diffusion"]
@@ -725,7 +745,7 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
             k5 = acc["conv5_gemm"]
             tot_ms = sum(v[1] for v in acc.values())
             achieved = k5[2] / (k5[1] * 1e-3) / 1e12          # algorithmic FLOPs of the k=5 conv launches / their time
-            f32_path = os.environ.get("CINDM_MFMA") == "f32"
+            f32_path = os.environ.get("CINDM_MFMA") == "f32" or bool(model.get_option("mfma_f32"))
             kname = "conv_gemm_kernel<5,32,48,*> (fp32 MFMA)" if f32_path else \
                 "dconv2_kernel<L,K0,K1,RES,KB> / dconv_kernel (the deep-level k=5 convolutions of a forward, two per launch where a whole " \
                 "ResidualTemporalBlock fits; fp32 products as 3 fp16 MFMAs, fp32 accumulate)"
@@ -734,8 +754,9 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
             pmc, pmc_note = pmc_step_traffic(pmc_file)
             roof = {"bound": "latency",
                     "bound_note": f"neither roofline binds: the reverse step is a chain of {step_launches} dependent launches; the per-launch phase "
-                                  "clocks (profiles/r04_phase_table_*.txt, the 1-D kernels are unchanged since) split each into dispatch, first loads, weight streaming / MFMA, "
-                                  "reductions, exchanges between workgroups and the store drain",
+                                  "clocks (profiles/r06_phase_table_*.txt) split each into dispatch, first loads, weight streaming / MFMA, "
+                                  "reductions, exchanges between workgroups and the store drain; the ablation builds (profiles/r06_ablation_kloops.txt) "
+                                  "put the K loops on the L2 -> L1 path (113 GB/s per CU with no MFMA at all)",
                     "kernel": kname,
                     # priced against the pipe that EXECUTES: every fp32 product is 3 fp16 MFMAs (f32 path: the fp32 MFMA itself)
                     "achieved": round(achieved if f32_path else 3 * achieved, 2),
@@ -757,11 +778,26 @@ def measure_1d(args, wl, steps, warmup, cpu_budget_s, threads_hint=None):
             roof["pmc_provenance"] = pmc_note
             # traffic / hbm_* come from the committed PMC passes (hash-checked against the loaded library), not from this run
             roof["pmc_measured_in_this_run"] = False
+            if wl == "cfg1-gpu":
+                # batch 4 streams the model's weights once per reverse step and does almost no arithmetic: priced against HBM
+                # (83.05 MB per step, bound = 8 TB/s / 83.05 MB = 96 k steps/s = 385 designs/s)
+                gbps = WEIGHT_BYTES_1D / step_s / 1e9
+                roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                        "traffic": pmc, "algorithmic_bytes_per_step": WEIGHT_BYTES_1D,
+                        "note": "algorithmic bytes = the U-Net's parameters streamed once per reverse step; the deep-level launches of this "
+                                "batch are 16 workgroups (one m-tile) -- the kernels are laid out for one residency wave at 256 rows, not for "
+                                "spreading a 5 MB weight stream over 256 CUs, so this regime sits far below its roofline",
+                        "designs_per_s_at_hbm_peak": round(B * PEAK_HBM_GBPS * 1e9 / WEIGHT_BYTES_1D / S, 1),
+                        "dominant_kernel": roof}
 
         line = None
         if rank == 0:
             recovered = int(model.recovered) + (int(w["single"].recovered) if w["single"] is not None else 0)
             line = bench_line_1d(world, B, steps, warmup, elapsed, w["text"], S, w["evals"], roof, recovered)
+            # the range rule's verdict for these weights: 0 = inside the split-fp16 window, 1 / 2 = the handle repacked for
+            # the exact fp32-MFMA kernels (a weight tensor / an activation left the window)
+            line["range_fallback"] = int(model.get_option("range_fallback"))
+            line["mfma_f32"] = int(model.get_option("mfma_f32"))
             if not args.no_cpu_baseline and world == 1:
                 line["cpu_baseline"], line["rel_err"], extra = cpu_baseline_1d(wl, w, B, dev, budget_s=cpu_budget_s, threads_hint=threads_hint)
                 line.update(extra)
@@ -782,7 +818,7 @@ def compact(line):
            "pmc_provenance": r.get("pmc_provenance"), "pmc_measured_in_this_run": False,
            "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
            "workload": line["config"]["workload"]}
-    for k in ("rel_err_ddim_teacher_forced", "launches_per_reverse_step", "exchange_timeouts_recovered"):
+    for k in ("rel_err_ddim_teacher_forced", "launches_per_reverse_step", "exchange_timeouts_recovered", "range_fallback", "mfma_f32"):
         if k in line:
             out[k] = line[k]
         elif k in r:
@@ -794,7 +830,7 @@ def compact(line):
 
 # what the default run measures after the headline: (workload, timed chains, warm-up chains, CPU-leg budget in seconds, t_stop)
 EXTRA_WORKLOADS = (("cfg3", 2, 1, 4.0, 0), ("cfg4", 3, 1, 4.0, 0), ("cfg2-ddim250", 3, 1, 3.0, 0), ("cfg5", 1, 1, 4.0, 0),
-                   ("cfg5g", 1, 1, 8.0, 980))
+                   ("cfg5g", 1, 1, 8.0, 980), ("cfg2-b1024", 1, 1, 3.0, 0), ("cfg1-gpu", 3, 1, 2.0, 0), ("cfg2-f32mfma", 2, 1, 3.0, 0))
 
 
 def main():
@@ -805,10 +841,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="designs per GPU (default: 256 for cfg2 / cfg3, 128 for cfg4, 64 for cfg5)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg2-ddim250", "cfg5", "cfg5g"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg2-ddim250", "cfg5", "cfg5g", "cfg2-b1024", "cfg1-gpu", "cfg2-f32mfma"), default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] (time composition, 3 windows -> "
                          "56 steps); cfg4 = configs[3] (4-body composition, script path, 128 designs per GPU); cfg2-ddim250 = cfg2 with the "
-                         "scripts' default 250 DDIM steps; cfg5 = configs[4] (2-D airfoil); cfg5g = cfg5 under the ForceUnet design objective")
+                         "scripts' default 250 DDIM steps; cfg5 = configs[4] (2-D airfoil); cfg5g = cfg5 under the ForceUnet design objective; "
+                         "cfg2-b1024 = cfg2 at 1024 designs per GPU; cfg1-gpu = configs[0] (batch 4) on the GPU; cfg2-f32mfma = cfg2 on the "
+                         "exact fp32-MFMA kernels (the range rule's fallback)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="the default run (cfg2, one GPU) also times cfg3, cfg4, cfg2-ddim250, cfg5 and a step-bounded cfg5g after the headline "
@@ -852,6 +890,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
+        from cindm_amd import dist as cdist
+        cdist.close_comms()                 # the library's own RCCL communicators (if the C entry was opted into) go first
         dist.destroy_process_group()
 
 

@@ -10,7 +10,7 @@ import os
 from . import build as _build
 
 _lib = None
-ABI_VERSION = 3          # == CINDM_ABI_VERSION of include/cindm_hip.h (tests/test_host_logic.py keeps the two in step)
+ABI_VERSION = 4          # == CINDM_ABI_VERSION of include/cindm_hip.h (tests/test_host_logic.py keeps the two in step)
 
 
 class CindmError(RuntimeError):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "cindm_unet1d_status": (C.c_int, [_vp, _vp]),
     "cindm_unet1d_poll": (C.c_int, [_vp, _vp]),
     "cindm_unet1d_recovered": (C.c_int, [_vp]),
+    "cindm_unet1d_range_escalate": (C.c_int, [_vp, _i32, _vp]),
     "cindm_unet1d_phase_prof_enable": (C.c_int, [_vp, _i32]),
     "cindm_unet1d_phase_prof_read": (C.c_int, [_vp, _vp, _i64, _vp]),
     "cindm_unet1d_phase_prof_name": (C.c_char_p, [_vp, _i32]),

@@ -12,10 +12,14 @@ DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(("
 # CINDM_LIB_VARIANT=prof selects the PROFILING build of the same sources (-DCINDM_PHASE_PROF: in-kernel phase clocks,
 # csrc/kernels.h PhaseBuf) -> libcindm_hip_prof.so; tools/phase_table.py runs on it.  The production library has no trace of it.
 VARIANT = os.environ.get("CINDM_LIB_VARIANT", "")
-if VARIANT not in ("", "prof"):
-    raise RuntimeError(f"unknown CINDM_LIB_VARIANT {VARIANT!r} (only 'prof')")
-EXTRA_FLAGS = ["-DCINDM_PHASE_PROF"] if VARIANT == "prof" else []
-LIB = os.path.join(HERE, "libcindm_hip_prof.so" if VARIANT == "prof" else "libcindm_hip.so")
+# abl1 / abl2 / abl3: the profiling build with ONE activity of dconv2_kernel's K loops taken out (wrong results by design; round 6's
+# question "what bounds the K loops": 1 = no MFMAs, 2 = every stage re-reads stage 0's weight fragments (L2-hot), 3 = both)
+_VARIANTS = {"": [], "prof": ["-DCINDM_PHASE_PROF"], "abl1": ["-DCINDM_PHASE_PROF", "-DCINDM_ABL=1"],
+             "abl2": ["-DCINDM_PHASE_PROF", "-DCINDM_ABL=2"], "abl3": ["-DCINDM_PHASE_PROF", "-DCINDM_ABL=3"]}
+if VARIANT not in _VARIANTS:
+    raise RuntimeError(f"unknown CINDM_LIB_VARIANT {VARIANT!r} (one of {sorted(_VARIANTS)})")
+EXTRA_FLAGS = _VARIANTS[VARIANT]
+LIB = os.path.join(HERE, f"libcindm_hip_{VARIANT}.so" if VARIANT else "libcindm_hip.so")
 
 
 HASH_FILE = LIB + ".srchash"
@@ -92,7 +96,7 @@ def build(force=False, verbose=False):
     tmp = f"{LIB}.tmp{os.getpid()}"          # per-process name + atomic replace: concurrent builders cannot corrupt the library
     sh = source_hash()
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f'-DCINDM_SRC_HASH="{sh}"'] + EXTRA_FLAGS + \
-          ["-shared", "-fPIC", "-o", tmp, SRC]
+          ["-shared", "-fPIC", "-o", tmp, SRC, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:

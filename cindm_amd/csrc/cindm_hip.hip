@@ -113,6 +113,7 @@ struct cindm_unet1d {
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
     int generation = 0;                    // bumped by every (re)pack: captured graphs that embed this handle's pointers check it
     bool force_f32 = false;                // calibration forward overflowed on the split-fp16 kernels: fp32 MFMA kernels in use
+    int force_reason = 0;                  // what "range_fallback" reads then: 2 = the synthetic calibration batch, 3 = the caller's own batch (cindm_unet1d_range_escalate)
     bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
     // Exchange-free mode (run-time option "no_exchange", or forced for the re-run of a chain whose exchange timed out): the
     // kernels that hand data between WORKGROUPS inside a launch (dconv / dconv2 at C = 512 and the y0 all-gather, attn1d_head)
@@ -224,7 +225,7 @@ static const OptDef kUnet1dOpts[] = {
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
     {"recover", 1, nullptr},                   // run-time: 0 = a chain whose exchange timed out is an error instead of an exchange-free re-run
     {"no_exchange", 0, "CINDM_NO_EXCHANGE"},   // 1: only kernels without an in-launch exchange between workgroups (run-time option: does not un-finalize)
-    {"tune", 0, "CINDM_TUNE"},         // experiment switches for same-box A/B runs (run-time; 0 = the shipped choices)
+    {"tune", 0, "CINDM_TUNE"},         // same-box A/B switches (run-time; 0 = the shipped choices): bit 0 = round 5's L2 warm-up placement and regions, bit 1 = round 5's plain output stores
     {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
@@ -240,6 +241,7 @@ static void unet1d_default_options(cindm_unet1d* h) {
     if (e && std::strcmp(e, "f32") == 0) h->opt["mfma_f32"] = 1;
 }
 
+static void unet1d_plan(cindm_unet1d* h);
 extern "C" int cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value) {
     REQUIRE(h && key, "null argument");
     auto it = h->opt.find(key);
@@ -248,7 +250,10 @@ extern "C" int cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t
         it->second = value;
         // "no_exchange" only selects among kernels whose operands are all packed already: the handle stays finalized
         if (std::strcmp(key, "no_exchange") != 0 && std::strcmp(key, "tune") != 0 && std::strcmp(key, "recover") != 0) h->finalized = false;
-        else h->generation = ++g_generation;         // (captured steps embed the switch: never replay an older capture)
+        else {
+            h->generation = ++g_generation;         // (captured steps embed the switch: never replay an older capture)
+            if (std::strcmp(key, "tune") == 0 && h->finalized) unet1d_plan(h);      // (a tune bit may change what a launch registers for the warm-up)
+        }
     }
     return 0;
 }
@@ -665,7 +670,9 @@ struct Emitter {
                 pf.bytes[k] = nx.bytes[k]; pf.stride[k] = nx.stride[k];
             }
             pf.sink = h->epoch_dev + 2;
+            pf.late = (h->O("tune") & 1) ? 0 : 1;      // round 6: touches a few microseconds before the launch ends (tune bit 0: round 5's, at its head)
         }
+        if (!dry && !pf_out) pf.wt = (h->O("tune") & 2) ? 0 : 1;        // round 6: the launch's outputs are written through (kernels.h st_out; tune bit 1: round 5's plain stores)
         ++pf_idx;
     }
     // weights tiled by 32-column n-tile (conv_gemm_h3_kernel / dconv_kernel packings): tile nt is streamed by the
@@ -958,7 +965,13 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
     {   // L2 warm-up registration: both convolutions' weights, tiled by n-tile
         cindm_unet1d::WReg r{};
         const size_t t0 = w0.sz * 4 / (size_t)NT, t1 = w1.sz * 4 / (size_t)NT;
-        if (NT % 8 == 0) { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
+        if (NT % 8 == 0 && !(h->O("tune") & 1)) {
+            // round 6: conv A's fragments only, n-tiles x AND x + 8 of XCD x (through round 5: tile x of conv A and of conv B -- half of a
+            // 512-channel layer's tiles were never warmed, and conv B's lines were touched a whole launch phase before their use)
+            r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
+            if (NT >= 16) { r.off[1] = w0.off * 4 + 8 * t0; r.bytes[1] = (unsigned)t0; r.stride[1] = (unsigned)t0; }
+        }
+        else if (NT % 8 == 0) { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
                            r.off[1] = w1.off * 4; r.bytes[1] = (unsigned)t1; r.stride[1] = (unsigned)t1;
                          }
         else { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)std::min(w0.sz * 4, (size_t)2 << 20); }
@@ -1646,7 +1659,7 @@ static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
     // that window runs on the exact fp32 MFMA kernels instead ("range_fallback" reads 1); "auto_range" = 0 disables
     // the check.  Activations need no rule: they are GroupNorm / LayerNorm outputs of O(gamma), and an input beyond
     // 65504 shows up as inf / nan in the output rather than as a silent loss.
-    h->opt["range_fallback"] = h->force_f32 ? 2 : 0;
+    h->opt["range_fallback"] = h->force_f32 ? (h->force_reason ? h->force_reason : 2) : 0;
     if (h->use_h3 && h->O("auto_range")) {
         for (const auto& p : h->params) {
             if (p.shape.size() < 2 || p.name.find("time_mlp") != std::string::npos) continue;      // time path: fp32 kernels at finalize
@@ -1749,7 +1762,7 @@ static int unet1d_check_flag(cindm_unet1d* h, hipStream_t stream);
 // repacked for the exact fp32 MFMA kernels ("range_fallback" reads 2; 1 = the weight-window rule fired).
 extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     REQUIRE(h, "null handle");
-    h->force_f32 = false;
+    h->force_f32 = false; h->force_reason = 0;
     if (unet1d_finalize_pack(h, stream_) != 0) return -1;
     if (!h->use_h3 || !h->O("auto_range")) return 0;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1779,10 +1792,28 @@ extern "C" int cindm_unet1d_finalize(cindm_unet1d* h, void* stream_) {
     h->seen_ws = nullptr; h->seen_rows = 0; h->taps.clear();
     if (unet1d_check_flag(h, stream) != 0) return -1;      // a calibration forward whose exchange timed out proves nothing
     if (!finite) {
-        h->force_f32 = true;
+        h->force_f32 = true; h->force_reason = 2;
         if (unet1d_finalize_pack(h, stream_) != 0) return -1;
     }
     return 0;
+}
+
+// The range rule on the CALLER's data (round 6).  The calibration above sees one synthetic unit-scale batch; a real checkpoint's
+// residual stream can still leave fp16's exponent range on real inputs, which shows as inf / nan in the result -- never as a silently
+// wrong finite value.  The Python face checks the result of the FIRST forward / chain after every weight synchronisation and, when it is
+// not finite, calls this with on = 1: the handle is repacked for the exact fp32-MFMA kernels ("range_fallback" reads 3) and the call is
+// repeated; on = 0 undoes exactly that (the repeat was not finite either: the cause was not the range).  Synchronises the stream.
+extern "C" int cindm_unet1d_range_escalate(cindm_unet1d* h, int32_t on, void* stream_) {
+    REQUIRE(h && h->finalized, "model not finalized");
+    if (on) {
+        if (h->force_f32 || !h->use_h3) return 0;
+        h->force_f32 = true; h->force_reason = 3;
+    } else {
+        if (!h->force_f32 || h->force_reason != 3) return 0;
+        h->force_f32 = false; h->force_reason = 0;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream_));
+    return unet1d_finalize_pack(h, stream_);
 }
 
 // (the larger of the two kernel selections: a chain whose exchange timed out is re-run in exchange-free mode on the SAME
@@ -1994,13 +2025,11 @@ struct cindm_ddpm1d {
     float* tab = nullptr;        // 13 tables, each [T]
     int* t_dev = nullptr;        // device step state used by the sample loops: [0] = t, [1] = block counter, [2] = DDIM step index
     hipStream_t own = nullptr;   // capture stream used when the caller passes the legacy default stream
-    float* ddim_buf = nullptr; int ddim_cap = 0;      // DDIM tables: [cap][4] floats then [cap] ints
     // the instantiated graph of the last captured step and everything it embeds (handles + their pack generation,
     // descriptor, tensor / workspace pointers, batch): a loop with the same key replays it without a new capture
     std::vector<unsigned char> gkey; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     int last_step_launches = 0, last_step_fused = 0;     // what the last emitted reverse step consisted of (cindm_ddpm1d_last_step_info)
-    float* xT = nullptr; size_t xT_cap = 0;              // the chain's initial state, kept for the exchange-free re-run after a time-out
-    int last_chain_recovered = 0, last_chain_crowded = 0, last_chain_in_flight = 0;     // cindm_ddpm1d_last_chain_info
+    int last_chain_recovered = 0, last_chain_crowded = 0, last_chain_in_flight = 0, last_chain_range = 0;     // cindm_ddpm1d_last_chain_info
     hipGraph_t graph1 = nullptr; hipGraphExec_t gexec1 = nullptr;      // ping-pong loops: the one-step graph that ends an odd count
     void drop_graph() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -2042,8 +2071,6 @@ extern "C" void cindm_ddpm1d_destroy(cindm_ddpm1d* h) {
     if (h->t_dev) (void)hipFree(h->t_dev);
     h->drop_graph();
     if (h->own) (void)hipStreamDestroy(h->own);
-    if (h->ddim_buf) (void)hipFree(h->ddim_buf);
-    if (h->xT) (void)hipFree(h->xT);
     delete h;
 }
 
@@ -2051,6 +2078,7 @@ struct StepLayout {
     int64_t pair_rows = 0, single_rows = 0;
     int pair_F = 0, Tw = 0, Lfull = 0;
     size_t off_pair_in = 0, off_pair_eps = 0, off_single_in = 0, off_single_eps = 0, off_ws_pair = 0, off_ws_single = 0, off_tmp = 0, total = 0;
+    size_t off_xT = 0, off_ddim = 0;      // the chain's x_T snapshot (recovery) and the DDIM loop's per-step tables: caller-owned too
     bool direct = false;     // plain mode, no cond: U-Net reads x directly
 };
 
@@ -2090,6 +2118,10 @@ static int step_layout(const cindm_unet1d* pair, const cindm_unet1d* uncond, con
     s.off_ws_pair = o; o += al(cindm_unet1d_workspace_bytes(pair, s.pair_rows));
     s.off_ws_single = o; if (s.single_rows) o += al(cindm_unet1d_workspace_bytes(uncond, s.single_rows));
     s.off_tmp = o; o += al((size_t)B * Ltot * c->n_bodies * 4 * 4);       // guided steps: x_out staging (the gradient reads neighbours of x)
+    // the sample loops keep the chain's initial state for the exchange-free re-run and the DDIM loop its per-step tables
+    // ([T][4] floats + [T] ints): both live in the caller's workspace -- no allocation after *_create
+    s.off_xT = o; o += al((size_t)B * Ltot * c->n_bodies * 4 * 4);
+    s.off_ddim = o; o += al((size_t)pair->d.timesteps * 5 * 4);
     s.total = o + 256;
     return 0;
 }
@@ -2379,6 +2411,18 @@ static int replay_steps(cindm_ddpm1d* h, const std::vector<unsigned char>& key, 
 // per device IN THIS PROCESS: a chain that starts while another is running takes the exchange-free plan up front -- correct, about
 // 10 % slower, no time-out, no re-run -- and the Python face warns once.  (Other processes on the device cannot be seen from here;
 // against them the bounded spin + recovery below remains.)  Concurrent chains need their own U-Net handles.
+// the chain-level slices of a step workspace: the x_T snapshot of the recovery and the DDIM loop's per-step tables (step_layout)
+static int chain_slices(const cindm_unet1d* pair, const cindm_unet1d* uncond, const cindm_compose_desc* c, int64_t B, void* ws,
+                        size_t ws_bytes, float** xT, float** ddim) {
+    REQUIRE(pair && c && ws, "null argument");
+    StepLayout s;
+    if (step_layout(pair, uncond, c, B, state_len(pair, c), s) != 0) return -1;
+    REQUIRE(ws_bytes >= s.total, "workspace too small (cindm_ddpm1d_workspace_bytes)");
+    *xT = reinterpret_cast<float*>((char*)ws + s.off_xT);
+    if (ddim) *ddim = reinterpret_cast<float*>((char*)ws + s.off_ddim);
+    return 0;
+}
+
 static std::atomic<int> g_chains_in_flight[64];
 struct ChainInFlight {
     std::atomic<int>* c = nullptr; int prev = 0;
@@ -2387,10 +2431,11 @@ struct ChainInFlight {
 };
 
 template <typename Body>
-static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, float* x, size_t n_floats,
+static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, float* x, float* xT, size_t n_floats,
                                    hipStream_t stream, Body body) {
     ChainInFlight inflight;
     h->last_chain_recovered = 0; h->last_chain_crowded = 0; h->last_chain_in_flight = inflight.prev + 1;
+    h->last_chain_range = std::max(pair->O("range_fallback"), uncond ? uncond->O("range_fallback") : 0);
     // (already exchange-free: nothing can time out, nothing to keep -- BOTH models of a multibody step count)
     const bool guard = !pair->NX() || (uncond && !uncond->NX());
     if (guard && inflight.prev > 0) {
@@ -2404,21 +2449,14 @@ static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
         if (rc == 1) return fail("an in-kernel exchange timed out in exchange-free mode (internal error)");
         return rc;
     }
-    if (guard) {
-        if (h->xT_cap < n_floats) {
-            if (h->xT) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(h->xT); h->xT = nullptr; h->xT_cap = 0; }
-            HIPCHK(hipMalloc((void**)&h->xT, n_floats * sizeof(float)));
-            h->xT_cap = n_floats;
-        }
-        HIPCHK(hipMemcpyAsync(h->xT, x, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    }
+    if (guard) HIPCHK(hipMemcpyAsync(xT, x, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));      // (xT: a slice of the caller's workspace)
     int rc = body();
     if (rc != 1) return rc;
     if (!guard) return fail("an in-kernel exchange timed out in exchange-free mode (internal error)");
     if (!pair->O("recover") || (uncond && !uncond->O("recover")))
         return fail("an in-kernel exchange between workgroups timed out (foreign load on the device kept a partner workgroup from becoming "
                     "resident); option recover = 0: the chain is not re-run");
-    HIPCHK(hipMemcpyAsync(x, h->xT, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync(x, xT, n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
     pair->no_xchg_force = 1; ++pair->recovered;
     if (uncond) { uncond->no_xchg_force = 1; ++uncond->recovered; }
     h->last_chain_recovered = 1;
@@ -2433,10 +2471,11 @@ static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
 
 // what the last chain of this handle did: info[0] = 1 when it was re-run on the exchange-free plan after a time-out, info[1] = 1 when
 // it ran on the exchange-free plan from the start because another chain was in flight on the device, info[2] = chains in flight on
-// the device when it started (itself included), info[3] = reserved
+// the device when it started (itself included), info[3] = the models' "range_fallback" when it ran (0 = the split-fp16 kernels; 1 / 2 / 3 =
+// the exact fp32-MFMA kernels because a weight / the calibration batch / the caller's own batch left the split-fp16 window)
 extern "C" int cindm_ddpm1d_last_chain_info(const cindm_ddpm1d* h, int32_t info[4]) {
     REQUIRE(h && info, "null argument");
-    info[0] = h->last_chain_recovered; info[1] = h->last_chain_crowded; info[2] = h->last_chain_in_flight; info[3] = 0;
+    info[0] = h->last_chain_recovered; info[1] = h->last_chain_crowded; info[2] = h->last_chain_in_flight; info[3] = h->last_chain_range;
     return 0;
 }
 
@@ -2475,7 +2514,9 @@ extern "C" int cindm_ddpm1d_sample(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_un
     const bool pp = pair->O("pingpong") != 0;
     io.pingpong = pp ? 1 : 0;
     cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
-    return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
+    float* xT = nullptr;
+    if (chain_slices(pair, uncond, c, B, ws, ws_bytes, &xT, nullptr) != 0) return -1;
+    return run_chain_with_recovery(h, pair, un, x, xT, (size_t)B * Ltot * F, stream, [&]() -> int {
         if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
         start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
         KeyBuilder K;
@@ -2501,19 +2542,18 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
         HIPCHK(hipDeviceSynchronize());
         stream = h->own;
     }
-    if (h->ddim_cap < n_steps) {
-        if (h->ddim_buf) { HIPCHK(hipStreamSynchronize(stream)); (void)hipFree(h->ddim_buf); h->ddim_buf = nullptr; }
-        HIPCHK(hipMalloc((void**)&h->ddim_buf, (size_t)n_steps * 5 * sizeof(float)));
-        h->ddim_cap = n_steps;
-    }
+    // the per-step tables ([n_steps][4] floats, then [n_steps] ints) and the x_T snapshot live in the caller's workspace
+    REQUIRE(n_steps <= pair->d.timesteps, "more DDIM steps than the U-Net's timesteps");
+    float* xT = nullptr; float* ddim_buf = nullptr;
+    if (chain_slices(pair, uncond, c, B, ws, ws_bytes, &xT, &ddim_buf) != 0) return -1;
     std::vector<float> tabv((size_t)n_steps * 4, 0.f);
     std::vector<int> tnv(n_steps);
     for (int i = 0; i < n_steps; ++i) {
         tabv[4 * i] = coefs[3 * i]; tabv[4 * i + 1] = coefs[3 * i + 1]; tabv[4 * i + 2] = coefs[3 * i + 2];
         tnv[i] = times[i + 1];
     }
-    int* tn_dev = reinterpret_cast<int*>(h->ddim_buf + (size_t)h->ddim_cap * 4);
-    HIPCHK(hipMemcpyAsync(h->ddim_buf, tabv.data(), tabv.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    int* tn_dev = reinterpret_cast<int*>(ddim_buf + (size_t)n_steps * 4);
+    HIPCHK(hipMemcpyAsync(ddim_buf, tabv.data(), tabv.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(tn_dev, tnv.data(), tnv.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));            // the host vectors go out of scope
     const int Ltot = state_len(pair, c);
@@ -2523,14 +2563,14 @@ extern "C" int cindm_ddpm1d_sample_ddim(cindm_ddpm1d* h, cindm_unet1d* pair, cin
     io.noise = noise_steps; io.noise_t_stride = (int64_t)B * Ltot * F; io.seed = seed; io.sample_off = sample_offset; io.add_noise = 1;
     io.inp_cond = inpaint_cond; io.inp_steps = inpaint_steps; io.inp_noise = inpaint_noise_steps;
     io.inp_noise_t_stride = (int64_t)B * inpaint_steps * F;
-    io.dec_t = 1; io.ddim_tab = h->ddim_buf; io.ddim_tnext = tn_dev;
+    io.dec_t = 1; io.ddim_tab = ddim_buf; io.ddim_tnext = tn_dev;
     io.dyn = reinterpret_cast<const unsigned long long*>(h->t_dev + 16);
     // (round 4) as in the DDPM loop the step state -- t, the step index, the epochs -- lives in two slots advanced by the step's own
     // update: no step_counter_kernel launch, and a plain single-model step runs its update inside the last U-Net kernel
     const bool pp = pair->O("pingpong") != 0;
     io.pingpong = pp ? 1 : 0;
     cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
-    return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
+    return run_chain_with_recovery(h, pair, un, x, xT, (size_t)B * Ltot * F, stream, [&]() -> int {
         if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
         start_loop(h, pair, uncond, c, (int)times[0], stream, seed, sample_offset);
         KeyBuilder K;
@@ -2587,7 +2627,9 @@ extern "C" int cindm_ddpm1d_sample_guided(cindm_ddpm1d* h, cindm_unet1d* pair, c
         return 0;
     };
     cindm_unet1d* un = c->mode == CINDM_COMPOSE_MULTIBODY ? uncond : nullptr;
-    return run_chain_with_recovery(h, pair, un, x, (size_t)B * Ltot * F, stream, [&]() -> int {
+    float* xT = nullptr;
+    if (chain_slices(pair, uncond, c, B, ws, ws_bytes, &xT, nullptr) != 0) return -1;
+    return run_chain_with_recovery(h, pair, un, x, xT, (size_t)B * Ltot * F, stream, [&]() -> int {
         if (prepare_step_ws(pair, uncond, c, B, ws, ws_bytes, stream) != 0) return -1;
         start_loop(h, pair, uncond, c, (int)t_start, stream, seed, sample_offset);
         KeyBuilder K;
@@ -2613,7 +2655,23 @@ extern "C" int cindm_fill_normal(float* out, int64_t B, int64_t per_sample, uint
 
 // ---- multi-GPU: the one all-gather of the path, on RCCL (include/cindm_hip.h) -----------------------------------------------
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm installation without RCCL's headers still builds the library: the five entry points bound below (resolved with dlopen /
+// dlsym at first use -- no link dependency either way), declared as RCCL's public header declares them (NCCL 2 ABI).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 namespace {
 struct RcclApi {
     void* lib = nullptr;

@@ -136,7 +136,7 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 // each, so tiles x + 8 are never warmed --: same-box A/B 329.9 us per reverse step with two regions, 332.4 with four.  The extra
 // touches cost more than cold tiles x + 8 do; two it stays.)
 constexpr int PF_REGIONS = 2;
-struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; };
+struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt; };      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
 struct PfRegs { unsigned v[PF_REGIONS][2]; };
 // (Every caller is a 256-thread kernel.  Round 4: the block size is a CONSTANT here.  `blockDim.x` is a 16-bit VECTOR-memory load
 // from the dispatch packet: its use made hipcc wait `vmcnt(0)` in the middle of this function -- vector loads return in order, so
@@ -161,11 +161,42 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
         }
     }
 }
+// A/B of the touches' placement (round 6): at the head of the launch (rounds 2 - 5), or a few microseconds before its end -- a line
+// touched 10 - 25 us early has to survive the launch's own stream through a 4 MB L2
+__device__ __forceinline__ void l2_prefetch_early(const Pf& p, PfRegs& r) {
+#pragma unroll
+    for (int k = 0; k < PF_REGIONS; ++k) r.v[k][0] = r.v[k][1] = 0u;
+    if (!p.late) l2_prefetch(p, r);
+}
+__device__ __forceinline__ void l2_prefetch_late(const Pf& p, PfRegs& r) { if (p.late) l2_prefetch(p, r); }
 __device__ __forceinline__ void l2_prefetch_done(const Pf& p, const PfRegs& r) {
     unsigned x = 0u;
 #pragma unroll
     for (int k = 0; k < PF_REGIONS; ++k) x ^= r.v[k][0] ^ r.v[k][1];
     if (p.sink && x == 0x9e3779b9u) p.sink[0] = 1;    // keeps the loads alive
+}
+
+// A launch's OUTPUT stores, written through the L2 (sc1) when `wt` (round 6).  With plain stores a launch leaves its outputs dirty in
+// the XCD's L2 and the end-of-kernel release writes them back before the dependent launch may start -- part of every gap of the
+// replayed step ("boundary ... + B / 6 TB/s when the predecessor leaves B bytes dirty", MI355X_MICROARCH.md) -- and the consumers, on
+// other XCDs, read them from memory anyway.  `base` must be wave-uniform (a kernel argument plus a block-uniform offset): it becomes a
+// buffer resource; `off` is the lane's element offset.
+__device__ __forceinline__ void st_out(float* base, size_t off, float v, int wt) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, 0x7ffffff0u, 0x00020000),
+                                                  (unsigned)(off * 4), 0, 16);      // aux 16 = sc1
+    else base[off] = v;
+}
+__device__ __forceinline__ void st_out4(float* base, size_t off, const float4& v, int wt) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, 0x7ffffff0u, 0x00020000),
+                                                   (unsigned)(off * 4), 0, 16);
+    else *reinterpret_cast<float4*>(base + off) = v;
+}
+__device__ __forceinline__ void st_out4(uint4* base, size_t off, const uint4& v, int wt) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, 0x7ffffff0u, 0x00020000),
+                                                   (unsigned)(off * 16), 0, 16);
+    else base[off] = v;
 }
 
 constexpr int TM = 48;        // tile rows
@@ -1352,7 +1383,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
             for (int pl = 0; pl < 2; ++pl)
                 wr[p][s][pl] = (p < K32) ? Wq4[(((size_t)tile[s] * K32 + p) * 2 + pl) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
 
     // ---- LayerNorm (as in attn1d_site_kernel), result split into the two fp16 planes ----
     {
@@ -1493,6 +1524,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
         }
     __syncthreads();
     PH(2);
+    l2_prefetch_late(a.pf, pfr);
 
     // ---- out = Wo att + bo + x ----
     // the epilogue's bias and residual rows of tile t + 1 are requested before tile t's MFMAs (round 4: loaded where they were
@@ -1550,7 +1582,7 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
                 const float4 xv = ex[t & 1][nt];
                 float4 o;
                 o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
-                *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
+                st_out4(a.out, row * a.ldo + c, o, a.pf.wt);
             }
         }
     }
@@ -1668,12 +1700,12 @@ __device__ __forceinline__ void lvl_to_planes(const f32x4 (&v)[NT], unsigned cha
 }
 
 template <int NT>
-__device__ __forceinline__ void lvl_store(const f32x4 (&v)[NT], float* dst, int c0, int n_valid, int lane) {      // dst: [positions, 64] of this sample
+__device__ __forceinline__ void lvl_store(const f32x4 (&v)[NT], float* dst, int c0, int n_valid, int lane, int wt = 0) {      // dst: [positions, 64] of this sample
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + lr;
-        if (n < n_valid) *reinterpret_cast<float4*>(dst + (size_t)n * 64 + c0 + lq * 4) = make_float4(v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
+        if (n < n_valid) st_out4(dst, (size_t)n * 64 + c0 + lq * 4, make_float4(v[nt][0], v[nt][1], v[nt][2], v[nt][3]), wt);
     }
 }
 
@@ -1693,7 +1725,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     const int t_now = step_scalar(a.t_ptr, a.t_imm);
     const int c0 = w * 16;                                               // this wave's channels
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
     const int cl = c0 + lq * 4;                                          // this lane's four channels
     // ---- every request of the kernel's head in ONE round trip (round 4): the input row, the parameter vectors and the first
     // layer's weight fragments are requested before anything waits (the row was converted and written to LDS right after its
@@ -1767,7 +1799,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     f32x4 h1[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) h1[nt] = v[nt] + r1[nt];
-    if (a.h1) lvl_store<NT>(h1, a.h1 + (size_t)b * L * C, c0, L, lane);
+    if (a.h1) lvl_store<NT>(h1, a.h1 + (size_t)b * L * C, c0, L, lane, a.pf.wt);
     lvl_to_planes<NT, PPB>(h1, P[1][0], P[1][1], c0, 2, L, lane);
     __syncthreads();
     PH(3);
@@ -1798,12 +1830,13 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     f32x4 h2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) h2[nt] = v[nt] + h1[nt];
-    if (a.h2) lvl_store<NT>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
+    if (a.h2) lvl_store<NT>(h2, a.h2 + (size_t)b * L * C, c0, L, lane, a.pf.wt);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
         *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl]) = make_float4(h2[nt][0], h2[nt][1], h2[nt][2], h2[nt][3]);
     __syncthreads();
     PH(5);
+    l2_prefetch_late(a.pf, pfr);
     // ---- attention: y = LN(h2) g -> planes P[1] (rows position + 2) ; q, k, v ; core ; out projection + h2 ----
     {
         constexpr int RPP = 16;                                          // 16 lanes per row, 16 rows per pass
@@ -1898,7 +1931,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
             h3[nt] += h2[nt];
         }
     }
-    lvl_store<NT>(h3, a.skip + (size_t)b * L * C, c0, L, lane);
+    lvl_store<NT>(h3, a.skip + (size_t)b * L * C, c0, L, lane, a.pf.wt);
     lvl_to_planes<NT, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
     PH(8);
@@ -1908,7 +1941,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
         lvl_conv<1, 3, 2, PPB>(wd6, P[0][0], P[0][1], 2, 1, ROWS - 1, lane, d);
         const float4 bd = pbd;
         d[0][0] += bd.x; d[0][1] += bd.y; d[0][2] += bd.z; d[0][3] += bd.w;
-        lvl_store<1>(d, a.down + (size_t)b * (L / 2) * C, c0, L / 2, lane);
+        lvl_store<1>(d, a.down + (size_t)b * (L / 2) * C, c0, L / 2, lane, a.pf.wt);
     }
     PH(9);
     l2_prefetch_done(a.pf, pfr);
@@ -2052,7 +2085,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     lvlm_prefetch<2, 5, 2, 4>(ring, wbase(a.Wc[0], 5, 2), lane);
     lvlm_prefetch<2, 1, 2, 2>(ring_r, wbase(a.Wr, 1, 2), lane);
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
     // (round 4) the input rows are requested BEFORE the parameter vectors go to LDS: `PV[i][tid] = src[i][tid]` waits for its loads,
     // and rows requested after that wait were a second serial round trip at the head of the launch
     float4 xin[NT];
@@ -2121,8 +2154,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 if (nt < s_here && lr < Lo_)
-                    *reinterpret_cast<float4*>(dst + ((size_t)(s0 + nt) * Lo_ + lr) * C + cl(mt)) =
-                        make_float4(v[mt][nt][0], v[mt][nt][1], v[mt][nt][2], v[mt][nt][3]);
+                    st_out4(dst, ((size_t)(s0 + nt) * Lo_ + lr) * C + cl(mt), make_float4(v[mt][nt][0], v[mt][nt][1], v[mt][nt][2], v[mt][nt][3]), a.pf.wt);
     };
     auto gn_all = [&](f32x4 (&v)[2][NT], int ci) {
 #pragma unroll
@@ -2190,6 +2222,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
             *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl(mt)]) = make_float4(h2[mt][nt][0], h2[mt][nt][1], h2[mt][nt][2], h2[mt][nt][3]);
     __syncthreads();
     PH(6);
+    l2_prefetch_late(a.pf, pfr);
     if (a.dbg == 3) return;
     // ---- attention: LayerNorm -> planes P[1] ----
     {
@@ -2477,7 +2510,7 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     lvlm_prefetch<1, 5, 8, 8>(ring8, wtile(a.Wc[0], 2 * w, 5, 8), lane);
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr0, 2 * w, 1, 8), lane);
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
     // (round 4) the input rows are requested BEFORE the parameter vectors go to LDS: `PV[i][tid] = src[i][tid]` waits for its loads,
     // and rows requested after that wait were a second serial round trip at the head of the launch
     float4 xin[4];                                                       // cat(x, skip) rows, requested before the zero fill and its barrier
@@ -2612,7 +2645,7 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     for (int mt = 0; mt < 2; ++mt) {
         lvlm_gn_mish(vb[mt][0], pvb4(3, mt), pvb4(4, mt), pvb4(5, mt), L, lane);
         h1b[mt][0] = vb[mt][0] + rb[mt][0];
-        if (a.h1 && lr < L) *reinterpret_cast<float4*>(a.h1 + ((size_t)b * L + lr) * CB + clb(mt)) = make_float4(h1b[mt][0][0], h1b[mt][0][1], h1b[mt][0][2], h1b[mt][0][3]);
+        if (a.h1 && lr < L) st_out4(a.h1, ((size_t)b * L + lr) * CB + clb(mt), make_float4(h1b[mt][0][0], h1b[mt][0][1], h1b[mt][0][2], h1b[mt][0][3]), a.pf.wt);
     }
     q_planes(h1b, Q[1][0], Q[1][1]);
     __syncthreads();
@@ -2638,7 +2671,7 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     lvlm_prefetch<1, 1, 4, 8>(ring, wbase(a.Wo, 1, 4), lane);           // to_out fragments: in flight through the attention
     lvl_gn_mish<1>(v1[0], pv4(3), pv4(4), pv4(5), L, lane);
     h2[0] = v1[0][0] + r1[0][0];
-    if (a.h2) lvl_store<1>(h2, a.h2 + (size_t)b * L * C, c0, L, lane);
+    if (a.h2) lvl_store<1>(h2, a.h2 + (size_t)b * L * C, c0, L, lane, a.pf.wt);
     *reinterpret_cast<float4*>(&H[lr * HP + cl]) = make_float4(h2[0][0], h2[0][1], h2[0][2], h2[0][3]);
     __syncthreads();
     PH(6);
@@ -2717,13 +2750,14 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     }
     __syncthreads();
     PH(8);
+    l2_prefetch_late(a.pf, pfr);
     f32x4 h3[1];
     lvlm_conv<1, 1, 1, 4, APB, 8>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 0, 1, 0, NP1 - 1, lane, v1);
     lvlm_prefetch<1, 4, 2, 8>(ring, wbase(a.Wu, 4, 2), lane);
     h3[0] = v1[0][0];
     add4(h3[0], pv4(11));
     h3[0] += h2[0];
-    if (a.h3) lvl_store<1>(h3, a.h3 + (size_t)b * L * C, c0, L, lane);
+    if (a.h3) lvl_store<1>(h3, a.h3 + (size_t)b * L * C, c0, L, lane, a.pf.wt);
     lvl_to_planes<1, PPB>(h3, P[0][0], P[0][1], c0, 2, L, lane);
     __syncthreads();
     PH(9);
@@ -2732,7 +2766,7 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     lvlm_conv<1, 2, 4, 2, PPB, 8, 1>(ring, wbase(a.Wu, 4, 2), P[0][0], P[0][1], 0, 0, 0, ROWS2 - 1, lane, u);
     lvlm_prefetch<1, 5, 2, 8>(ring, wbase(a.Wc[4], 5, 2), lane);
     add4(u[0][0], pv4(12)); add4(u[0][1], pv4(12));
-    if (a.up) lvl_store<2>(u[0], a.up + (size_t)b * L2 * C, c0, L2, lane);
+    if (a.up) lvl_store<2>(u[0], a.up + (size_t)b * L2 * C, c0, L2, lane, a.pf.wt);
     lvl_to_planes<2, PPB>(u[0], P[1][0], P[1][1], c0, 2, L2, lane);
     __syncthreads();
     PH(10);
@@ -2749,7 +2783,7 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
     lvlm_conv<1, 2, 5, 2, PPB, 8>(ring, wbase(a.Wc[4], 5, 2), P[1][0], P[1][1], 16, 1, 0, ROWS2 - 1, lane, y);
     if (w == 0) lvlm_prefetch<1, 1, 2, 8>(ring, reinterpret_cast<const float4*>(a.Wf), lane);
     add4(y[0][0], pv4(6)); add4(y[0][1], pv4(6));
-    if (a.ypre) lvl_store<2>(y[0], a.ypre + (size_t)b * L2 * C, c0, L2, lane);
+    if (a.ypre) lvl_store<2>(y[0], a.ypre + (size_t)b * L2 * C, c0, L2, lane, a.pf.wt);
     lvl_gn_mish<2>(y[0], zero4, pv4(7), pv4(8), L2, lane);
     lvl_to_planes<2, PPB>(y[0], P[0][0], P[0][1], c0, 2, L2, lane);
     __syncthreads();
@@ -2769,11 +2803,11 @@ __global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a
             if (n < L2 && lq * 4 < a.F) {
                 const size_t i0 = ((size_t)b * L2 + n) * a.F + lq * 4;
                 const float4 o = make_float4(e[0][nt][0] + bf.x, e[0][nt][1] + bf.y, e[0][nt][2] + bf.z, e[0][nt][3] + bf.w);
-                *reinterpret_cast<float4*>(a.eps + i0) = o;
+                st_out4(a.eps, i0, o, a.pf.wt);
                 if (a.fuse_upd)
-                    *reinterpret_cast<float4*>(u.x_out + i0) =
-                        make_float4(plain_step_value(u, sc, tu, xq[nt].x, o.x, zq[nt].x), plain_step_value(u, sc, tu, xq[nt].y, o.y, zq[nt].y),
-                                    plain_step_value(u, sc, tu, xq[nt].z, o.z, zq[nt].z), plain_step_value(u, sc, tu, xq[nt].w, o.w, zq[nt].w));
+                    st_out4(u.x_out, i0,
+                            make_float4(plain_step_value(u, sc, tu, xq[nt].x, o.x, zq[nt].x), plain_step_value(u, sc, tu, xq[nt].y, o.y, zq[nt].y),
+                                        plain_step_value(u, sc, tu, xq[nt].z, o.z, zq[nt].z), plain_step_value(u, sc, tu, xq[nt].w, o.w, zq[nt].w)), a.pf.wt);
             }
         }
         if (a.fuse_upd && blockIdx.x == 0 && lane == 0) compose_advance(u, tu);
@@ -2827,7 +2861,7 @@ __global__ __launch_bounds__(256, MINB) void ups_tail128_kernel(const UpsTailArg
     lvlm_prefetch<1, 5, 8, 8>(ring8, wtile(a.Wc[0], 2 * w, 5, 8), lane);
     lvlm_prefetch<1, 1, 8, 8>(ring_r, wtile(a.Wr, 2 * w, 1, 8), lane);
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
     // (round 4) the input rows are requested BEFORE the parameter vectors go to LDS: `PV[i][tid] = src[i][tid]` waits for its loads,
     // and rows requested after that wait were a second serial round trip at the head of the launch
     float4 xin[4];                                                       // the input rows, requested before the zero fill and its barrier
@@ -2885,7 +2919,7 @@ __global__ __launch_bounds__(256, MINB) void ups_tail128_kernel(const UpsTailArg
     auto store = [&](const f32x4 (&v)[2], float* dst, int nvalid) {      // dst [Bp, nvalid, 128]
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-            if (lr < nvalid) *reinterpret_cast<float4*>(dst + ((size_t)b * nvalid + lr) * C + cl(mt)) = make_float4(v[mt][0], v[mt][1], v[mt][2], v[mt][3]);
+            if (lr < nvalid) st_out4(dst, ((size_t)b * nvalid + lr) * C + cl(mt), make_float4(v[mt][0], v[mt][1], v[mt][2], v[mt][3]), a.pf.wt);
     };
     __syncthreads();
     PH(2);
@@ -2952,6 +2986,7 @@ __global__ __launch_bounds__(256, MINB) void ups_tail128_kernel(const UpsTailArg
     }
     __syncthreads();
     PH(5);
+    l2_prefetch_late(a.pf, pfr);
     f32x4 qa[2][1], ka[1][2], va[1][2];
     {
         const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);

@@ -566,16 +566,28 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
 #pragma unroll
     for (int j = 0; j < KPW0; ++j) load_raw(g0, j, raw0[j]);
 
-    half8 breg[T][2][2];
+    // The weight ring: one 128-channel stage (5 taps x 4 fragments = 80 registers), refilled tap by tap one stage ahead.
+    // (Round 6 built a ring of up to three stages for phase B -- requested inside phase A's epilogue, one wave publishing so that the
+    // other three need no drain: 438 - 453 registers, loads straight into AGPRs, no scratch -- and it did NOT pay: phase B's K loop
+    // went 3.9 -> 3.4 us, the issue of 60 requests per lane cost 1.5 us in front of it, the step was 0.6 us slower.  With the weights
+    // already in registers the K loop still waits for y0: the all-gather through memory runs at ~33 GB/s per CU whatever is in flight
+    // (DESIGN.md section 5).  Removed; the slot index stays a template constant of the helpers.)
+    constexpr int BD = 1;
+    half8 wr[BD][T][2][2];
     const uint4* wbase = a.Wa + (size_t)nt * a.ncha * (T * 4) * 256 + tid;
     const uint4* wbase_b = a.Wb + (size_t)nt * KPWB * (T * 4) * 256 + tid;
-    auto load_b_tap = [&](const uint4* wb, int ch, int tap) {
+    auto load_b_tap = [&](const uint4* wb, int ch, int tap, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+#if defined(CINDM_ABL) && (CINDM_ABL & 2)
+        ch = 0;                                   // ablation build: every stage re-reads the first stage's fragments (L2-hot)
+#endif
         const uint4* wp = wb + ((size_t)ch * (T * 4) + tap * 4) * 256;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) breg[tap][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+        for (int q = 0; q < 4; ++q) wr[SL][tap][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
     };
+    constexpr std::integral_constant<int, 0> SLOT0{};
 #pragma unroll
-    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase, 0, tap);
+    for (int tap = 0; tap < T; ++tap) load_b_tap(wbase, 0, tap, SLOT0);
     half8 rreg[2][2];
     const uint4* rbase = a.W2 + (size_t)nt * a.ncha * 4 * 256 + tid;
     auto load_r = [&](int ch) {
@@ -636,9 +648,10 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         for (int j = 0; j < 2; ++j) { accRM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accRL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // one k-step against all five taps (dconv_kernel's); WB: the weight stream this phase reads; RIDE: the 1x1 on the centre tap
-    auto kstep = [&](const uint4* wb, int j, int chn, auto pf, auto ride) {
+    auto kstep = [&](const uint4* wb, int j, int chn, auto pf, auto ride, auto slot_c) {
         constexpr bool PF = decltype(pf)::value;
         constexpr bool RIDE = decltype(ride)::value;
+        constexpr int SL = decltype(slot_c)::value;      // the ring slot this k-step multiplies (and refills with stage chn)
         const int base = ((4 * j + w) * 4 + (lane >> 4)) * RPAD + (lane & 15);
         half8 fh[NWIN], fl[NWIN];
 #pragma unroll
@@ -652,14 +665,31 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             for (int mb = 0; mb < 3; ++mb) {
                 const int p = mb * PB + tap - 2 + H;
                 if (p < 0 || p >= NWIN) continue;
+#if defined(CINDM_ABL) && (CINDM_ABL & 1)
+                // ablation build: no MFMAs; one VALU op per operand register keeps the fragment reads and the weight loads alive
+                // (empty asm statements with the operands as inputs: the values must be IN their registers here -- the waits stay,
+                // no instruction is issued)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const uint4 u = __builtin_bit_cast(uint4, wr[SL][tap][nb][pl]);
+                        asm volatile("" :: "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
+                    }
+                {
+                    const uint4 u = __builtin_bit_cast(uint4, fh[p]), u2 = __builtin_bit_cast(uint4, fl[p]);
+                    asm volatile("" :: "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(u2.x), "v"(u2.y), "v"(u2.z), "v"(u2.w));
+                }
+#else
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][0], accM[mb][nb], 0, 0, 0);
-                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][1], accL[mb][nb], 0, 0, 0);
+                    accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], wr[SL][tap][nb][0], accM[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], wr[SL][tap][nb][1], accL[mb][nb], 0, 0, 0);
                 }
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], breg[tap][nb][0], accL[mb][nb], 0, 0, 0);
+                    accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], wr[SL][tap][nb][0], accL[mb][nb], 0, 0, 0);
+#endif
             }
             if constexpr (RIDE) if (tap == 2) {
 #pragma unroll
@@ -679,7 +709,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             if constexpr (PF) {
                 // the next stage's fragments of this tap: requested HERE, behind the tap's last use (pinned: left to itself the
                 // scheduler gathers the requests at the end of the k-step, where the next k-step's first taps find them late)
-                load_b_tap(wb, chn, tap);
+                load_b_tap(wb, chn, tap, slot_c);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -690,27 +720,29 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     // ---- phase A K loop; its last k-step requests phase B's first stage of weights instead of nothing ------------------
     if constexpr (KPW1 == 0) {
 #pragma unroll
-        for (int j = 0; j < KPW0 - 1; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A); }
+        for (int j = 0; j < KPW0 - 1; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A, SLOT0); }
         store_raw(g0.f32, g0.slot, KPW0 - 1, raw0[KPW0 - 1]);
-        kstep(wbase, KPW0 - 1, 0, NO, RIDE_A);
+        kstep(wbase, KPW0 - 1, 0, NO, RIDE_A, SLOT0);
     } else {
 #pragma unroll
-        for (int j = 0; j < KPW0; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A); }
+        for (int j = 0; j < KPW0; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A, SLOT0); }
 #pragma unroll
-        for (int j = 0; j < KPW1 - 1; ++j) { store_raw(g1.f32, g1.slot, j, raw1[j]); kstep(wbase, j, KPW0 + j + 1, YES, RIDE_A); }
+        for (int j = 0; j < KPW1 - 1; ++j) { store_raw(g1.f32, g1.slot, j, raw1[j]); kstep(wbase, j, KPW0 + j + 1, YES, RIDE_A, SLOT0); }
         store_raw(g1.f32, g1.slot, KPW1 - 1, raw1[KPW1 - 1]);
-        kstep(wbase, KPW1 - 1, 0, NO, RIDE_A);
+        kstep(wbase, KPW1 - 1, 0, NO, RIDE_A, SLOT0);
     }
     PH(2);                                    // 2 = phase A's K loop done (staging waits + MFMAs)
     // (phase B's first stage of weights is requested further down, where this wave would otherwise idle: requested HERE, the
     // 20 KB per wave sat in front of the epilogue's first LDS writes in the issue queue -- the cross-wave reduction of phase A
     // measured 1.5 us in the replayed step against 0.5 us for the same code in phase B)
     PfRegs pfr;
-    if (a.tune & 1) {                         // A/B: the round-3 placement
 #pragma unroll
-        for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
-        l2_prefetch(a.pf, pfr);
-    }
+    for (int k = 0; k < PF_REGIONS; ++k) pfr.v[k][0] = pfr.v[k][1] = 0u;
+    auto issue_b = [&]() {                    // phase B's first stage of weights
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap, SLOT0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // ---- shared epilogue pieces ---------------------------------------------------------------------------------------
     auto reduce_to = [&](const f32x4 (&m)[3][2], const f32x4 (&l)[3][2], float bs, float (&v)[6]) {
@@ -732,7 +764,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     const int gwt = a.gw < TN ? a.gw : TN;
     const float cnt = (float)(L * gwt);
     // GroupNorm + Mish of the reduced tile v (dconv_kernel's, incl. the pair exchange through `xchg` when gw == 64)
-    auto gn_mish = [&](const float (&v)[6], unsigned long long* xchg, float gam, float bet, float (&y)[6], auto phb) {
+    auto gn_mish = [&](const float (&v)[6], unsigned long long* xchg, float gam, float bet, float (&y)[6], auto phb, auto after_xchg) {
         constexpr int PHB = decltype(phb)::value;      // phase marks PHB (own statistics done, published) and PHB + 1 (partner's in)
         (void)PHB;
         float mean[NSAMP], rstd[NSAMP];
@@ -796,6 +828,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             }
             PH(PHB + 1);
         }
+        after_xchg();                             // (requests that must not sit in front of the exchange's poll in the return queue)
         const float cnt_all = a.gw == 64 ? 2.f * cnt : cnt;
 #pragma unroll
         for (int js = 0; js < NSAMP; ++js) rstd[js] = 1.0f / sqrtf(rstd[js] / cnt_all + 1e-5f);
@@ -827,7 +860,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     stress_delay(a.stress, 3u);
     reduce_to(accM, accL, bias_a, v);
     PH(3);                                    // 3 = cross-wave reduction of phase A (LDS round trip + barrier)
-    gn_mish(v, a.xchg_a, gam_a, bet_a, y, std::integral_constant<int, 4>{});      // 4, 5 = GroupNorm statistics / pair exchange
+    gn_mish(v, a.xchg_a, gam_a, bet_a, y, std::integral_constant<int, 4>{}, [&]() {});      // 4, 5 = GroupNorm statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += tbv;
     planes_to_tile(y);
@@ -837,27 +870,25 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         const uint32_t* tw = reinterpret_cast<const uint32_t*>(Tile);
         const size_t plane_bytes = a.y0_pstride * 16;
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.y0), 0, (unsigned)(2 * plane_bytes), 0x00020000);
-        for (int i = tid; i < 384; i += 256) {
+        auto store_item = [&](int i) {
             const int pl = i >= 192 ? 1 : 0, within = i - pl * 192;
             const int kq = within / 48, row = within - kq * 48;
             const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * 48 * TP + row * TP + kq * 4);
             const unsigned off = (unsigned)(pl * plane_bytes + (((size_t)mt * a.NT + nt) * 192 + within) * 16);
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rsrc, off, 0, 16);     // aux 16 = sc1: write-through
-        }
-    }
-    PH(6);                                    // 6 = Mish, time bias, planes through LDS, write-through stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
-    stress_delay(a.stress, 6u);
-    __syncthreads();
-    if (tid == 0 && !(a.dbg == 9 && (nt & 1)))
-        __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    PH(7);                                    // 7 = stores drained, flag raised
-    // phase B's first stage of weights + the next launch's L2 warm-up: in flight during the hand-over (flag poll, y0 fetch)
-    if (!(a.tune & 1)) {
-#pragma unroll
-        for (int tap = 0; tap < T; ++tap) load_b_tap(wbase_b, 0, tap);
-        l2_prefetch(a.pf, pfr);
+        };
+        for (int i = tid; i < 384; i += 256) store_item(i);
+        PH(6);                                // 6 = Mish, time bias, planes through LDS, write-through stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+        stress_delay(a.stress, 6u);
+        __syncthreads();
+        if (tid == 0 && !(a.dbg == 9 && (nt & 1)))
+            __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PH(7);                                // 7 = stores drained, flag raised
+        // phase B's first stage of weights: in flight during the hand-over (flag poll, y0 fetch)
+        issue_b();
+        if (a.tune & 1) l2_prefetch(a.pf, pfr);       // A/B: round 5's placement of the next launch's warm-up
     }
     // r = Wr x + br stays in registers (Red is free again: the barrier above)
     float r2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -915,30 +946,41 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     }
     // ---- phase B K loop --------------------------------------------------------------------------------------------------
     zero_acc();
-#pragma unroll
-    for (int j = 0; j < KPWB; ++j) {
+    // k-step j multiplies ring slot j % BD and refills it, tap by tap behind each tap's last use, with stage j + BD
+    auto kb_step = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr std::integral_constant<int, j % BD> slot{};
         store_raw(false, slotb, j, rawb[j % YB]);
         if (j + YB < KPWB) fetch_y0(j + YB, rawb[j % YB]);
         // k-steps are scheduling regions of their own: in ONE region the scheduler sinks the next stage's weight requests
-        // (issued behind each tap's last use, a k-step ahead of their consumers) down to those consumers.  Phase A has the
+        // (issued behind each tap's last use, ahead of their consumers) down to those consumers.  Phase A has the
         // same protection by accident -- store_raw's run-time source-kind branch ends a basic block per k-step.
         __builtin_amdgcn_sched_barrier(0);
-        if (j < KPWB - 1) kstep(wbase_b, j, j + 1, YES, NO);
-        else kstep(wbase_b, j, 0, NO, NO);
+        if constexpr (j + BD < KPWB) kstep(wbase_b, j, j + BD, YES, NO, slot);
+        else kstep(wbase_b, j, 0, NO, NO, slot);
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    kb_step(std::integral_constant<int, 0>{});
+    if constexpr (KPWB > 1) kb_step(std::integral_constant<int, 1>{});
+    if constexpr (KPWB > 2) kb_step(std::integral_constant<int, 2>{});
+    if constexpr (KPWB > 3) kb_step(std::integral_constant<int, 3>{});
+    static_assert(KPWB <= 4, "phase B: at most four k-steps per wave");
     PH(10);                                   // 10 = phase B's K loop done (y0 fetch waits + MFMAs)
+    // the NEXT launch's L2 warm-up (kernels.h Pf), round 6: issued HERE, a few microseconds before this launch ends.  Through round 5 it
+    // was issued behind the publish, i.e. in front of phase B's 1.3 MB per XCD of weights and 1.6 MB of y0: the touched lines did not
+    // survive in the 4 MB L2 (n-tiles with and without warm-up streamed equally fast; the option was a net loss)
+    if (!(a.tune & 1)) l2_prefetch(a.pf, pfr);
 
     // ---- phase B epilogue: out = Mish(GN(.)) + (x | r) -------------------------------------------------------------------
     stress_delay(a.stress, 8u);
     reduce_to(accM, accL, bias_b, v);
     PH(11);                                   // 11 = cross-wave reduction of phase B
-    gn_mish(v, a.xchg_b, gam_b, bet_b, y, std::integral_constant<int, 12>{});     // 12, 13 = statistics / pair exchange
+    gn_mish(v, a.xchg_b, gam_b, bet_b, y, std::integral_constant<int, 12>{}, [&]() {});     // 12, 13 = statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += RES ? r2[q] : rs[q];
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        if (a.out_f32 && sok[q]) a.out_f32[(size_t)grow[q] * a.ldo + gn] = y[q];
+        if (a.out_f32 && sok[q]) st_out(a.out_f32, (size_t)grow[q] * a.ldo + gn, y[q], a.pf.wt);
     if (a.out_planes) {
         __syncthreads();                                          // Tile: the publish above has been read
         planes_to_tile(y);
@@ -948,7 +990,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             const int pl = i >= 192 ? 1 : 0, within = i - pl * 192;
             const int kq = within / 48, row = within - kq * 48;
             const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * 48 * TP + row * TP + kq * 4);
-            a.out_planes[pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within] = t4;
+            st_out4(a.out_planes, pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within, t4, a.pf.wt);
         }
     }
     PH(14);                                   // 14 = Mish, residual, fp32 + planes stores issued
@@ -1022,7 +1064,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     const float bias_ld = (a.bias ? a.bias : reinterpret_cast<const float*>(a.W))[gn];      // (pointer selected, load unconditional)
     const float bias = a.bias ? bias_ld : 0.f;
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
     __builtin_amdgcn_sched_barrier(0);
     PH(1);
 
@@ -1078,6 +1120,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     for (int j = 0; j < KPW - 1; ++j) kstep(j, j + 1, YES);
     kstep(KPW - 1, 0, NO);
     PH(2);
+    l2_prefetch_late(a.pf, pfr);
 
     // cross-wave K reduction; thread (n, rq) ends with column n of rows rq + 8 q (row = position * 16 + sample)
 #pragma unroll
@@ -1094,7 +1137,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     for (int q = 0; q < NQ; ++q) {
         const int r = rq + 8 * q, sm = r & 15, pos = r >> 4;
         const float y = ((Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n])) + bias;
-        if (sm < ns) a.out_f32[(size_t)((b0 + sm) * LOUT + pos) * a.ldo + gn] = y;
+        if (sm < ns) st_out(a.out_f32, (size_t)((b0 + sm) * LOUT + pos) * a.ldo + gn, y, a.pf.wt);
         const _Float16 hi = (_Float16)y;
         const _Float16 lo = (_Float16)((y - (float)hi) * H3_SCALE);
         const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
@@ -1117,7 +1160,7 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
                 if (tile * 8 >= a.Bp) continue;                  // (a ragged batch: the second 8-sample tile does not exist)
                 dst = ((size_t)tile * a.NT + nt) * 192 + kq * 48 + pos * 8 + (sm & 7);
             }
-            a.out_planes[pl * a.out_pstride + dst] = t4;
+            st_out4(a.out_planes, pl * a.out_pstride + dst, t4, a.pf.wt);
         }
     }
     PH(4);
@@ -1219,7 +1262,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             for (int pl = 0; pl < 2; ++pl)
                 wo[t][k][pl] = Wo4[(((size_t)(hd * CT4 + w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane];
     PfRegs pfr;
-    l2_prefetch(a.pf, pfr);
+    l2_prefetch_early(a.pf, pfr);
     PH(1);
 
     // ---- LayerNorm of the group's positions -> split-fp16 planes (as attn1d_site_h3_kernel) ----
@@ -1360,6 +1403,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
                 __hip_atomic_store(gx + hd * 512 + (et * 16 + lq * 4 + i) * 16 + lr, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PH(6);
+    l2_prefetch_late(a.pf, pfr);
     // gather all four heads' tiles (own head included: one code path) -> att planes [position][128 channels]
     stress_delay(a.stress, 12u);
     {
@@ -1415,7 +1459,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             const float4 xv = ex[t];
             float4 o;
             o.x = z[0] + b.x + xv.x; o.y = z[1] + b.y + xv.y; o.z = z[2] + b.z + xv.z; o.w = z[3] + b.w + xv.w;
-            *reinterpret_cast<float4*>(a.out + row * a.ldo + c) = o;
+            st_out4(a.out, row * a.ldo + c, o, a.pf.wt);
         }
     }
     PH(9);

@@ -175,7 +175,28 @@ class GaussianDiffusion1D(nn.Module):
         exchange-free plan from the start (correct, about 10 % slower); ``chains_in_flight`` when it started, itself included."""
         info = (C.c_int32 * 4)()
         _ffi.check(_ffi.lib().cindm_ddpm1d_last_chain_info(self._handle(), info))
-        return {"recovered": bool(info[0]), "exchange_free_up_front": bool(info[1]), "chains_in_flight": int(info[2])}
+        return {"recovered": bool(info[0]), "exchange_free_up_front": bool(info[1]), "chains_in_flight": int(info[2]),
+                "range_fallback": int(info[3])}
+
+    def _chain(self, img, desc, call):
+        """One library chain over ``img`` (in place): ``call(h, un, ws)`` issues it.  The FIRST chain after a weight synchronisation
+        also carries the range rule on the caller's own data (TemporalUnet1D.range_guard): x_T is kept, the designs are
+        checked once, and a chain that came back inf / nan from the split-fp16 kernels is repeated on the exact fp32-MFMA kernels."""
+        device, B = img.device, img.shape[0]
+        h, un, ws = self._prepare(desc, B, device)
+        models = [self.model] + ([self.model_unconditioned] if un is not None else [])
+        pend = [m for m in models if m.range_guard_pending()]
+        x0 = img.clone() if pend else None
+        call(h, un, ws)
+        self._note_chain()
+
+        def rerun():
+            img.copy_(x0)
+            call(*self._prepare(desc, B, device))        # (the fp32 plan sizes its own workspace)
+            self._note_chain()
+        for m in pend:
+            m.range_guard(lambda: img, rerun, device)
+        return img
 
     def _note_chain(self):
         info = self.last_chain_info()
@@ -405,17 +426,17 @@ class GaussianDiffusion1D(nn.Module):
                   inpaint_noise_steps, use_graph=True):
         """The unguided reverse loop as one library call (cindm_ddpm1d_sample)."""
         B = img.shape[0]
-        h, un, ws = self._prepare(desc, B, img.device)
         cond_d = self._f32(cond, img.device) if (cond is not None and self.conditioned_steps != 0) else None
         inp = self._f32(inpaint_cond, img.device)
-        with torch.cuda.device(img.device):
-            _ffi.check(_ffi.lib().cindm_ddpm1d_sample(
-                h, self.model._h, un, C.byref(desc), _ffi.ptr(img), _ffi.ptr(cond_d), _ffi.ptr(noise_steps),
-                C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
-                _ffi.ptr(inpaint_noise_steps), t_start, t_end, B, _ffi.ptr(ws), ws.numel(),
-                _ffi.current_stream(img.device), int(use_graph)))
-        self._note_chain()
-        return img
+
+        def call(h, un, ws):
+            with torch.cuda.device(img.device):
+                _ffi.check(_ffi.lib().cindm_ddpm1d_sample(
+                    h, self.model._h, un, C.byref(desc), _ffi.ptr(img), _ffi.ptr(cond_d), _ffi.ptr(noise_steps),
+                    C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
+                    _ffi.ptr(inpaint_noise_steps), t_start, t_end, B, _ffi.ptr(ws), ws.numel(),
+                    _ffi.current_stream(img.device), int(use_graph)))
+        return self._chain(img, desc, call)
 
     @torch.no_grad()
     def _run_guided_loop(self, img, cond, desc, dz, t_start, t_end, *, noise, seed, sample_offset, inpaint_cond,
@@ -423,19 +444,19 @@ class GaussianDiffusion1D(nn.Module):
         """Reverse steps t_start .. t_end guided by the built-in objective as one library call
         (cindm_ddpm1d_sample_guided); ``noise`` rows (step / recur / cond) are indexed by t."""
         device, B = img.device, img.shape[0]
-        h, un, ws = self._prepare(desc, B, device)
         cond_d = self._f32(cond, device) if (cond is not None and self.conditioned_steps != 0) else None
         inp = self._f32(inpaint_cond, device)
         iso = self._f32(initial_state_overwrite, device)
-        with torch.cuda.device(device):
-            _ffi.check(_ffi.lib().cindm_ddpm1d_sample_guided(
-                h, self.model._h, un, C.byref(desc), C.byref(dz), _ffi.ptr(img), _ffi.ptr(cond_d),
-                _ffi.ptr(None if noise is None else noise.step), _ffi.ptr(None if noise is None else noise.recur),
-                C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
-                _ffi.ptr(None if noise is None else noise.cond), _ffi.ptr(iso), 0 if iso is None else iso.shape[1],
-                int(t_start), int(t_end), B, _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
-        self._note_chain()
-        return img
+
+        def call(h, un, ws):
+            with torch.cuda.device(device):
+                _ffi.check(_ffi.lib().cindm_ddpm1d_sample_guided(
+                    h, self.model._h, un, C.byref(desc), C.byref(dz), _ffi.ptr(img), _ffi.ptr(cond_d),
+                    _ffi.ptr(None if noise is None else noise.step), _ffi.ptr(None if noise is None else noise.recur),
+                    C.c_uint64(seed), sample_offset, _ffi.ptr(inp), 0 if inp is None else inp.shape[1],
+                    _ffi.ptr(None if noise is None else noise.cond), _ffi.ptr(iso), 0 if iso is None else iso.shape[1],
+                    int(t_start), int(t_end), B, _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+        return self._chain(img, desc, call)
 
     def _init_state(self, shape, device, noise, seed, sample_offset, tag):
         if noise is not None:
@@ -618,19 +639,19 @@ class GaussianDiffusion1D(nn.Module):
         inpaint = cond if (self.conditioned_steps == 0 and cond is not None) else None
         if design_fn is None:
             desc = self._desc_for(shape, None, clip=clip_denoised)
-            h, un, ws = self._prepare(desc, B, device)
             cond_d = self._f32(cond, device) if (cond is not None and self.conditioned_steps != 0) else None
             inp = self._f32(inpaint, device)
             tarr = (C.c_int32 * (S + 1))(*times)
             carr = coefs.contiguous()
-            with torch.cuda.device(device):
-                _ffi.check(_ffi.lib().cindm_ddpm1d_sample_ddim(
-                    h, self.model._h, un, C.byref(desc), _ffi.ptr(img), _ffi.ptr(cond_d), S, tarr, _ffi.ptr(carr),
-                    _ffi.ptr(None if noise is None else noise.step), C.c_uint64(seed), sample_offset, _ffi.ptr(inp),
-                    0 if inp is None else inp.shape[1], _ffi.ptr(None if noise is None else noise.cond), B,
-                    _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
-            self._note_chain()
-            return img
+
+            def call(h, un, ws):
+                with torch.cuda.device(device):
+                    _ffi.check(_ffi.lib().cindm_ddpm1d_sample_ddim(
+                        h, self.model._h, un, C.byref(desc), _ffi.ptr(img), _ffi.ptr(cond_d), S, tarr, _ffi.ptr(carr),
+                        _ffi.ptr(None if noise is None else noise.step), C.c_uint64(seed), sample_offset, _ffi.ptr(inp),
+                        0 if inp is None else inp.shape[1], _ffi.ptr(None if noise is None else noise.cond), B,
+                        _ffi.ptr(ws), ws.numel(), _ffi.current_stream(device), int(use_graph)))
+            return self._chain(img, desc, call)
         if "recurrence" not in design_guidance:
             raise NotImplementedError("DDIM with design_fn needs a '-recurrence-N' guidance (the reference's other branch "
                                       "returns x_{t-1}, not a noise prediction, :1283)")

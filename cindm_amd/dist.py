@@ -1,8 +1,8 @@
 """Multi-GPU sampling: the design batch is embarrassingly parallel (every design is an independent
 Markov chain), so it is partitioned into contiguous slices, one process per GPU, with
-NO communication inside the reverse loop and ONE all-gather of the final designs: the library's own
-``cindm_all_gather_designs`` (ncclAllGather of librccl over xGMI, include/cindm_hip.h) when the process group's backend is
-"nccl" (= RCCL on ROCm), ``torch.distributed`` over gloo in the CPU tests.  Noise is keyed by the GLOBAL sample index
+NO communication inside the reverse loop and ONE all-gather of the final designs: ``torch.distributed.all_gather`` (the
+"nccl" backend IS RCCL over xGMI on ROCm; gloo in the CPU tests), or -- opt-in, ``CINDM_RCCL_C_ENTRY=1`` -- the library's own
+``cindm_all_gather_designs`` (ncclAllGather of librccl, include/cindm_hip.h).  Noise is keyed by the GLOBAL sample index
 (``sample_offset``), so the gathered result does not depend on the number of ranks.
 The reference has no counterpart (its inference scripts are single-device)."""
 import torch
@@ -16,26 +16,51 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-_COMMS = {}          # process group -> RcclComm (the library's own communicator: one per group, made on first use)
+_COMMS = {}          # key -> (process-group object, RcclComm): the library's own communicator, one per group, made on first use
+
+
+def _use_library_default():
+    """The library's C entry (``cindm_all_gather_designs``) is an OPT-IN (``CINDM_RCCL_C_ENTRY=1`` or ``use_library=True``):
+    it has executed with one rank only (no multi-GPU node was available to this build), so the default
+    multi-rank gather is ``torch.distributed``'s all_gather -- which on the "nccl" backend IS RCCL over xGMI."""
+    import os
+    return os.environ.get("CINDM_RCCL_C_ENTRY", "0") not in ("", "0")
 
 
 class RcclComm:
     """The library's RCCL communicator (include/cindm_hip.h: cindm_comm_*): rank 0 makes the 128-byte unique id with
     ``ncclGetUniqueId``, the id travels over the torch.distributed group the caller already has, every rank calls
-    ``ncclCommInitRank`` on its current device.  ``all_gather(local)`` is ONE ``ncclAllGather`` on the current stream."""
+    ``ncclCommInitRank`` on its current device.  ``all_gather(local)`` is ONE ``ncclAllGather`` on the current stream.
+    Failures are collective: rank 0 broadcasts (ok, id) so that every rank raises together instead of the others hanging in
+    the broadcast, and the outcome of ``ncclCommInitRank`` is all-reduced before anyone uses the communicator."""
 
     def __init__(self, group=None):
         import ctypes as C
         from . import _ffi
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         buf = (C.c_ubyte * 128)()
+        ok, why = True, ""
         if rank == 0:
-            _ffi.check(_ffi.lib().cindm_comm_unique_id(buf))
-        box = [bytes(buf)]
+            try:
+                _ffi.check(_ffi.lib().cindm_comm_unique_id(buf))
+            except Exception as e:      # noqa: BLE001 -- forwarded to every rank below
+                ok, why = False, str(e)
+        box = [(ok, why, bytes(buf))]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        idb = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        ok, why, idbytes = box[0]
+        if not ok:
+            raise _ffi.CindmError(f"cindm_comm_unique_id failed on rank 0: {why}")
+        idb = (C.c_ubyte * 128).from_buffer_copy(idbytes)
         h = C.c_void_p()
-        _ffi.check(_ffi.lib().cindm_comm_init(idb, world, rank, C.byref(h)))
+        rc = _ffi.lib().cindm_comm_init(idb, world, rank, C.byref(h))
+        err = _ffi.lib().cindm_last_error().decode() if rc != 0 else ""
+        flags = [None] * world
+        dist.all_gather_object(flags, (rc, err), group=group)
+        bad = [(r, e) for r, (c, e) in enumerate(flags) if c != 0]
+        if bad:
+            if rc == 0 and h.value:
+                _ffi.lib().cindm_comm_destroy(h)
+            raise _ffi.CindmError("cindm_comm_init failed on rank(s) " + ", ".join(f"{r}: {e}" for r, e in bad))
         self._h, self.world, self.rank = h, world, rank
 
     def all_gather(self, local):
@@ -56,25 +81,37 @@ class RcclComm:
 
 
 def rccl_comm(group=None):
-    key = group if group is not None else "world"
-    if key not in _COMMS:
-        _COMMS[key] = RcclComm(group)
-    return _COMMS[key]
+    """The library communicator of ``group`` (made on first use).  The cache entry remembers the process-group OBJECT it was
+    made for: after ``destroy_process_group`` + a new ``init_process_group`` the world group is another object, the stale
+    communicator is destroyed and a new one is made (a stale ``world`` / ``rank`` would otherwise survive the re-init)."""
+    pg = group if group is not None else dist.group.WORLD
+    key = id(pg) if group is not None else "world"
+    ent = _COMMS.get(key)
+    if ent is not None and ent[0] is not pg:
+        ent[1].close()
+        ent = None
+    if ent is None:
+        ent = (pg, RcclComm(group))
+        _COMMS[key] = ent
+    return ent[1]
 
 
 def close_comms():
-    """Destroys the library's communicators (before ``dist.destroy_process_group``)."""
-    for c in _COMMS.values():
+    """Destroys the library's communicators (call before ``dist.destroy_process_group``)."""
+    for _, c in _COMMS.values():
         c.close()
     _COMMS.clear()
 
 
-def all_gather_designs(local, total, group=None, use_library=True):
-    """Gathers per-rank [B_r, L, F] slices (in rank order) into [total, L, F] on every rank.  On the RCCL backend with device
-    tensors this is the library's own ``cindm_all_gather_designs`` (one ncclAllGather over xGMI, SURVEY.md section 8b);
-    ``use_library=False`` and the gloo backend (CPU tests; several ranks sharing one GPU) go through ``torch.distributed``."""
+def all_gather_designs(local, total, group=None, use_library=None):
+    """Gathers per-rank [B_r, L, F] slices (in rank order) into [total, L, F] on every rank: ONE all-gather of the shards padded to
+    the largest one.  Default: ``torch.distributed.all_gather`` -- RCCL over xGMI on the "nccl" backend, gloo (staged through the
+    host) in the CPU tests and when several ranks share one GPU.  ``use_library=True`` (or ``CINDM_RCCL_C_ENTRY=1``) issues the
+    same collective through the library's own C entry ``cindm_all_gather_designs`` instead."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
+    if use_library is None:
+        use_library = _use_library_default()
     world = dist.get_world_size(group)
     sizes = [shard_bounds(total, r, world) for r in range(world)]
     maxb = max(hi - lo for lo, hi in sizes)

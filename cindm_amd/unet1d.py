@@ -202,7 +202,43 @@ class TemporalUnet1D(nn.Module):
         launch()
         if check and self.poll_status(x.device):
             self.rerun_exchange_free(launch, x.device)
+        if check and self.range_guard_pending():
+            # the range rule on the caller's own data: the FIRST checked forward after a weight synchronisation
+            self.range_guard(lambda: out, launch, x.device)
         return out
+
+    # ------------------------------------------------------------------ range rule on the caller's data (round 6)
+    def range_guard_pending(self):
+        """True until the first result after the last weight synchronisation has been checked -- and only where the check can
+        change anything: the handle runs the split-fp16 kernels with ``auto_range`` on."""
+        if self.__dict__.get("_range_checked_sig") == self._sig and self._sig is not None:
+            return False
+        return bool(self.get_option("auto_range")) and not self.get_option("mfma_f32") and not self.get_option("range_fallback")
+
+    def range_guard(self, result, rerun, device):
+        """``result()`` is what the split-fp16 kernels just produced for the caller's own inputs.  Finite: nothing to do (one
+        reduction and one synchronise, once per weight synchronisation).  inf / nan: the un-normalised residual stream of this
+        checkpoint left fp16's exponent range on real data although the synthetic calibration batch passed -- the handle is repacked
+        for the exact fp32-MFMA kernels (``get_option("range_fallback")`` reads 3), ``rerun()`` repeats the work; if that is not
+        finite either the cause was not the range (non-finite inputs / weights) and the split-fp16 pack is restored.
+        Returns True when the handle was escalated."""
+        self._range_checked_sig = self._sig
+        if bool(torch.isfinite(result()).all()):
+            return False
+        import warnings
+        with torch.cuda.device(device):
+            _ffi.check(_ffi.lib().cindm_unet1d_range_escalate(self._h, 1, _ffi.current_stream(device)))
+        self._ws = None; self._ws_rows = 0           # (the fp32 plan has its own workspace size)
+        rerun()
+        if bool(torch.isfinite(result()).all()):
+            warnings.warn("cindm_amd: the first result after loading these weights was not finite on the split-fp16 kernels (an activation left "
+                          "fp16's exponent range on the caller's data); the model now runs on the exact fp32-MFMA kernels, about 2x slower "
+                          "(get_option('range_fallback') == 3)", RuntimeWarning)
+            return True
+        with torch.cuda.device(device):
+            _ffi.check(_ffi.lib().cindm_unet1d_range_escalate(self._h, 0, _ffi.current_stream(device)))
+        self._ws = None; self._ws_rows = 0
+        return False
 
     TIMEOUT_TEXT = ("an in-kernel exchange between workgroups timed out (GroupNorm pair / attention head exchange): "
                     "the results of that forward are invalid")

@@ -34,7 +34,7 @@ extern "C" {
  * positional sum_boundary argument of cindm_airfoil_design_grad / cindm_ddpm2d_sample_force, and round 4's additions
  * (cindm_unet1d_poll, cindm_ddpm2d_predict, cindm_unet1d_phase_prof_*, option "no_exchange", cindm_unet1d_recovered).
  * A caller compiled against another version must not bind: compare cindm_abi_version() with this constant. */
-#define CINDM_ABI_VERSION 3
+#define CINDM_ABI_VERSION 4
 
 typedef struct cindm_unet1d cindm_unet1d;
 typedef struct cindm_ddpm1d cindm_ddpm1d;
@@ -113,6 +113,11 @@ int  cindm_unet1d_status(cindm_unet1d* h, void* stream);
  * resident) is re-run ONCE from its initial state on the exchange-free kernels; cindm_unet1d_recovered() counts those re-runs. */
 int  cindm_unet1d_poll(cindm_unet1d* h, void* stream);
 int  cindm_unet1d_recovered(const cindm_unet1d* h);
+/* The range rule on the caller's own data (ABI 4): on = 1 repacks a handle that runs the split-fp16 kernels for the exact fp32-MFMA
+ * kernels ("range_fallback" then reads 3) -- called by the Python face when the FIRST forward / chain after a weight synchronisation
+ * returns inf / nan; on = 0 undoes exactly that.  Synchronises the stream and repacks the weights as cindm_unet1d_finalize does (a
+ * finalisation step, not part of a chain's steady state: at most once per weight synchronisation). */
+int  cindm_unet1d_range_escalate(cindm_unet1d* h, int32_t on, void* stream);
 /* Profiling builds only (cindm_amd/build.py --prof: -DCINDM_PHASE_PROF -> libcindm_hip_prof.so): per-launch, per-workgroup,
  * per-wave phase clocks (s_memrealtime, 100 MHz) of the level kernels, dconv2_kernel, dresample_kernel and attn1d_head_kernel.
  * enable: (re)allocates the record buffer and arms it for every following forward of this handle (inside graph replays too);
@@ -200,6 +205,10 @@ typedef struct {
     float   uncond_coef;        /* coefficient_unconditioned_grad = 1.4 (MULTIBODY)        :1900 */
 } cindm_compose_desc;
 
+/* Bytes of the step workspace: the U-Net inputs / predictions of a composed step, the U-Net workspace(s), the guided step's
+ * staging, AND (ABI 4) the chain-level buffers of the sample loops -- the x_T snapshot the exchange-time-out recovery re-runs
+ * from (B * L_tot * F floats) and the DDIM loop's per-step tables (5 words per U-Net timestep).  Nothing is allocated after
+ * *_create / *_finalize: no entry point below calls hipMalloc / hipFree (asserted by a CPU test over the sources). */
 size_t cindm_ddpm1d_workspace_bytes(const cindm_ddpm1d* h, const cindm_unet1d* pair,
                                     const cindm_unet1d* uncond, const cindm_compose_desc* c, int64_t B);
 

@@ -236,6 +236,32 @@ def test_bench_two_ranks_end_to_end(device):
         assert "shared_gpus" in line
 
 
+def test_bench_eight_ranks_cfg4_first_contact(device):
+    """First-contact insurance for the driver's 8-GPU run (no multi-GPU node has ever been available to this build): `bench.py --gpus 8
+    --workload cfg4` -- BASELINE configs[3], "batch 1024 sharded over 8 GPUs" -- with 8 designs per rank: the child
+    torch.distributed.run, EIGHT ranks rendezvous, every rank samples its shard of the 4-body composition (pair + single-body U-Nets),
+    one gather, max over ranks, rank 0's one line.  On this one-GPU box the eight ranks share the device over gloo (labelled
+    "shared_gpus", a code-path run); on an 8-GPU node the same command is the RCCL path.  What has still never run with N > 1 on RCCL:
+    torch's nccl all_gather of the designs, and -- behind CINDM_RCCL_C_ENTRY=1 -- the library communicator's id broadcast, a second
+    communicator beside torch's, the ragged-shard padding."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "cfg4", "--steps", "1", "--warmup", "0",
+                        "--batch", "8", "--no-cpu-baseline", "--no-extra-workloads"], capture_output=True, text=True, timeout=2400, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["designs_per_step"] == 64 and line["config"]["parallelism"].startswith("dp8")
+    assert line["config"]["reverse_steps_per_design"] == 400 and line["value"] > 0
+    if torch.cuda.device_count() < 8:
+        assert "shared_gpus" in line
+
+
 def test_rccl_one_rank_through_the_c_entry():
     """RCCL is loaded and CALLED on this box: torch.distributed's "nccl" backend with one rank, and the library's own
     communicator (cindm_comm_unique_id / cindm_comm_init -> ncclCommInitRank) + cindm_all_gather_designs (ncclAllGather) must

@@ -40,6 +40,8 @@ PATHS_1D = [
     {"l2_prefetch": 0}, {"h3_resample": 0}, {"site_pack": 0},
     {"dconv": 0, "level0": 0, "attn_head": 0},      # the round-1 per-layer path
     {"no_exchange": 1},                   # the exchange-free selection a timed-out chain is re-run on (no in-launch hand-over between workgroups)
+    {"tune": 3},                          # round 5's memory-system choices: L2 warm-ups at the head of a launch, outputs left dirty in L2
+    {"tune": 1}, {"tune": 2},             # ... one at a time (bit 0: warm-up placement / regions, bit 1: plain output stores)
 ]
 IDS_1D = ["-".join(f"{k}{v}" for k, v in p.items()) for p in PATHS_1D]
 
@@ -737,3 +739,72 @@ def test_unet2d_round5_paths_agree_at_full_occupancy(device):
     assert rel(m(x, t), ref) < 5e-6
     m.set_option("ws_nosplit", 2); m.set_option("ws_m32", 0)
     assert torch.equal(m(x, t), new)
+
+
+def _standin_simulation(features, n_steps, **kw):
+    """The deterministic stand-in of tests/test_host_logic.py (utils.simulation is a pymunk program): constant velocity with
+    reflecting walls, [batch, n_bodies, 4] -> [batch, n_steps, n_bodies, 4]; runs on whatever device `features` lives on."""
+    f = features.double()
+    steps = torch.arange(1, n_steps + 1, dtype=torch.float64, device=f.device).view(1, -1, 1, 1)
+    pos = f[:, None, :, :2] + f[:, None, :, 2:] * steps / 60.0
+    pos = 200.0 - (pos.remainder(400.0) - 200.0).abs()
+    vel = f[:, None, :, 2:].expand(-1, n_steps, -1, -1)
+    return torch.cat([pos, vel], dim=-1).float()
+
+
+def test_checkpoint_to_eval_simu_on_the_device(device, tmp_path):
+    """SURVEY section 8 f4, end to end ON THE DEVICE: a checkpoint FILE -> `load_state_dict(torch.load(path)["model"])` (1-D,
+    inference/inverse_design_diffusion_1d.py:179-180) and `Trainer(diffusion, ...).load(milestone)` (2-D, model/diffusion_2d.py:1213-1231)
+    -> a few reverse steps on the HIP path -> `to_simulator_units` -> `eval_simu` (utils.py:1127-1148, stand-in simulator) on the device
+    output -- compared with the oracle driven the same way from the same file."""
+    from cindm_amd.data_utils import eval_simu, get_item_1d, to_simulator_units
+    # ---- 1-D: the checkpoint a training run of the reference would have written ({"step", "model": diffusion.state_dict(), ...}) ----
+    src, sd = build_unet(device)
+    d_src = cindm_amd.GaussianDiffusion1D(src, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000, loss_type="l1")
+    path = tmp_path / "model-7.pt"
+    torch.save({"step": 7000, "model": {k: v.detach().cpu() for k, v in d_src.state_dict().items()}, "version": "1.0"}, str(path))
+    fresh = cindm_amd.TemporalUnet1D(24, 8, False, attention=True)
+    d = cindm_amd.GaussianDiffusion1D(fresh, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000, loss_type="l1")
+    d.load_state_dict(torch.load(str(path), map_location="cpu")["model"])          # strict: the reference's key names
+    d = d.to(device)
+    tape = _tape(4242, (4, 24, 8), 1000)
+    out = d.sample(batch_size=4, cond=None, n_composed=0, compose_n_bodies=2, noise=tape, t_stop=990)
+    file_sd = {k[len("model."):]: v for k, v in torch.load(str(path), map_location="cpu")["model"].items() if k.startswith("model.")}
+    od = O.Diffusion1D(file_sd, image_size=24, conditioned_steps=0)
+    otape = O.NoiseTape.make(4242, (4, 24, 8), 1000)
+    ref = O.sample(od, 4, otape, n_composed=0, compose_n_bodies=2, t_stop=990)
+    assert out.is_cuda and rel(out, ref) < TOL_CHAIN
+    # post-processing on the DEVICE output: simulator units and back, then the re-simulation + objective of eval_simu
+    sim_units = to_simulator_units(out, 2)
+    assert sim_units.is_cuda and tuple(sim_units.shape) == (8, 24, 4)
+
+    class Batch(dict):
+        dyn_dims = [0, 0, 0, 0]
+    assert torch.allclose(get_item_1d(Batch(y=sim_units), "y"), out, rtol=0, atol=1e-6)
+    objective = lambda traj: ((traj[:, -1, :2] - 0.25) ** 2).sum(-1).mean() + ((traj[:, -1, 4:6] + 0.5) ** 2).sum(-1).mean()
+    pred, score = eval_simu(out[:, :4], objective, 2, 20, time_interval=4, simulation=_standin_simulation)
+    pred_ref, score_ref = eval_simu(ref[:, :4], objective, 2, 20, time_interval=4, simulation=_standin_simulation)
+    assert pred.is_cuda and tuple(pred.shape) == (4, 20, 8)
+    assert rel(pred, pred_ref) < TOL_CHAIN and abs(float(score) - float(score_ref)) < TOL_CHAIN * max(1.0, abs(float(score_ref)))
+    with pytest.raises(TypeError):
+        eval_simu(out[:, :4], objective, 2, 20, simulation=None)
+    # ---- 2-D: Trainer(diffusion, ...).load(milestone), as inverse_design_2d.py:191-207 does ----
+    sd2 = O.synth_state_dict_2d(O.unet2d_param_shapes(64, (1, 2), 21), 3)
+    donor = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64)
+    donor.load_state_dict(sd2, strict=True)
+    gd_src = cindm_amd.GaussianDiffusion(donor, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                         loss_type="l2", objective="pred_noise")
+    torch.save({"step": 11, "model": {k: v.detach().cpu() for k, v in gd_src.state_dict().items()}, "version": "1.0"}, str(tmp_path / "model-3.pt"))
+    m2 = cindm_amd.Unet(dim=64, dim_mults=(1, 2), channels=21, image_size=64)
+    gd = cindm_amd.GaussianDiffusion(m2, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000,
+                                     loss_type="l2", objective="pred_noise")
+    tr = cindm_amd.Trainer(gd, None, results_folder=str(tmp_path), train_batch_size=1).load(3)
+    assert tr.step == 11
+    gd = gd.to(device)
+    from test_gpu_parity_2d import _tape as tape2d
+    t2 = tape2d(91, 1, 2, 21, 64, 64, 1000)
+    out2 = gd.sample(batch_size=1, num_boundaries=2, noise=t2, t_stop=996)
+    od2 = O.Diffusion2D(sd2, image_size=64, frames=6)
+    steps = {t: (t2.step_state[t], t2.step_boundary[t]) for t in range(1, 1000)}
+    ref2 = O.p_sample_loop_2d(od2, (1, 2, 21, 64, 64), t2.init, steps, t_stop=996)
+    assert out2.is_cuda and rel(out2, ref2) < TOL_CHAIN

@@ -102,12 +102,51 @@ def test_input_magnitude_vs_oracle(device, amp):
 
 
 def test_inputs_beyond_fp16_range_are_loud(device):
-    """|x| > 65504 cannot be represented in the hi plane: the output is inf / nan (never a silently wrong finite value)."""
+    """|x| > 65504 cannot be represented in the hi plane: on the split-fp16 kernels the output is inf / nan (never a silently wrong
+    finite value) -- what an unchecked forward (check=False: captures, asynchronous pipelines) hands back."""
     sd = _scaled()
     m = _model(device, sd)
     x = torch.full((1, 24, 8), 1.0e5)
-    out = m(x.to(device), torch.full((1,), 77, device=device))
-    assert not bool(torch.isfinite(out).all())
+    out = m(x.to(device), torch.full((1,), 77, device=device), check=False)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(out).all()) and m.get_option("range_fallback") == 0
+
+
+def test_range_rule_on_the_callers_first_batch(device):
+    """Round 6: the calibration forward at finalize sees ONE synthetic unit-scale batch.  The first CHECKED result after a weight
+    synchronisation is inspected as well: data that leaves fp16's range there (here: inputs of 1e6, which pass the weight window and
+    the calibration) repacks the handle for the exact fp32-MFMA kernels and repeats the work -- forward and sampling chain alike;
+    `range_fallback` reads 3, `last_chain_info()` carries it, later calls stay on fp32 and agree with the fp32 oracle."""
+    import warnings
+    sd = _scaled()
+    x = torch.randn((3, 24, 8), generator=torch.Generator().manual_seed(5)) * 1.0e6      # (the un-normalised residual stream then sits far beyond 65504)
+    t = 77
+    ref = O.unet1d_forward(sd, x, torch.full((3,), t))
+    m = _model(device, sd)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        out = m(x.to(device), torch.full((3,), t, device=device))
+    assert bool(torch.isfinite(out).all()) and rel(out, ref) < TOL_FWD
+    assert m.get_option("range_fallback") == 3 and any("fp32-MFMA" in str(w.message) for w in wl)
+    # benign data first: nothing happens, and the check is not repeated (one reduction per weight synchronisation)
+    m2 = _model(device, sd)
+    xs = torch.randn((3, 24, 8), generator=torch.Generator().manual_seed(6))
+    assert rel(m2(xs.to(device), torch.full((3,), t, device=device)), O.unet1d_forward(sd, xs, torch.full((3,), t))) < TOL_FWD
+    assert m2.get_option("range_fallback") == 0 and not m2.range_guard_pending()
+    # a chain: x_T of 1e6 (initialization_mode 1 hands the caller's image in), explicit noise -> the first chain escalates and is repeated
+    m3 = _model(device, sd)
+    d = cindm_amd.GaussianDiffusion1D(m3, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000, loss_type="l1").to(device)
+    tape = O.NoiseTape.make(11, (2, 24, 8), 1000)
+    big = torch.randn((2, 24, 8), generator=torch.Generator().manual_seed(12)) * 1.0e6
+    od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
+    want = O.p_sample_loop(od, (2, 24, 8), None, tape, n_composed=0, compose_n_bodies=2, initialization_mode=1, initialization_img=big, t_stop=995)
+    gtape = cindm_amd.NoiseTape(tape.init, tape.step, None, None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = d.p_sample_loop((2, 24, 8), None, n_composed=0, compose_n_bodies=2, initialization_mode=1, initialization_img=big.to(device),
+                              noise=gtape, t_stop=995)
+    assert bool(torch.isfinite(got).all()) and rel(got, want) < 1e-4
+    assert m3.get_option("range_fallback") == 3 and d.last_chain_info()["range_fallback"] == 3
 
 
 @pytest.mark.parametrize("scale,fallback", [(4.0, (0,)), (1.0e-4, (1,))])

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     # the version the header declares, the library reports and the binding was written for are one number
     hv = int(re.search(r"#define\s+CINDM_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "cindm_hip.h")).read()).group(1))
-    assert L.cindm_abi_version() == hv == _ffi.ABI_VERSION == 3
+    assert L.cindm_abi_version() == hv == _ffi.ABI_VERSION == 4
 
 
 def test_descriptor_structs_match_header_layout():
@@ -185,6 +185,27 @@ def test_package_never_imports_the_reference():
             src = open(os.path.join(pkg, fn)).read()
             assert not pat.search(src), fn
             assert "/root/reference" not in src, fn
+
+
+def test_no_allocation_outside_create_finalize_destroy():
+    """SURVEY section 8b / include/cindm_hip.h: the caller owns every buffer and the workspace -- the library allocates device
+    memory only in *_create, *_finalize (the packed weights, the time tables, the calibration forward) and the profiling switch,
+    and frees in *_destroy.  In particular the sampling entries (cindm_ddpm1d_sample*, cindm_ddpm2d_sample_force) keep their x_T
+    snapshot and the DDIM tables in the caller's workspace (round 5's review: run_chain_with_recovery called hipMalloc)."""
+    allowed = re.compile(r"(_create|_destroy|_finalize|finalize_pack|_phase_prof_enable)$")
+    csrc = os.path.join(ROOT, "cindm_amd", "csrc")
+    seen = 0
+    for fn in ("cindm_hip.hip", "unet2d_host.inc", "forceunet_host.inc"):
+        cur = None
+        for i, line in enumerate(open(os.path.join(csrc, fn)).read().split("\n"), 1):
+            if line and not line[0].isspace() and line[0] not in "}#/" and "(" in line:
+                m = re.search(r"([A-Za-z_0-9:~]+)\s*\(", line)
+                if m:
+                    cur = m.group(1)
+            if re.search(r"\bhip(Malloc|Free|MallocAsync|FreeAsync|HostMalloc)\s*\(", line):
+                seen += 1
+                assert cur and allowed.search(cur), f"{fn}:{i}: device allocation inside {cur}"
+    assert seen > 10
 
 
 def test_product_does_not_import_oracle():

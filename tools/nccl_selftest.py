@@ -23,8 +23,11 @@ same = all(torch.equal(mine[r], out[r]) for r in range(world))
 # the sharded-gather helper on a ragged split goes through the same entry when world > 1
 total = 5 * world - (1 if world > 1 else 0)
 lo, hi = cdist.shard_bounds(total, rank, world)
-g = cdist.all_gather_designs(x[:hi - lo].contiguous(), total)
+g = cdist.all_gather_designs(x[:hi - lo].contiguous(), total, use_library=True)      # the C entry (opt-in), ragged shards padded
+g2 = cdist.all_gather_designs(x[:hi - lo].contiguous(), total)                        # the default: torch.distributed over RCCL
+same = same and torch.equal(g, g2)
 print("rccl ok", same, float(t), tuple(mine.shape), tuple(g.shape), comm.world, flush=True)
 assert same and float(t) == 1.5 + world - 1 and tuple(mine.shape) == (world, 5, 24, 8) and g.shape[0] == total
+comm.close()
 cdist.close_comms()
 dist.destroy_process_group()

@@ -23,7 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-assert os.environ.get("CINDM_LIB_VARIANT") == "prof", "run with CINDM_LIB_VARIANT=prof (the production library has no phase clocks)"
+assert os.environ.get("CINDM_LIB_VARIANT") in ("prof", "abl1", "abl2", "abl3"), "run with CINDM_LIB_VARIANT=prof (the production library has no phase clocks)"
 import bench                                 # noqa: E402
 from cindm_amd import _ffi                   # noqa: E402
 
@@ -103,6 +103,23 @@ def table(names, rec, out):
             msum += float(np.median(d)); csum += cm if cm == cm else 0.0
             prev_i = i
         out.write(f"    {'sum of phases (workgroup lifetime)':46s} {msum:8.2f} {'':8s} {csum:8.2f}\n")
+        if os.environ.get("PHASE_SPLIT_NT") and kind_of(name) == "dconv2":
+            # n-tiles 0-7 have their fragments warmed by the predecessor launch (kernels.h Pf: two regions), 8-15 do not
+            NT = 4 * int(name.split("<")[1].split(">")[0].split(",")[-1])
+            wg_ids = np.nonzero(wg_used)[0]
+            for lab, sel in (("n-tiles 0-7", (wg_ids % NT) < 8), ("n-tiles 8-15", (wg_ids % NT) >= 8)):
+                if not sel.any():
+                    continue
+                parts = []
+                prev_i = 0
+                for i in range(1, NST):
+                    cur, prv = r[sel][:, :, i], r[sel][:, :, prev_i]
+                    ok = u[sel] & (cur != 0) & (prv != 0)
+                    if not ok.any():
+                        continue
+                    parts.append(f"{np.median((cur - prv)[ok]) * TICK_US:.2f}")
+                    prev_i = i
+                out.write(f"    medians, {lab:13s}: " + " ".join(parts) + "\n")
     out.write(f"\nsum over the step's instrumented launches: spans {tot_span:.1f} us + gaps {tot_gap:.1f} us = {tot_span + tot_gap:.1f} us\n")
 
 
@@ -111,9 +128,12 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    B = 128 if wl == "cfg4" else 256
+    B = bench.default_batch(wl)
     w = bench.build_1d(wl, B, dev)
     d, model = w["diffusion"], w["pair"]
+    for kv in filter(None, os.environ.get("PHASE_OPTS", "").split(",")):      # e.g. PHASE_OPTS=tune=4,l2_prefetch=0
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     if wl == "cfg4":
         run = lambda n: d.sample_compose_multibodies(w["cond"], n, 0, 4, seed=1)
     else:

@@ -13,7 +13,7 @@ import bench                       # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-B = 128 if wl == "cfg4" else 256
+B = bench.default_batch(wl)
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 w = bench.build_1d(wl, B, dev)
