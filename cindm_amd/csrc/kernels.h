@@ -68,6 +68,12 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
     return v;
 }
 
+// x_start.clamp_(-1, 1) of the posterior (model/diffusion_1d.py:1038-1041, model/diffusion_2d.py:763): torch.clamp hands a NaN
+// through, fminf / fmaxf return their OTHER operand -- a U-Net output that left fp16's range inside a chain (NaN) would become a
+// silent x_start of 1 and the range rule's "never a silently wrong finite value" would not hold for chains (found in round 6 by the
+// range test on a chain).
+__device__ __forceinline__ float clamp_pm1(float v) { const float c = fminf(fmaxf(v, -1.f), 1.f); return v != v ? v : c; }
+
 // The step's timestep: from device memory inside the sample loops (t_ptr, graph-replayable), an immediate otherwise.  The
 // immediate goes through an opaque SGPR move so that it is a VALUE, not a kernarg LOCATION: hipcc otherwise folds
 // `p ? *p : a.t_imm` into ONE load from a selected address -- a FLAT vector load (one address global, one constant) whose
@@ -2445,7 +2451,7 @@ __device__ __forceinline__ bool plain_step_draws(const ComposeArgs& a, const Ste
 // plain_step_value with the coefficients in hand: operation for operation the same expression
 __device__ __forceinline__ float plain_step_value(const ComposeArgs& a, const StepCoefs& c, int t, float xv, float o, float z) {
     float x0 = (a.objective == 1) ? o : __fsub_rn(__fmul_rn(c.cx, xv), __fmul_rn(c.co, o));
-    if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    if (a.clip) x0 = clamp_pm1(x0);
     if (a.ddim_tab) {       // compose_update_element's DDIM tail (objective pred_noise: eps = o; the host fuses only that objective)
         if (c.tn < 0) return x0;
         return __fadd_rn(__fadd_rn(__fmul_rn(x0, c.san), __fmul_rn(c.cc, o)), __fmul_rn(c.sg, z));
@@ -2459,7 +2465,7 @@ __device__ __forceinline__ float plain_step_value(const ComposeArgs& a, int t, f
     if (a.objective == 0) x0 = __fsub_rn(__fmul_rn(a.sqrt_recip[t], xv), __fmul_rn(a.sqrt_recipm1[t], o));
     else if (a.objective == 1) x0 = o;
     else x0 = __fsub_rn(__fmul_rn(a.sqrt_ac[t], xv), __fmul_rn(a.sqrt_1mac[t], o));
-    if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    if (a.clip) x0 = clamp_pm1(x0);
     float v = __fadd_rn(__fmul_rn(a.coef1[t], x0), __fmul_rn(a.coef2[t], xv));
     if (a.add_noise && t > 0) v += expf(0.5f * a.logvar[t]) * z;
     return v;
@@ -3226,7 +3232,7 @@ __device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
         const float o = a.pair_eps[((size_t)b * Lfull + l) * a.F + f];
         x0 = x0_of(o);
         eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
-        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        if (a.clip) x0 = clamp_pm1(x0);
         mean = post_mean(x0);
     } else if (a.mode == 1 || a.mode == 2 || a.mode == 4) {
         // eps aggregated over senders then windows (model/diffusion_1d.py:994-999, :1457-1458)
@@ -3242,7 +3248,7 @@ __device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
         const float o = (a.mode == 1) ? tot / (float)cover : tot / ((float)cover / (float)a.W);
         x0 = x0_of(o);
         eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
-        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        if (a.clip) x0 = clamp_pm1(x0);
         mean = post_mean(x0);
     } else if (a.mode == 3) {
         // p_mean_variance per (window, pair), then average mean and x0 (:1436-1452)
@@ -3255,7 +3261,7 @@ __device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
                 if (o == body) continue;
                 const float e = pair_eps_at(kk, o, lw);
                 float x0e = x0_of(e);
-                if (a.clip) x0e = fminf(fmaxf(x0e, -1.f), 1.f);
+                if (a.clip) x0e = clamp_pm1(x0e);
                 sm += post_mean(x0e); sx += x0e; se += e;
             }
             tm += sm / (float)(a.nb - 1); tx += sx / (float)(a.nb - 1); te += se / (float)(a.nb - 1);
@@ -3268,7 +3274,7 @@ __device__ void compose_update_element(const ComposeArgs& a, int64_t i) {
         const float o = s - a.uncond_coef * u;
         x0 = x0_of(o);
         eps = (a.objective == 0) ? o : (ra * xv - x0) / rb;
-        if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        if (a.clip) x0 = clamp_pm1(x0);
         mean = post_mean(x0);
     }
 

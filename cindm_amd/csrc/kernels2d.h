@@ -2916,7 +2916,7 @@ __global__ __launch_bounds__(256) void update2d_kernel(const Update2dArgs a) {
         const float sa = obj == 2 ? a.sqrt_ac[t] : 0.f, sm = obj == 2 ? a.sqrt_1mac[t] : 0.f;
         auto x0_of = [&](float xv, float e) -> float {
             float x0 = obj == 0 ? __fsub_rn(__fmul_rn(ra, xv), __fmul_rn(rb, e)) : obj == 1 ? e : __fsub_rn(__fmul_rn(sa, xv), __fmul_rn(sm, e));
-            if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            if (a.clip) x0 = clamp_pm1(x0);
             return x0;
         };
         const float sigma = (a.add_noise && t > 0) ? expf(0.5f * a.logvar[t]) : 0.f;

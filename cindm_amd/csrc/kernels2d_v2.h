@@ -758,7 +758,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         const bool nok = col < N;                            // N is a multiple of 4 (host)
         // this wave's 32 pixels = 8 blocks of 4 (block b: tile row 2 lw + (b >> 2), columns 4 (b & 3) ..); lane = (channel
         // quad oc4, blocks q and q + 4): four 16-byte LDS reads give 4 channels x 4 pixels, whose transpose is a renaming
-        float* o0 = outp + (((PAIR ? 2 * img : img) * Hout + ty0 + 2 * lw) * Wout + tx0) * ldo + col;
+        const size_t o_off = (size_t)(((PAIR ? 2 * img : img) * Hout + ty0 + 2 * lw) * Wout + tx0) * ldo + col;
         const float* t0 = Tile + (oc4 * 4) * V2LDT + 32 * lw + 4 * q;
         float4 f[2][4];                                      // all eight LDS reads in flight before the first store
 #pragma unroll
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)               // block b = q + 4 jj: row jj, column 4 q + pi
-                    *reinterpret_cast<float4*>(o0 + opix(jj, q, pi) * ldo) = v[4 * jj + pi];
+                    st_out4(outp, o_off + (size_t)opix(jj, q, pi) * ldo, v[4 * jj + pi], dbg == 31);      // dbg2 = 31 (experiment): written through
         }
         if (!stats_out) return;
         // shifted sums about the group's first element of the wave's first pixel
