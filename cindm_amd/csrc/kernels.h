@@ -139,8 +139,9 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 #endif
 
 // PF_REGIONS regions.  (Round 4 tried four -- a dconv2 launch streams two convolutions' weights and an XCD owns two n-tiles of
-// each, so tiles x + 8 are never warmed --: same-box A/B 329.9 us per reverse step with two regions, 332.4 with four.  The extra
-// touches cost more than cold tiles x + 8 do; two it stays.)
+// each --: same-box A/B 329.9 us per reverse step with two regions, 332.4 with four.  Round 6, with the touches issued late and the
+// outputs written through: conv A's tiles x and x + 8 are the two regions of a dconv2 successor; adding conv B's tiles (touched a
+// whole phase before their use) cost 1.2 us per step again, adding the riding 1x1's changed nothing.  Two it stays.)
 constexpr int PF_REGIONS = 2;
 struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt; };      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
 struct PfRegs { unsigned v[PF_REGIONS][2]; };
@@ -203,6 +204,24 @@ __device__ __forceinline__ void st_out4(uint4* base, size_t off, const uint4& v,
     if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, 0x7ffffff0u, 0x00020000),
                                                    (unsigned)(off * 16), 0, 16);
     else base[off] = v;
+}
+
+// 4 x 4 transpose inside every lane quad: lane j of a quad enters with a[i] = M[j][i] and leaves with a[i] = M[i][j] (two butterfly
+// stages of DPP quad permutes; 4 moves + 8 selects).  Used to turn "lane = column, registers = rows" epilogues into 16-byte row stores.
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {             // lanes (0,1) and (2,3): swap M[even][2m + 1] <-> M[odd][2m]
+        const float send = o1 ? a[2 * m] : a[2 * m + 1];
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+        if (o1) a[2 * m] = got; else a[2 * m + 1] = got;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {             // lanes (0,2) and (1,3): swap M[low][m + 2] <-> M[high][m]
+        const float send = o2 ? a[m] : a[m + 2];
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+        if (o2) a[m] = got; else a[m + 2] = got;
+    }
 }
 
 constexpr int TM = 48;        // tile rows

@@ -978,9 +978,25 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     gn_mish(v, a.xchg_b, gam_b, bet_b, y, std::integral_constant<int, 12>{}, [&]() {});     // 12, 13 = statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += RES ? r2[q] : rs[q];
+    if (a.out_f32 && a.pf.wt) {
+        // fp32 rows as 16-byte write-through stores: the quad of lanes that holds columns 4k .. 4k + 3 of rows rq + 8 q transposes
+        // its 4 x 4 blocks, lane j then owns row q = j (and lanes 0 / 1 rows q = 4 / 5) of those four columns.  (A 4-byte sc1
+        // store is one fabric write each: ~6 x the time per byte of a 16-byte one, MI355X_MICROARCH.md.)
+        float ta[4] = {y[0], y[1], y[2], y[3]}, tb[4] = {y[4], y[5], 0.f, 0.f};
+        quad_transpose4(ta, lane);
+        quad_transpose4(tb, lane);
+        const int j = lane & 3;
+        const size_t c4 = (size_t)(gn & ~3);
+        // (row of q = j: the same formula as grow[], evaluated for this lane's q)
+        auto row_ok = [&](int q, int& g) { const int pos = (S == 16) ? (q >> 1) : q; const int sm = (S == 16) ? rq + 8 * (q & 1) : rq; g = (b0 + min(sm, ns - 1)) * L + pos; return sm < ns; };
+        int g0; const bool ok0 = row_ok(j, g0);
+        if (ok0) st_out4(a.out_f32, (size_t)g0 * a.ldo + c4, make_float4(ta[0], ta[1], ta[2], ta[3]), 1);
+        if (j < 2) { int g1; if (row_ok(4 + j, g1)) st_out4(a.out_f32, (size_t)g1 * a.ldo + c4, make_float4(tb[0], tb[1], tb[2], tb[3]), 1); }
+    } else {
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
-        if (a.out_f32 && sok[q]) st_out(a.out_f32, (size_t)grow[q] * a.ldo + gn, y[q], a.pf.wt);
+        for (int q = 0; q < 6; ++q)
+            if (a.out_f32 && sok[q]) st_out(a.out_f32, (size_t)grow[q] * a.ldo + gn, y[q], 0);
+    }
     if (a.out_planes) {
         __syncthreads();                                          // Tile: the publish above has been read
         planes_to_tile(y);

@@ -1,1 +1,16 @@
-cd /root/repo; timeout 1200 python -m pytest tests/test_gpu_range.py tests/test_gpu_parity.py tests/test_gpu_parity_2d.py -x -q 2>&1 | tail -8
+cd /root/repo; python - <<'PY'
+import torch, cindm_amd
+from cindm_amd.synthetic import synthetic_init_
+dev = torch.device("cuda:0")
+m = synthetic_init_(cindm_amd.TemporalUnet1D(horizon=24, transition_dim=8, cond_dim=False, dim=64, dim_mults=(1, 2, 4, 8), attention=True), seed=0).to(dev)
+d = cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(dev)
+ref = None
+for t in (3, 0):
+    m.set_option("tune", t)
+    for B in (256, 37):
+        x = d.sample(batch_size=B, seed=1, t_stop=960, n_composed=0, compose_n_bodies=2)
+        torch.cuda.synchronize()
+        if t == 3: ref = {**(ref or {}), B: x.clone()}
+        else: print("B", B, "tune 0 bitwise equal to tune 3:", bool(torch.equal(x, ref[B])), flush=True)
+PY
+python tools/ab1d.py tune 3 0 600 cfg2 | grep us/step
