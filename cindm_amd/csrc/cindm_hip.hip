@@ -203,18 +203,13 @@ struct OptDef { const char* key; int def; const char* env; };
 static const OptDef kUnet1dOpts[] = {
     {"mfma_f32", 0, nullptr},          // 1: every product on the exact fp32 MFMA kernels (CINDM_MFMA=f32)
     {"local_gn", 1, "CINDM_LOCAL_GN"}, // producer-side GroupNorm + Mish, block tails folded into launch B
-    {"wide_qkv", 1, "CINDM_WIDE_QKV"}, // shallow-level qkv projections on conv1x1_wide_kernel (three-launch attention path)
     {"attn_site", 1, "CINDM_ATTN_SITE"},   // one launch per attention site
     {"level0", 1, "CINDM_LEVEL0"},     // level kernels (master switch)
     {"level1", 1, "CINDM_LEVEL1"},     // level1_down_kernel: samples per workgroup (0 = off, 1, 2)
     {"ups_last", 1, "CINDM_UPS_LAST"},
     {"ups_tail", 1, "CINDM_UPS_TAIL"},
-    {"h3_resample", 1, "CINDM_H3_RESAMPLE"},   // resampling convolutions on the split-fp16 kernel
-    {"site_pack", 1, "CINDM_SITE_PACK"},   // several samples per attention-site workgroup
     {"attn_head", 1, "CINDM_ATTN_HEAD"},   // deep attention sites with the heads split over workgroups (attn1d_head_kernel)
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
-    {"dconv_pair", 1, "CINDM_DCONV_PAIR"},   // ... including C_out = 512 (GroupNorm halves exchanged between workgroup pairs)
-    {"level_occ2", 3, nullptr},        // above 320 rows: level0_down (bit 0) / level1_down (bit 1) / ups_last (bit 2) / ups_tail128 (bit 3) capped at 256 registers, two workgroups per CU
     {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled: 0 never, 1 above 320 rows, 2 always
     {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
     {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
@@ -229,7 +224,7 @@ static const OptDef kUnet1dOpts[] = {
     {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
-    {"dbg", 0, "CINDM_DBG"}, {"dbg3", 0, "CINDM_DBG3"}, {"dbg4", 0, "CINDM_DBG4"},   // timing ablations (wrong results)
+    {"dbg", 0, "CINDM_DBG"},           // timing ablations / forced time-outs (wrong results)
 };
 static void unet1d_default_options(cindm_unet1d* h) {
     for (const auto& o : kUnet1dOpts) {
@@ -927,7 +922,7 @@ static bool dconv_applicable(cindm_unet1d* h, const std::string& p, const Ten& x
     if (!h->O("dconv") || !h->use_h3 || !h->use_local_gn) return false;
     const int L = x0.L, gw = cout / 8;
     if ((L != 3 && L != 6) || cout % 32 || (gw != 16 && gw != 32 && gw != 64)) return false;
-    if (gw == 64 && (!h->O("dconv_pair") || (cout / 32) % 2 || h->NX())) return false;
+    if (gw == 64 && ((cout / 32) % 2 || h->NX())) return false;
     if (x0.C % 128 || (x1 && (x1->C % 128 || x1->L != L))) return false;
     if (x0.ld != x0.C || (x1 && x1->ld != x1->C)) return false;      // (every tensor that reaches a block has an fp32 copy)
     auto w0 = h->packed.find(p + ".blocks.0.block.0"), w1 = h->packed.find(p + ".blocks.1.block.0");
@@ -1224,11 +1219,11 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
             s.x = x.p; s.ldx = x.ld; s.out = out.p; s.ldo = out.ld; s.g = E.V(p + ".fn.norm.g");
             s.Wqkv = E.W(site->second); s.Wo = E.W(h->packed.at(p + ".fn.fn.to_out#site")); s.bo = E.B(h->packed.at(p + ".fn.fn.to_out"));
             s.L = L; s.Bp = Bp;
-            s.dbg = h->O("dbg3");
+            s.dbg = 0;
             s.ph = site->second.h3 ? E.ph_next("attn1d_site<" + std::to_string(C) + "> " + p) : PhaseBuf{nullptr, 0};
             // samples per workgroup: as many 4-aligned slots as fit one 16-position tile (weights are streamed once
             // per workgroup); CINDM_SITE_PACK=0 keeps one sample per workgroup
-            const int pack = h->O("site_pack");
+            const int pack = 1;
             const int NTsel = (L > 16) ? 2 : 1;
             s.slot = (L > 16) ? 32 : ceil_to(L, 4);
             s.S = (L > 16 || !pack) ? 1 : 16 / s.slot;
@@ -1429,7 +1424,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.ph = E.ph_next("level0_down downs.0");
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
-                    if (L > 16 && E.rows > 320 && (h->O("level_occ2") & 1)) KLAUNCH(E, (level0_down_kernel<2, 2>), dim3((unsigned)E.rows), dim3(256), 0, l);
+                    if (L > 16 && E.rows > 320) KLAUNCH(E, (level0_down_kernel<2, 2>), dim3((unsigned)E.rows), dim3(256), 0, l);
                     else if (L > 16) KLAUNCH(E, level0_down_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
                     else KLAUNCH(E, level0_down_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, l);
                 }
@@ -1471,13 +1466,13 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.Wo = E.W(h->packed.at("downs.1.2.fn.fn.to_out#site")); l.bo = E.B(h->packed.at("downs.1.2.fn.fn.to_out"));
                 l.Wd = E.W(h->packed.at("downs.1.3.conv#lvl")); l.bd = E.B(h->packed.at("downs.1.3.conv"));
                 l.t_ptr = E.t_ptr; l.t_imm = E.t_imm; l.L = L; l.Bp = (int)E.rows;
-                l.dbg = h->O("dbg4");
+                l.dbg = 0;
                 l.ph = E.ph_next("level1_down downs.1");
                 const int S = lvl1 == 1 ? 1 : 2;
                 const dim3 grid((unsigned)((E.rows + S - 1) / S));
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep) {
-                    if (S == 1 && E.rows > 320 && (h->O("level_occ2") & 2)) KLAUNCH(E, (level1_down_kernel<1, 2>), grid, dim3(256), 0, l);
+                    if (S == 1 && E.rows > 320) KLAUNCH(E, (level1_down_kernel<1, 2>), grid, dim3(256), 0, l);
                     else if (S == 1) KLAUNCH(E, level1_down_kernel<1>, grid, dim3(256), 0, l);
                     else KLAUNCH(E, level1_down_kernel<2>, grid, dim3(256), 0, l);
                 }
@@ -1541,8 +1536,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.ph = E.ph_next("ups_last " + p + " + final_conv");
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
-                    if (E.rows > 320 && (h->O("level_occ2") & 4)) KLAUNCH(E, ups_last_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
-                    else KLAUNCH(E, ups_last_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    KLAUNCH(E, ups_last_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
                 E.prof_end();
             }
             if (taps) { E.tap(p + ".0", h1); E.tap(p + ".1", h2); E.tap(p + ".2", h3); E.tap(p + ".3", up); E.tap("final_conv.0.pre", ypre); }
@@ -1582,8 +1576,7 @@ static int emit_forward(Emitter& E, const float* x, float* eps) {
                 l.ph = E.ph_next("ups_tail128 " + p);
                 E.prof_begin(5, 0.0);
                 for (int rep = 0; rep < (E.prof ? Emitter::prof_reps : 1); ++rep)
-                    if (E.rows > 320 && (h->O("level_occ2") & 8)) KLAUNCH(E, ups_tail128_kernel<2>, dim3((unsigned)E.rows), dim3(256), 0, l);
-                    else KLAUNCH(E, ups_tail128_kernel<1>, dim3((unsigned)E.rows), dim3(256), 0, l);
+                    KLAUNCH(E, ups_tail128_kernel, dim3((unsigned)E.rows), dim3(256), 0, l);
                 E.prof_end();
             }
             if (taps) { E.tap(p + ".1", h2); E.tap(p + ".2", h3); }
@@ -1669,10 +1662,10 @@ static int unet1d_finalize_pack(cindm_unet1d* h, void* stream_) {
         }
     }
     h->use_local_gn = h->O("local_gn") != 0;
-    h->use_wide_qkv = h->O("wide_qkv") != 0;
+    h->use_wide_qkv = true;
     h->use_attn_site = h->O("attn_site") != 0;
     h->use_level0 = h->O("level0") != 0;
-    h->use_h3_resample = h->O("h3_resample") != 0;
+    h->use_h3_resample = true;
     h->packed.clear(); h->vec_off.clear(); h->tb_off.clear();
     std::vector<RtbDesc> rtbs;
     int tb_ld = 0;

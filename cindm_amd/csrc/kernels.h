@@ -2505,9 +2505,9 @@ struct UpsLastArgs {
     int fuse_upd; ComposeArgs upd;                       // plain single-model step: x_{t-1} from this kernel's eps rows, in place
 };
 
-// MINB = 2 (above 320 rows, option level_occ2 bit 2): the same code capped at 256 registers so that two workgroups share a CU
-template <int MINB = 1>
-__global__ __launch_bounds__(256, MINB) void ups_last_kernel(const UpsLastArgs a) {
+// (Round 4 also compiled this kernel and ups_tail128_kernel for two workgroups per CU above 320 rows -- 89 / 60 spilled registers, config 3
+// 833 -> 841 / 838 us per step --: removed in round 6; level0_down / level1_down keep their two-workgroup instantiations.)
+__global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     PH_DECL;
     PH(0);        // phase clocks (profiling builds, kernels.h PhaseBuf): mark k follows the k-th workgroup barrier, the last one the final stores
     constexpr int C = 64, CB = 128, CI = 256, NP1 = 16, NP2 = 32, ROWS1 = NP1 + 4, ROWS2 = NP2 + 4;
@@ -2861,9 +2861,7 @@ struct UpsTailArgs {
     Pf pf; PhaseBuf ph;                                 // L2 warm-up for the next launch
 };
 
-// MINB = 2 (above 320 rows, option level_occ2 bit 3): capped at 256 registers, two workgroups per CU
-template <int MINB = 1>
-__global__ __launch_bounds__(256, MINB) void ups_tail128_kernel(const UpsTailArgs a) {
+__global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     PH_DECL;
     PH(0);        // phase clocks (profiling builds, kernels.h PhaseBuf): mark k follows the k-th workgroup barrier, the last one the final stores
     constexpr int C = 128, CI = 256, NP = 16, ROWS = NP + 4;

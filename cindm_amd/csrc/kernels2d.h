@@ -904,154 +904,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem7_h3d_kernel(const Conv2dAr
     }
 }
 
-// conv2d_stem7_h3p_kernel (round 5): conv2d_stem7_h3_kernel as a pipelined loop over pixel tiles with a row-wise store path.
-// The one-tile-per-workgroup form ran 237 us at 128 images against ~150 us of matrix time: (1) its phases follow each other (window
-// loads -> split -> 600 MFMAs per wave -> reduce -> stores); (2) its epilogue (conv2d_h3_epilogue) sends every accumulator through LDS
-// as single floats and writes the output with 4-BYTE global stores (16 per thread: a dword store costs ~6 x a dwordx4 store per
-// byte, MI355X_MICROARCH.md).  Here a workgroup owns a contiguous run of tiles; the next tile's window is requested before the
-// products (registers), the waves park their partial tiles channel-major ([32 channels][64 pixels], one ds_write_b128 per
-// accumulator), and every thread adds the two k-group partials and writes FOUR float4 pixel rows (4 channels x 4 pixels from four
-// 16-byte LDS reads per partial: the transpose is a renaming).  Same products in the same order per tile as the kernel it replaces
-// (bit-identical).  No statistics / epilogue operands (the stem has none); Cout = 64.
-__global__ __launch_bounds__(256, 2) void conv2d_stem7_h3p_kernel(const Conv2dArgs a) {
-    constexpr int SW = 22, SH = 10, R = SW * SH, PITCH = 80, PLANE = R * PITCH, NP = (R * 8 + 255) / 256, TLD = T2M + 4;
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2 * PLANE];
-    __shared__ __attribute__((aligned(16))) float Tw[4][32 * TLD];           // per wave: [channel of its column half][pixel]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int kg = w & 1, nh = w >> 1;
-    const int ntl = a.NI * a.tpi;
-    const int t_lo = (int)(((long long)blockIdx.x * ntl) / gridDim.x), t_hi = (int)(((long long)(blockIdx.x + 1) * ntl) / gridDim.x);
-    if (t_lo >= t_hi) return;
-    const int HWi = a.Hin * a.Win;
-    const float* src = a.src[0].p;
-    const int ld = a.src[0].ld;
-    const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + tid;
-    half8 bs[2][2][2];
-    auto load_b = [&](int i, half8 (&b)[2][2]) {
-        const uint4* wp = wbase + (size_t)i * 4 * 256;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b[q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
-    };
-    float4 sv[NP];
-    unsigned okbits = 0;
-    auto tile_xy = [&](int mt, int& img, int& ty0, int& tx0) {
-        img = mt / a.tpi;
-        const int ti = mt - img * a.tpi, tyi = ti / a.tiles_x;
-        ty0 = tyi * T2Y; tx0 = (ti - tyi * a.tiles_x) * T2X;
-    };
-    auto load_win = [&](int mt) {
-        int img, ty0, tx0;
-        tile_xy(mt, img, ty0, tx0);
-        okbits = 0;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int i = tid + 256 * p;
-            const int r = i >> 3, c4 = i & 7;
-            const int hy = r / SW, hx = r - hy * SW;
-            const int y = ty0 - 3 + hy, x = tx0 - 3 + hx;
-            const bool ok = (r < R) && (c4 * 4 < ld) && (y >= 0) && (y < a.Hin) && (x >= 0) && (x < a.Win);
-            okbits |= ok ? (1u << p) : 0u;
-            const size_t off = ok ? ((size_t)img * HWi + (size_t)y * a.Win + x) * ld + c4 * 4 : (size_t)img * HWi * ld;
-            sv[p] = *reinterpret_cast<const float4*>(src + off);
-        }
-    };
-    auto split_win = [&]() {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int i = tid + 256 * p;
-            const int r = i >> 3, c4 = i & 7;
-            const float4 v = ((okbits >> p) & 1u) ? sv[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-            half4v hi, lo;
-            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-            lo[0] = (_Float16)((v.x - (float)hi[0]) * H3_SCALE); lo[1] = (_Float16)((v.y - (float)hi[1]) * H3_SCALE);
-            lo[2] = (_Float16)((v.z - (float)hi[2]) * H3_SCALE); lo[3] = (_Float16)((v.w - (float)hi[3]) * H3_SCALE);
-            if (r < R) {
-                *reinterpret_cast<half4v*>(planes + r * PITCH + c4 * 8) = hi;
-                *reinterpret_cast<half4v*>(planes + PLANE + r * PITCH + c4 * 8) = lo;
-            }
-        }
-    };
-    const unsigned char* P0 = planes + (lane & 15) * PITCH + (lane >> 4) * 16;
-    const unsigned char* P1 = P0 + PLANE;
-    // store path: thread = (column half h2, channel quad oc4 of that half, pixel quad pq): 4 channels x 4 pixels
-    const int h2 = tid >> 7, oc4 = (tid >> 4) & 7, pq = tid & 15;
-    const int gcol = h2 * 32 + oc4 * 4;
-    const float4 bias = (a.bias && gcol < a.N) ? *reinterpret_cast<const float4*>(a.bias + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-    load_win(t_lo);
-    for (int mt = t_lo; mt < t_hi; ++mt) {
-        int img, ty0, tx0;
-        tile_xy(mt, img, ty0, tx0);
-        split_win();
-        load_b(0, bs[0]);
-        __syncthreads();                                      // planes of tile mt complete; Tw of tile mt - 1 consumed
-        if (mt + 1 < t_hi) load_win(mt + 1);                  // under the products
-        f32x4 accM[4][2], accL[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
-        for (int i = 0; i < STEM3_NI; i += 2) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ii = i + u;
-                if (ii < STEM3_NI) {
-                    load_b(min(ii + 1, STEM3_NI - 1), bs[(u + 1) & 1]);
-                    const int tap = min(2 * ii + kg, 48);                 // wave-uniform; the pad slot carries zero weights
-                    const int dy = tap / 7, dx = tap - dy * 7;
-                    const int o = (dy * SW + dx) * PITCH;
-                    half8 ah[4], al[4];
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        ah[mb] = *reinterpret_cast<const half8*>(P0 + o + mb * SW * PITCH);
-                        al[mb] = *reinterpret_cast<const half8*>(P1 + o + mb * SW * PITCH);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) {
-                            accM[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bs[u][nb][0], accM[mb][nb], 0, 0, 0);
-                            accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bs[u][nb][1], accL[mb][nb], 0, 0, 0);
-                            accL[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], bs[u][nb][0], accL[mb][nb], 0, 0, 0);
-                        }
-                }
-            }
-        }
-        // partial tile of this wave, channel-major: accumulator (mb, nb) = channel nb*16 + lr, pixels mb*16 + lq*4 .. +3
-        {
-            float* tw = &Tw[w][0] + (lane & 15) * TLD + (lane >> 4) * 4;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const f32x4 v = accM[mb][nb] + accL[mb][nb] * H3_INV;
-                    *reinterpret_cast<float4*>(tw + nb * 16 * TLD + mb * 16) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-        }
-        __syncthreads();                                      // partial tiles complete (and every wave is done with the planes)
-        {
-            const float* t0 = &Tw[2 * h2][0] + (oc4 * 4) * TLD + pq * 4;      // k-group 0 of this column half; + 32 * TLD: k-group 1
-            float4 f[4];
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {
-                const float4 p0 = *reinterpret_cast<const float4*>(t0 + ci * TLD);
-                const float4 p1 = *reinterpret_cast<const float4*>(t0 + 32 * TLD + ci * TLD);
-                f[ci] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
-            }
-            if (gcol < a.N) {
-                const size_t img_base = (size_t)img * a.Hout * a.Wout;
-                const int r0 = pq * 4;                        // the quad's first pixel: tile row r0 >> 4, columns (r0 & 15) .. + 3
-                float* o = a.out + (img_base + (size_t)(ty0 + (r0 >> 4)) * a.Wout + tx0 + (r0 & 15)) * a.ldo + gcol;
-                *reinterpret_cast<float4*>(o) = make_float4(f[0].x + bias.x, f[1].x + bias.y, f[2].x + bias.z, f[3].x + bias.w);
-                *reinterpret_cast<float4*>(o + a.ldo) = make_float4(f[0].y + bias.x, f[1].y + bias.y, f[2].y + bias.z, f[3].y + bias.w);
-                *reinterpret_cast<float4*>(o + 2 * a.ldo) = make_float4(f[0].z + bias.x, f[1].z + bias.y, f[2].z + bias.z, f[3].z + bias.w);
-                *reinterpret_cast<float4*>(o + 3 * a.ldo) = make_float4(f[0].w + bias.x, f[1].w + bias.y, f[2].w + bias.z, f[3].w + bias.w);
-            }
-        }
-    }
-}
-
 // 7x7 stem (init_conv, :303): input = the padded state (CP = 24 channels, 21 real).  Halo tile 10 x 22 pixels x 24
 // channels staged once; K = 49 taps x 6 channel-quads = 294 k-steps (padded to 320), k-step 4i + w belongs to wave w,
 // so no MFMA is spent on padding channels beyond 24.  8 k-steps per B stage, 10 stages.
@@ -1576,10 +1428,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_tail_h3_kernel(const Conv2dArg
 // conv1x1_tail_h3_kernel (bit-identical output).  e_y required, no residual / LayerNorm-out operand.
 // NW = waves per workgroup = output channels / 16: 4 (64 channels, two workgroups per CU) or 8 (128 channels: the 32 x 32 level's
 // 192 -> 128 blocks; one 512-thread workgroup per CU, every wave keeps the weights of its own 16 channels).
-// EPI: 0 = the tail proper (+ SiLU(GN(y1)), e_y required); 1 = + residual (a.res: the bottleneck attention's to_out); 2 = bias only (its
-// to_qkv).  blockIdx.y selects a group of 16 NW output channels (to_qkv: 384 = 3 groups of 128).
-template <int KT, int NW, int EPI = 0>
-__global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
+// (Round 5 also ran the bottleneck attention's two projections on this loop -- epilogue variants "+ residual" and "bias only" --: 54.7
+// instead of 50.2 us per launch, one 512-thread workgroup per CU loses against short workgroups there; removed in round 6.)
+template <int KT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv1x1_tail_h3p_kernel(const Conv2dArgs a) {
     constexpr int KS = KT / 32, PITCH = KT * 2 + 16, F4 = KT / 4, NTH = 64 * NW, NPASS = (64 * F4) / NTH;
     static_assert((64 * F4) % NTH == 0, "whole passes");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2][64 * PITCH];
@@ -1605,12 +1457,8 @@ __global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x
     const bool nok = col < a.N;
     const int colc = nok ? col : 0;
     const float4 bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 eg = make_float4(1.f, 1.f, 1.f, 1.f), eb = make_float4(0.f, 0.f, 0.f, 0.f);
-    int g = 0;
-    if constexpr (EPI == 0) {
-        eg = *reinterpret_cast<const float4*>(a.e_gamma + colc); eb = *reinterpret_cast<const float4*>(a.e_beta + colc);
-        g = colc >> (31 - __builtin_clz(a.e_gw));
-    }
+    const float4 eg = *reinterpret_cast<const float4*>(a.e_gamma + colc), eb = *reinterpret_cast<const float4*>(a.e_beta + colc);
+    const int g = colc >> (31 - __builtin_clz(a.e_gw));
     float4 sv[NPASS];
     auto load_x = [&](int t) {
         const size_t row0 = (size_t)t * 64;
@@ -1647,7 +1495,7 @@ __global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x
     for (int t = t_lo; t < t_hi; ++t) {
         const size_t row0 = (size_t)t * 64;
         const int img = (int)(row0 / HWo);
-        if (EPI == 0 && img != img_have && w == 1) {             // (wave-uniform: img is a function of t)
+        if (img != img_have && w == 1) {             // (wave-uniform: img is a function of t)
             float m, r;
             merge_stats8(a.e_stats + (size_t)img * 8 * a.e_P * 2, a.e_P, a.e_cnt, lane, m, r);
             if ((lane & 7) == 0) { tabE[2 * (lane >> 3)] = m; tabE[2 * (lane >> 3) + 1] = r; }
@@ -1657,13 +1505,8 @@ __global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x
         __syncthreads();
         if (t + 1 < t_hi) load_x(t + 1);                         // the next tile's rows, then this tile's y1 rows: both under the products
         float4 yv[4];
-        if constexpr (EPI == 0) {
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + (row0 + pb * 16 + lq) * a.e_ld + colc);
-        } else if constexpr (EPI == 1) {
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.res + (row0 + pb * 16 + lq) * a.ldres + colc);
-        }
+        for (int pb = 0; pb < 4; ++pb) yv[pb] = *reinterpret_cast<const float4*>(a.e_y + (row0 + pb * 16 + lq) * a.e_ld + colc);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 accM[4], accL[4];
 #pragma unroll
@@ -1678,7 +1521,7 @@ __global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][0], xl, accL[pb], 0, 0, 0);
                 accL[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ks][1], xh, accL[pb], 0, 0, 0);
             }
-        const float em = EPI == 0 ? tabE[2 * g] : 0.f, er = EPI == 0 ? tabE[2 * g + 1] : 1.f;
+        const float em = tabE[2 * g], er = tabE[2 * g + 1];
         __builtin_amdgcn_sched_barrier(0);
         if (nok) {
 #pragma unroll
@@ -1686,13 +1529,9 @@ __global__ __launch_bounds__(64 * NW, (EPI != 0 && NW == 8) ? 4 : 2) void conv1x
                 const size_t prow = row0 + pb * 16 + lq;
                 float4 v = make_float4((accM[pb][0] + accL[pb][0] * H3_INV) + bias.x, (accM[pb][1] + accL[pb][1] * H3_INV) + bias.y,
                                        (accM[pb][2] + accL[pb][2] * H3_INV) + bias.z, (accM[pb][3] + accL[pb][3] * H3_INV) + bias.w);
-                if constexpr (EPI == 0) {
-                    const float4 y = yv[pb];
-                    v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
-                    v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
-                } else if constexpr (EPI == 1) {
-                    v.x += yv[pb].x; v.y += yv[pb].y; v.z += yv[pb].z; v.w += yv[pb].w;
-                }
+                const float4 y = yv[pb];
+                v.x += silu_f((y.x - em) * er * eg.x + eb.x); v.y += silu_f((y.y - em) * er * eg.y + eb.y);
+                v.z += silu_f((y.z - em) * er * eg.z + eb.z); v.w += silu_f((y.w - em) * er * eg.w + eb.w);
                 *reinterpret_cast<float4*>(a.out + prow * a.ldo + col) = v;
             }
         }

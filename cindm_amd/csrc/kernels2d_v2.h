@@ -75,12 +75,11 @@ __device__ unsigned long long g_ws_prof[WSP_CAT][2][WSP_NPH];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// VAR: how the matrix waves divide an item.  3 = as 1 with the TRANSPOSED product and the store path (bias, float4 rows, GroupNorm
-// partials) inside the matrix waves: no output tile in LDS, no write_tile in the memory waves, ONE barrier per item (plain and
-// GroupNorm sources of the 3x3 / upsampled kinds; the input-gradient mode and the paired kind keep the tile path).  0 = round 2's k-groups (wave = k half x column half, reduction through LDS per tile);
-// 1 = no split, v_mfma_f32_16x16x32_f16 (wave = pixel half x column half); 2 = no split on v_mfma_f32_32x32x16_f16: half as many
-// matrix instructions per item (216 x 32 cycles instead of 432 x 16-17: the 32 x 32 shape reaches the pipe's full rate,
-// MI355X_MICROARCH.md, and every MFMA boundary is a place where the co-resident memory wave's VALU issue can delay the next one).
+// VAR: how the matrix waves divide an item.  0 = round 2's k-groups (wave = k half x column half, reduction through LDS per tile);
+// 1 = no split (wave = pixel half x column half, all 64 channels of the chunk).  Round 5 also measured the same on
+// v_mfma_f32_32x32x16_f16 (half as many matrix instructions per item: 5.35 -> 5.45 ms per step) and the transposed product with the
+// store path inside the matrix waves (no LDS tile, one barrier per item: 6.4 -> 7.4 us per item) -- both slower, both removed in
+// round 6 (DESIGN.md section 4.5b keeps the measurements).
 template <int KIND, int MODE, int VAR = 0>
 __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     constexpr bool KSPLIT = VAR == 0;
@@ -131,120 +130,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
     const int tpi_sh = (a.tpi & (a.tpi - 1)) == 0 ? 31 - __builtin_clz(a.tpi) : -1;
     const int tx_sh = (a.tiles_x & (a.tiles_x - 1)) == 0 ? 31 - __builtin_clz(a.tiles_x) : -1;
 
-    if (role == 0 && VAR == 2) {
-        // =========================== matrix waves, K not split, 32 x 32 x 16 MFMAs (round 5) =======================
-        // wave = (pixel half ph: tile rows 4 ph .. 4 ph + 3 = two 32-pixel blocks, column half nh: 32 channels).  A fragment of a
-        // 32-pixel block: lane l = pixel (tile row (l >> 4) & 1, x = l & 15), channels 16 ks + 8 (l >> 5) + e; B fragment: lane l =
-        // column l & 31, the same k -- read from the k-group pack of the other variants at a per-lane offset (the 16 bytes of
-        // (k half kg = ks >> 1, column block (l >> 4) & 1, k quarter 2 (ks & 1) + (l >> 5), column l & 15)), so no second weight layout.
-        // Accumulator i of a 32 x 32 tile: column l & 31, row 8 (i >> 2) + 4 (l >> 5) + (i & 3): four consecutive pixels per quad.
-        const int ph = lw & 1, nh = lw >> 1;
-        if (a.dbg == 11 || (a.dbg != 10 && a.dbg != 12 && MODE != SRC2_GN_SS_SILU)) __builtin_amdgcn_s_setprio(3);
-        f32x16 accM[2], accL[2];
-        half8 breg[3][4][2];                                  // [ring slot][k-step of 16][plane]
-        const int l15 = lane & 15, lb4 = (lane >> 4) & 1, l5 = lane >> 5;
-        // uint4 index inside a (n-tile, chunk, tap) block of 4 q-blocks x 256 threads: q = 2 * column block + plane
-        const uint4* wbase = reinterpret_cast<const uint4*>(a.W) + (2 * lb4) * 256 + (2 * nh) * 64 + l5 * 16 + l15;
-        auto load_b = [&](int nt, int ch, int tap, int slot_) {
-            const uint4* wp = wbase + ((size_t)(nt * nch + ch) * 9 + tap) * 4 * 256;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) breg[slot_][ks][pl] = __builtin_bit_cast(half8, wp[pl * 256 + (ks >> 1) * 64 + (ks & 1) * 32]);
-        };
-        const int foff = (lb4 * SW + l15 + (PAIR && l15 >= 8 ? 2 : 0)) * V2PITCH + l5 * 16;
-        // 36 steps (tap, k-step of 16): both 32-pixel blocks per step, fragments of step s + 2 read while step s multiplies
-        auto compute = [&](const unsigned char* P0, int nt, int ch, int nt2, int ch2, auto FIRST_) {
-            constexpr bool FIRST = decltype(FIRST_)::value;
-            const unsigned char* P1 = P0 + PLANE;
-            half8 fh[3][2], fl[3][2];
-            auto read_frag = [&](int s, int slot_) {
-                const int tap = s >> 2, ks = s & 3;
-                const int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb) {
-                    const int o = ((4 * ph + 2 * pb + dy) * SW + dx) * V2PITCH + ks * 32;
-                    fh[slot_][pb] = *reinterpret_cast<const half8*>(P0 + o);
-                    fl[slot_][pb] = *reinterpret_cast<const half8*>(P1 + o);
-                }
-            };
-            read_frag(0, 0); read_frag(1, 1);
-#pragma unroll
-            for (int s = 0; s < 36; ++s) {
-                const int tap = s >> 2, ks = s & 3, bs = tap % 3, fs = s % 3;
-                if (s + 2 < 36) read_frag(s + 2, (s + 2) % 3);
-                __builtin_amdgcn_sched_barrier(0);
-                const bool z = FIRST && s == 0;
-                f32x16 zero;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-                accM[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][0], breg[bs][ks][0], z ? zero : accM[0], 0, 0, 0);
-                accM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][1], breg[bs][ks][0], z ? zero : accM[1], 0, 0, 0);
-                accL[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][0], breg[bs][ks][1], z ? zero : accL[0], 0, 0, 0);
-                accL[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[fs][1], breg[bs][ks][1], z ? zero : accL[1], 0, 0, 0);
-                accL[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[fs][0], breg[bs][ks][0], accL[0], 0, 0, 0);
-                accL[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[fs][1], breg[bs][ks][0], accL[1], 0, 0, 0);
-                if (ks == 3) {                               // this slot's next tap (of this or the next item), two taps ahead
-                    if (tap + 3 < 9) load_b(nt, ch, tap + 3, bs);
-                    else load_b(nt2, ch2, tap + 3 - 9, bs);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
-        stress_delay(a.stress, 100u);
-        __syncthreads();                                     // S0: item 0 is staged
-        WSP_DECL;
-        int k = 0;
-        for (int tl = 0; tl < mine; ++tl)
-            for (int nt = NSPLIT ? nt_of(tl) : 0, nt_end = NSPLIT ? nt + 1 : ntiles; nt < nt_end; ++nt) {
-                const int nt_after = NSPLIT ? (tl + 1 < mine ? nt_of(tl + 1) : 0) : (nt + 1 < ntiles ? nt + 1 : 0);
-                {
-                    const int nt2 = nch > 1 ? nt : nt_after, ch2 = nch > 1 ? 1 : 0;
-                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, 0, nt2, ch2, std::true_type{});
-                    else {
-#pragma unroll
-                        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { accM[pb][i] = 0.f; accL[pb][i] = 0.f; }
-                    }
-                    ++k;
-                    WSP(0); WSP_COUNT();
-                    stress_delay(a.stress, 101u + 8u * (unsigned)k);
-                    __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
-                    WSP(1);
-                }
-                for (int ch = 1; ch < nch; ++ch) {
-                    const int nt2 = ch + 1 < nch ? nt : nt_after, ch2 = ch + 1 < nch ? ch + 1 : 0;
-                    if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
-                    ++k;
-                    WSP(0); WSP_COUNT();
-                    stress_delay(a.stress, 102u + 8u * (unsigned)k);
-                    __syncthreads();                         // S1
-                    WSP(1);
-                }
-                // channel nh * 32 + (lane & 31); pixels 64 ph + 32 pb + 8 j + 4 (lane >> 5) .. + 3: one ds_write_b128 per (pb, j)
-                const int gn = nt * T2N + nh * 32 + (lane & 31);
-                const float bias = (a.bias && gn < a.N) ? a.bias[gn] : 0.f;
-                float* const trow = Tile + (nh * 32 + (lane & 31)) * V2LDT + ph * 64 + l5 * 4;
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float4 v;
-                        v.x = (accM[pb][4 * j + 0] + accL[pb][4 * j + 0] * H3_INV) + bias; v.y = (accM[pb][4 * j + 1] + accL[pb][4 * j + 1] * H3_INV) + bias;
-                        v.z = (accM[pb][4 * j + 2] + accL[pb][4 * j + 2] * H3_INV) + bias; v.w = (accM[pb][4 * j + 3] + accL[pb][4 * j + 3] * H3_INV) + bias;
-                        *reinterpret_cast<float4*>(trow + pb * 32 + j * 8) = v;
-                    }
-                WSP(2);
-                stress_delay(a.stress, 104u + 8u * (unsigned)k);
-                __syncthreads();                             // S3: the finished tile is in LDS
-                WSP(3);
-            }
-        WSP_FLUSH(0);
-        return;
-    }
-    if (role == 0 && (VAR == 1 || VAR == 3)) {
+    if (role == 0 && VAR == 1) {
         // ================================ matrix waves, K not split over the waves (round 5) ======================
         // wave = (pixel half ph: pixel blocks 4 ph .. 4 ph + 3, column half nh), ALL 64 channels of the chunk: the k-group
         // reduction of the variant below (kg = 1 parks its partial tile in LDS, barrier, kg = 0 adds, barrier: 1.75 us of a
@@ -284,10 +170,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const bool z = FIRST && tap == 0 && kh == 0;
-                // VAR 3: the TRANSPOSED product (A = weights, B = pixels): an accumulator's four registers are four consecutive output
-                // CHANNELS of pixel (lane & 15), i.e. one float4 of the channel-last output row -- the matrix waves store the tile
-                // themselves (below) and no tile goes through LDS
-#define WS_MMA(X_, W_, C_) (VAR == 3 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(W_, X_, C_, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(X_, W_, C_, 0, 0, 0))
+#define WS_MMA(X_, W_, C_) __builtin_amdgcn_mfma_f32_16x16x32_f16(X_, W_, C_, 0, 0, 0)
                 accM[mb][0] = WS_MMA(fh[fs], breg[bs][kh][0][0], z ? zero : accM[mb][0]);
                 accL[mb][0] = WS_MMA(fh[fs], breg[bs][kh][0][1], z ? zero : accL[mb][0]);
                 accM[mb][1] = WS_MMA(fh[fs], breg[bs][kh][1][0], z ? zero : accM[mb][1]);
@@ -300,63 +183,6 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     else load_b(nt2, ch2, tap + 3 - 9, bs);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // ---- VAR 3: store path of the matrix waves (bias, float4 row stores, GroupNorm partials), called BEFORE the barrier that ends
-        // the tile's last chunk: in GroupNorm mode the matrix waves would otherwise wait there for the staging
-        auto store_tile3 = [&](int tl, int nt) {
-            const int mt = lo + wj + tl * wpx;
-            const int img = tpi_sh >= 0 ? mt >> tpi_sh : mt / a.tpi, ti = mt - img * a.tpi;
-            const int tyi = tx_sh >= 0 ? ti >> tx_sh : ti / a.tiles_x;
-            const int ty0 = tyi * V2Y, tx0 = (ti - tyi * a.tiles_x) * V2X;
-            const int lr_ = lane & 15, lq_ = lane >> 4;
-            const int gw = a.so_gw;               // 8 or 16 channels per GroupNorm group
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int col = nt * T2N + nh * 32 + nb * 16 + lq_ * 4;
-                const bool nok = col < a.N;               // N is a multiple of 4 (host)
-                // (pointer selected, load unconditional: a load under a branch makes the join wait vmcnt(0) and drains the weight ring)
-                const float4 braw = *reinterpret_cast<const float4*>((a.bias ? a.bias : a.W) + (nok ? col : 0));
-                const float4 b4 = (a.bias && nok) ? braw : make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 v[4];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    v[mb].x = (accM[mb][nb][0] + accL[mb][nb][0] * H3_INV) + b4.x; v[mb].y = (accM[mb][nb][1] + accL[mb][nb][1] * H3_INV) + b4.y;
-                    v[mb].z = (accM[mb][nb][2] + accL[mb][nb][2] * H3_INV) + b4.z; v[mb].w = (accM[mb][nb][3] + accL[mb][nb][3] * H3_INV) + b4.w;
-                    if (nok && a.dbg != 4)
-                        *reinterpret_cast<float4*>(a.out + ((size_t)(img * a.Hout + ty0 + 4 * ph + mb) * a.Wout + tx0 + lr_) * a.ldo + col) = v[mb];
-                }
-                if (a.stats_out) {
-                    // one partial per 32 pixels (tile rows 4 ph + 2 mp, + 1) and group: shifted sums about the group's first
-                    // channel at the pair's first pixel -- lane (lr = 0, first lq of the group), register x of block 2 mp
-#pragma unroll
-                    for (int mp = 0; mp < 2; ++mp) {
-                        const int kb = __builtin_bit_cast(int, v[2 * mp].x);
-                        const float K0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kb, 0));
-                        const float K2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kb, 32));
-                        const float K = (gw == 8 && lq_ >= 2) ? K2 : K0;
-                        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const float4 x = v[2 * mp + u];
-                            const float d0 = x.x - K, d1 = x.y - K, d2 = x.z - K, d3 = x.w - K;
-                            s1 += (d0 + d1) + (d2 + d3);
-                            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                        }
-                        s1 = row16_sum(s1); s2 = row16_sum(s2);            // the 16 pixels of a tile row (lanes lr)
-                        s1 = xsum16(s1); s2 = xsum16(s2);                  // the lq pair: 8 channels
-                        if (gw >= 16) { s1 = xsum32(s1); s2 = xsum32(s2); }        // all four lq: 16 channels
-                        const bool writer = lr_ == 0 && (gw == 8 ? (lq_ & 1) == 0 : lq_ == 0);
-                        if (writer && nok) {
-                            const int g = col >> (31 - __builtin_clz(gw));
-                            const float ine = 1.0f / (float)(32 * gw);             // a power of two
-                            float* o = a.stats_out + (((size_t)img * 8 + g) * (a.tpi * WS_SPT) + ti * WS_SPT + 2 * ph + mp) * 2;
-                            const float mean_d = s1 * ine;
-                            o[0] = K + mean_d;
-                            o[1] = fmaxf(s2 - s1 * mean_d, 0.f);
-                        }
-                    }
-                }
             }
         };
         { const int nt0 = NSPLIT ? nt_of(0) : 0; load_b(nt0, 0, 0, 0); load_b(nt0, 0, 1, 1); load_b(nt0, 0, 2, 2); }
@@ -378,7 +204,6 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     }
                     ++k;
                     WSP(0); WSP_COUNT();
-                    if constexpr (VAR == 3) { if (nch == 1) store_tile3(tl, nt); }
                     stress_delay(a.stress, 101u + 8u * (unsigned)k);
                     __syncthreads();                         // S1: planes consumed; the memory waves are done with Tile
                     WSP(1);
@@ -388,12 +213,10 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
                     if (a.dbg != 3) compute(&smem[k & 1][0] + foff, nt, ch, nt2, ch2, std::false_type{});
                     ++k;
                     WSP(0); WSP_COUNT();
-                    if constexpr (VAR == 3) { if (ch == nch - 1) store_tile3(tl, nt); }
                     stress_delay(a.stress, 102u + 8u * (unsigned)k);
                     __syncthreads();                         // S1
                     WSP(1);
                 }
-                if constexpr (VAR == 3) { WSP(2); continue; }      // (stored before the last chunk's barrier, above)
                 // every wave writes its finished 64 pixels x 32 channels (+ bias) into the channel-major tile: one ds_write_b128
                 // per (pixel block, column block)
                 float* const trow = Tile + (nh * 32 + (lane & 15)) * V2LDT + (lane >> 4) * 4 + ph * 64;
@@ -787,7 +610,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)               // block b = q + 4 jj: row jj, column 4 q + pi
-                    st_out4(outp, o_off + (size_t)opix(jj, q, pi) * ldo, v[4 * jj + pi], dbg == 31);      // dbg2 = 31 (experiment): written through
+                    *reinterpret_cast<float4*>(outp + o_off + (size_t)opix(jj, q, pi) * ldo) = v[4 * jj + pi];
         }
         if (!stats_out) return;
         // shifted sums about the group's first element of the wave's first pixel
@@ -837,7 +660,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         if (stress > 0) stress_delay(stress, 204u + 8u * (unsigned)k);
         if (k + 1 < nitems && dbg != 5 && !staged_skip) { finish_stats(); store_item((k + 1) & 1, k + 1); }
         WSP(0); WSP_COUNT();
-        if (VAR != 3 && pmt >= 0) load_acc(pmt, pnt);
+        if (pmt >= 0) load_acc(pmt, pnt);
         if (k + 2 < nitems && dbg != 5) {
             mtn = c2.mt; chn = c2.ch;
             staged_skip = (mtn == mt && chn == ch);                // its buffer, (k + 2) & 1, holds item k's planes: these
@@ -846,12 +669,12 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         }
         WSP(1);
         if (stress > 0) stress_delay(stress, 201u + 8u * (unsigned)k);
-        if (VAR != 3 && pmt >= 0 && dbg != 5) { write_tile(pmt, pnt, pk); pmt = -1; }
+        if (pmt >= 0 && dbg != 5) { write_tile(pmt, pnt, pk); pmt = -1; }
         WSP(2);
         if (stress > 0) stress_delay(stress, 202u + 8u * (unsigned)k);
         __syncthreads();                                     // S1
         WSP(3);
-        if (VAR != 3 && ch == nch - 1) {                     // (VAR 3: the matrix waves store the tile themselves: one barrier per item)
+        if (ch == nch - 1) {
             if constexpr (KSPLIT) __syncthreads();           // S2
             if (stress > 0) stress_delay(stress, 203u + 8u * (unsigned)k);
             __syncthreads();                                 // S3
@@ -861,7 +684,7 @@ __global__ __launch_bounds__(512) void conv2d_ws_kernel(const Conv2dArgs a) {
         c0 = c1; c1 = c2; cur_next(c2);
         mt = c0.mt; nt = c0.nt; ch = c0.ch;
     }
-    if (VAR != 3 && pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
+    if (pmt >= 0) { load_acc(pmt, pnt); write_tile(pmt, pnt, pk); }
     WSP_FLUSH(1);
 }
 

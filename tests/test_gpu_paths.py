@@ -25,7 +25,6 @@ PATHS_1D = [
     {"mfma_f32": 1},                      # every product on the exact fp32 MFMA kernels
     {"local_gn": 0},                      # consumer-side GroupNorm (A / B / C launches), no fused levels
     {"attn_site": 0},                     # three-launch attention (wide qkv, core, out projection)
-    {"attn_site": 0, "wide_qkv": 0},      # ... with the qkv projection on the K-split GEMM kernel
     {"level0": 0},                        # no level kernels: per-layer launches at every level
     {"level1": 2},                        # two samples per workgroup in level1_down_kernel
     {"level1": 0}, {"ups_last": 0}, {"ups_tail": 0},
@@ -34,10 +33,9 @@ PATHS_1D = [
     {"dconv2": 0},                        # deep-level blocks as two dconv_kernel launches (no in-launch all-gather)
     {"dresample": 0},                     # deep-level resampling convolutions on conv_gemm_h3_kernel<3 | 4>
     {"dconv": 0},                         # deep levels on conv_gemm_h3_kernel
-    {"dconv_pair": 0},                    # dconv only where GroupNorm groups are tile-local (C_out <= 256)
     {"attn_head": 0},                     # deep attention sites on attn1d_site_h3_kernel
     {"attn_head": 2},                     # ... all of them on attn1d_head_kernel
-    {"l2_prefetch": 0}, {"h3_resample": 0}, {"site_pack": 0},
+    {"l2_prefetch": 0},
     {"dconv": 0, "level0": 0, "attn_head": 0},      # the round-1 per-layer path
     {"no_exchange": 1},                   # the exchange-free selection a timed-out chain is re-run on (no in-launch hand-over between workgroups)
     {"tune": 3},                          # round 5's memory-system choices: L2 warm-ups at the head of a launch, outputs left dirty in L2
@@ -82,10 +80,9 @@ def test_unet1d_paths_chain_and_ragged(gold_dir, device, opts):
     assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
 
 
-@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}, {"tail_h3": 0}, {"tail_ew": 0},
-                                  {"ws_nosplit": 0}, {"ws_nosplit": 1}, {"ws_m32": 1, "ws_nosplit": 1}, {"ws_store3": 1, "ws_nosplit": 1}, {"stem_pipe": 1}, {"attn_q128": 0}, {"tail_pipe": 0}, {"la_h16": 0}, {"unshuf_h3": 0}, {"stem_dense": 0}, {"final_h3": 0}, {"tail_pipe": 3}, {"la_wpi": 4, "la_nsplit": 4}],
-                         ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0", "tail_h3_0", "tail_ew_0",
-                              "ws_kgroups", "ws_nosplit_all", "ws_m32", "ws_store3", "stem_pipelined", "attn_q64", "tail_pipe_0", "la_f32_heads", "unshuf_tile", "stem_per_tap", "final_f32", "attn_proj_pipe", "la_4_per_image"])
+@pytest.mark.parametrize("opts", [{"mfma_f32": 1}, {"la_site": 0}, {"conv_ws": 0}, {"ws_alias": 0}, {"tail_h3": 0},
+                                  {"ws_nosplit": 0}, {"ws_nosplit": 1}, {"la_wpi": 4, "la_nsplit": 4}],
+                         ids=["mfma_f32", "la_site0", "conv_ws_0", "ws_alias_0", "tail_h3_0", "ws_kgroups", "ws_nosplit_all", "la_4_per_image"])
 def test_unet2d_paths_golden(gold_dir, device, opts):
     from test_gpu_parity_2d import build_unet2d
     g = np.load(os.path.join(gold_dir, "unet2d_fwd.npz"))
@@ -95,25 +92,6 @@ def test_unet2d_paths_golden(gold_dir, device, opts):
     x = torch.from_numpy(g["x"]).to(device)
     for t in (0, 500, 999):
         assert rel(m(x, torch.full((2,), t, device=device)), g[f"eps_t{t}"]) < TOL_FWD, (opts, t)
-
-
-def test_unet2d_identity_tail_paths_bitwise(device):
-    """The ResnetBlock tail without a res_conv as an element-wise pass (tail_identity_kernel, option tail_ew = 1) writes the same
-    expression in the same order as the 1x1 kernel's identity mode it replaces: outputs and every block tap (incl. the ones whose
-    LayerNorm partials feed an attention) are bit-identical."""
-    from test_gpu_parity_2d import build_unet2d
-    m, _ = build_unet2d(device)
-    x = torch.randn((4, 21, 64, 64), generator=torch.Generator().manual_seed(11)).to(device)
-    t = torch.full((4,), 700, device=device)
-    names = ["downs.0.0", "downs.0.1", "downs.0.2", "downs.1.0", "downs.1.2", "mid_block1", "mid_attn", "mid_block2", "ups.1.1", "ups.1.2", "final_res_block"]
-    res = {}
-    for v in (1, 0):
-        m.set_option("tail_ew", v)
-        y = m(x, t).clone()
-        res[v] = [y] + [m.tap(n, 4).clone() for n in names]
-    m.set_option("tail_ew", 1)
-    for a, b in zip(res[1], res[0]):
-        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("conv_ws", [1, 2, 3], ids=["all", "plain_only", "groupnorm_only"])
@@ -252,25 +230,6 @@ def test_pingpong_step_state(device, unet8, cfg):
     for n in steps:
         assert info[(1, n)] == info[(0, n)] - 1, info
     assert cindm_amd._ffi.lib().cindm_unet1d_status(m._h, None) == 0
-
-
-def test_level_kernels_two_workgroups_per_cu(device, unet8):
-    """Above 320 rows the level kernels are instantiated with 256 registers so that two workgroups share a CU (option
-    level_occ2, one bit per kernel: level0_down, level1_down, ups_last, ups_tail128): the same arithmetic under another
-    register allocation -- the 768-row forward (config 3's row count) is bit-identical under every choice."""
-    m, _ = unet8
-    x = torch.randn((768, 24, 8), generator=torch.Generator().manual_seed(21)).to(device)
-    t = torch.full((768,), 432, device=device)
-    out = {}
-    try:
-        default = m.get_option("level_occ2")
-        for v in (0, 3, 12, 15):
-            m.set_option("level_occ2", v)
-            out[v] = m(x, t).clone()
-    finally:
-        m.set_option("level_occ2", default)
-    for v in (3, 12, 15):
-        assert torch.equal(out[0], out[v]), v
 
 
 def test_workspace_recycling(device, unet8):
@@ -727,17 +686,10 @@ def test_unet2d_round5_paths_agree_at_full_occupancy(device):
     t = torch.full((128,), 400, device=device)
     new = m(x, t).clone()
     assert torch.equal(m(x, t), new)
-    old = {"ws_nosplit": 0, "tail_pipe": 0, "attn_q128": 0, "la_h16": 0, "unshuf_h3": 0, "stem_dense": 0, "final_h3": 0}
-    for k, v in old.items():
-        m.set_option(k, v)
-    ref = m(x, t).clone()
-    assert rel(new, ref) < 5e-6
-    for k in old:                                   # one at a time back to the default
-        m.set_option(k, {"ws_nosplit": 2}.get(k, 1))
-        assert rel(m(x, t), ref) < 5e-6, k
-    m.set_option("ws_nosplit", 1); m.set_option("ws_m32", 1)
-    assert rel(m(x, t), ref) < 5e-6
-    m.set_option("ws_nosplit", 2); m.set_option("ws_m32", 0)
+    for v in (0, 1):                                # round 2's k-groups everywhere / K never split
+        m.set_option("ws_nosplit", v)
+        assert rel(m(x, t), new) < 5e-6, v
+    m.set_option("ws_nosplit", 2)
     assert torch.equal(m(x, t), new)
 
 
