@@ -175,6 +175,9 @@ __device__ __forceinline__ void l2_prefetch_early(const Pf& p, PfRegs& r) {
     for (int k = 0; k < PF_REGIONS; ++k) r.v[k][0] = r.v[k][1] = 0u;
     if (!p.late) l2_prefetch(p, r);
 }
+// The late point of a kernel = right behind its LAST load request where there is one (vector loads return in order: a request that
+// is issued behind the touches waits for them, ~1 - 1.5 us from the Infinity Cache -- placed in front of a LayerNorm gain load they cost
+// level0_down 1.6 us), else behind its last K loop.
 __device__ __forceinline__ void l2_prefetch_late(const Pf& p, PfRegs& r) { if (p.late) l2_prefetch(p, r); }
 __device__ __forceinline__ void l2_prefetch_done(const Pf& p, const PfRegs& r) {
     unsigned x = 0u;
@@ -1861,7 +1864,6 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
         *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl]) = make_float4(h2[nt][0], h2[nt][1], h2[nt][2], h2[nt][3]);
     __syncthreads();
     PH(5);
-    l2_prefetch_late(a.pf, pfr);
     // ---- attention: y = LN(h2) g -> planes P[1] (rows position + 2) ; q, k, v ; core ; out projection + h2 ----
     {
         constexpr int RPP = 16;                                          // 16 lanes per row, 16 rows per pass
@@ -1931,6 +1933,7 @@ __global__ __launch_bounds__(256, MINB) void level0_down_kernel(const Level0Args
     float4 wo4[4][2], wd6[6][2];                             // out projection and Downsample1d fragments: in flight during the core
     lvl_wload<4>(reinterpret_cast<const float4*>(a.Wo) + (size_t)w * (4 * 2 * 64), lane, wo4);
     lvl_wload<6>(Wd4, lane, wd6);
+    l2_prefetch_late(a.pf, pfr);                         // (behind the kernel's LAST load request: vector loads return in order, nothing younger can queue behind the touches)
     f32x4 att[2][NT];
     attn_site_core<NT>(qa, ka, va, att, 1, NP, NP, L, lq, lr);
 #pragma unroll
@@ -2247,7 +2250,6 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
             *reinterpret_cast<float4*>(&H[(nt * 16 + lr) * HP + cl(mt)]) = make_float4(h2[mt][nt][0], h2[mt][nt][1], h2[mt][nt][2], h2[mt][nt][3]);
     __syncthreads();
     PH(6);
-    l2_prefetch_late(a.pf, pfr);
     if (a.dbg == 3) return;
     // ---- attention: LayerNorm -> planes P[1] ----
     {
@@ -2354,6 +2356,7 @@ __global__ __launch_bounds__(256, MINB) void level1_down_kernel(const Level1Args
     f32x4 h3[2][NT];
     lvlm_conv<2, NT, 1, 4, APB, 4>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 16, 1, 0, NP - 1, lane, h3);
     lvlm_prefetch<2, 3, 4, 4>(ring, wbase(a.Wd, 3, 4), lane);
+    l2_prefetch_late(a.pf, pfr);
     add4(h3, 15);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -2775,7 +2778,6 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     }
     __syncthreads();
     PH(8);
-    l2_prefetch_late(a.pf, pfr);
     f32x4 h3[1];
     lvlm_conv<1, 1, 1, 4, APB, 8>(ring, wbase(a.Wo, 1, 4), Aph, Apl, 0, 1, 0, NP1 - 1, lane, v1);
     lvlm_prefetch<1, 4, 2, 8>(ring, wbase(a.Wu, 4, 2), lane);
@@ -2807,6 +2809,7 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     f32x4 y[1][2];
     lvlm_conv<1, 2, 5, 2, PPB, 8>(ring, wbase(a.Wc[4], 5, 2), P[1][0], P[1][1], 16, 1, 0, ROWS2 - 1, lane, y);
     if (w == 0) lvlm_prefetch<1, 1, 2, 8>(ring, reinterpret_cast<const float4*>(a.Wf), lane);
+    l2_prefetch_late(a.pf, pfr);
     add4(y[0][0], pv4(6)); add4(y[0][1], pv4(6));
     if (a.ypre) lvl_store<2>(y[0], a.ypre + (size_t)b * L2 * C, c0, L2, lane, a.pf.wt);
     lvl_gn_mish<2>(y[0], zero4, pv4(7), pv4(8), L2, lane);
@@ -3009,7 +3012,6 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
     }
     __syncthreads();
     PH(5);
-    l2_prefetch_late(a.pf, pfr);
     f32x4 qa[2][1], ka[1][2], va[1][2];
     {
         const float4* Wq4 = reinterpret_cast<const float4*>(a.Wqkv);
@@ -3090,6 +3092,7 @@ __global__ __launch_bounds__(256) void ups_tail128_kernel(const UpsTailArgs a) {
         f32x4 t[1][1];
         lvlm_conv<1, 1, 4, 4, PPB, 8, 1>(ring, wtile(a.Wu, 2 * w, 4, 4), P[0][0], P[0][1], 0, 0, 0, ROWS - 1, lane, t); u[0] = t[0][0];
         lvlm_prefetch<1, 4, 4, 8>(ring, wtile(a.Wu, 2 * w + 1, 4, 4), lane);
+        l2_prefetch_late(a.pf, pfr);
         lvlm_conv<1, 1, 4, 4, PPB, 8, 1>(ring, wtile(a.Wu, 2 * w + 1, 4, 4), P[0][0], P[0][1], 0, 0, 0, ROWS - 1, lane, t); u[1] = t[0][0];
         add4(u[0], pv4(9, 0)); add4(u[1], pv4(9, 1));
         store(u, a.up, L2);

@@ -1390,6 +1390,7 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
             ex[t] = ok ? *reinterpret_cast<const float4*>(a.x + (row0 + sn * L + pn) * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    l2_prefetch_late(a.pf, pfr);                         // (behind the kernel's last load request)
     // ---- core: wave w owns sample w of the group ----
     f32x4 att[2][1];
     attn_site_core_range<1>(qa, ka, va, att, w, min(w + 1, s_here), nend, slot, L, lq, lr);
@@ -1419,7 +1420,6 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
                 __hip_atomic_store(gx + hd * 512 + (et * 16 + lq * 4 + i) * 16 + lr, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PH(6);
-    l2_prefetch_late(a.pf, pfr);
     // gather all four heads' tiles (own head included: one code path) -> att planes [position][128 channels]
     stress_delay(a.stress, 12u);
     {
