@@ -1571,11 +1571,13 @@ __global__ __launch_bounds__(128 * NCT, 2) void conv1x1_h3p_kernel(const Conv2dA
     }
     const bool sok = col < a.ldo;                            // columns N .. ldo - 1 (the pitch's pad): zero weights, zero bias
     const bool nok = col < a.N;                              // (N % 4 == 0, or the pad columns belong to this buffer: the host checks)
-    const float4 braw = *reinterpret_cast<const float4*>((a.bias ? a.bias : a.W) + (nok ? col : 0));
-    float4 bias = (a.bias && nok) ? braw : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col + 1 >= a.N) bias.y = 0.f;
-    if (col + 2 >= a.N) bias.z = 0.f;
-    if (col + 3 >= a.N) bias.w = 0.f;
+    // (element-wise with clamped addresses: N = 21 is not a multiple of 4 and a float4 at column 20 would read three floats past the
+    // bias vector -- inside the weight blob only by the allocation's padding.  Pointer selected, loads unconditional.)
+    const float* bp = a.bias ? a.bias : a.W;
+    const int cmax = a.bias ? a.N - 1 : 0;
+    const float b0 = bp[min(col, cmax)], b1 = bp[min(col + 1, cmax)], b2 = bp[min(col + 2, cmax)], b3 = bp[min(col + 3, cmax)];
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && nok) { bias.x = b0; bias.y = col + 1 < a.N ? b1 : 0.f; bias.z = col + 2 < a.N ? b2 : 0.f; bias.w = col + 3 < a.N ? b3 : 0.f; }
     const float* src = a.src[0].p;
     const int ld = a.src[0].ld, Win = a.Win, HWi = a.Hin * a.Win, Wout = a.Wout;
     float4 sv[NPASS];

@@ -709,6 +709,8 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             if constexpr (PF) {
                 // the next stage's fragments of this tap: requested HERE, behind the tap's last use (pinned: left to itself the
                 // scheduler gathers the requests at the end of the k-step, where the next k-step's first taps find them late)
+                // (round 6 also spread the tap's four requests over its MFMAs -- column block by column block, each fragment requested
+                // behind its own last use --: 321.2 -> 321.9 us per step in alternating processes, not kept)
                 load_b_tap(wb, chn, tap, slot_c);
                 __builtin_amdgcn_sched_barrier(0);
             }
