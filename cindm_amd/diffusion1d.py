@@ -118,11 +118,12 @@ class GaussianDiffusion1D(nn.Module):
         self._h, self._tab_sig = h, sig
         return h
 
-    def _compose_desc(self, mode, n_composed, compose_start_step, window, n_bodies, clip=True):
+    def _compose_desc(self, mode, n_composed, compose_start_step, window, n_bodies, clip=True, uncond_coef=1.4):
         c = _ffi.ComposeDesc()
         c.mode, c.n_windows, c.compose_start_step, c.window = mode, n_composed + 1, compose_start_step, window
         c.n_bodies, c.cond_steps = n_bodies, self.conditioned_steps
-        c.objective, c.clip_denoised, c.uncond_coef = _ffi.OBJECTIVES[self.objective], int(clip), 1.4
+        # (coefficient_unconditioned_grad: 1.4 in the 4-body branch of gradient(), :1900; the 3-body branch subtracts the plain prediction, :1958)
+        c.objective, c.clip_denoised, c.uncond_coef = _ffi.OBJECTIVES[self.objective], int(clip), uncond_coef
         return c
 
     def _desc_for(self, x_shape, compose_mode=None, n_composed=0, compose_start_step=4, single_model_step=-1,
@@ -147,8 +148,8 @@ class GaussianDiffusion1D(nn.Module):
         nb = x_shape[-1] // 4
         if self.model_unconditioned is not None:           # :1003-1004 -> gradient()
             if nb != 4:
-                raise NotImplementedError("gradient(): only the 4-body branch is supported (the reference's 3-body "
-                                          "branch hard-codes batch 20, model/diffusion_1d.py:1958-1960)")
+                raise NotImplementedError("model_predictions calls gradient(x, t, 4) whatever the state's width (model/diffusion_1d.py:1004): "
+                                          "with model_unconditioned set the state must hold 4 bodies (the 3-body branch: gradient(x_t, t, 3))")
             return self._compose_desc(_ffi.COMPOSE_MULTIBODY, 0, 0, self.model.horizon, nb, clip)
         return self._compose_desc(_ffi.COMPOSE_PLAIN, 0, 0, self.model.horizon, nb, clip)
 
@@ -314,13 +315,20 @@ class GaussianDiffusion1D(nn.Module):
 
     @torch.no_grad()
     def gradient(self, x_t, t, n_bodies, scalar_for_gradient=None):
-        """:1857-1926 (4-body branch, t <= 400): pair + unconditioned composition of eps."""
-        if n_bodies != 4 or self.model_unconditioned is None:
-            raise NotImplementedError("gradient(): only n_bodies == 4 with model_unconditioned set is supported")
+        """:1857-1982 (t <= 400): pair + unconditioned composition of eps.  ``n_bodies == 4`` (:1865-1926): six pairs, the single-body
+        predictions weighted by 1.4 -- what ``model_predictions`` calls (:1004).  ``n_bodies == 3`` (:1927-1982, reached only by a direct
+        call): three pairs, weight 1; the reference slices its batched pair output with the literal bounds 0:20 / 20:40 / 40:60, so its
+        branch is defined for a batch of 20 only -- here any batch gives what batch 20 gives there (golden at 20:
+        tests/golden/gradient3_1d_r6.npz)."""
+        if n_bodies not in (3, 4) or self.model_unconditioned is None:
+            raise NotImplementedError("gradient(): n_bodies must be 3 or 4, with model_unconditioned set")
+        if x_t.shape[-1] != 4 * n_bodies:
+            raise ValueError(f"gradient(): x_t has {x_t.shape[-1]} features, n_bodies = {n_bodies} needs {4 * n_bodies}")
         ti = self._t_int(t)
         if ti > 400:
             raise NotImplementedError("gradient(): t > 400 dereferences scalar_for_gradient (unreachable for N <= 401)")
-        desc = self._compose_desc(_ffi.COMPOSE_MULTIBODY, 0, 0, self.model.horizon, 4, clip=False)
+        desc = self._compose_desc(_ffi.COMPOSE_MULTIBODY, 0, 0, self.model.horizon, n_bodies, clip=False,
+                                  uncond_coef=1.4 if n_bodies == 4 else 1.0)
         desc.cond_steps = 0                             # x_t here already is cat(cond, x)
         _, _, eps = self._predict(x_t, None, ti, desc)
         return eps

@@ -306,6 +306,28 @@ def gradient_4body(d, x_t, t):
     return torch.cat([torch.cat([n1, n2], dim=2), torch.cat([n3, n4], dim=2)], dim=2)
 
 
+def gradient_3body(d, x_t, t):
+    """GaussianDiffusion1D.gradient, n_bodies == 3 branch, model/diffusion_1d.py:1927-1982: three pair evaluations (batched on dim 0
+    in the order 12, 13, 23) plus three single-body evaluations weighted by -1 (no 1.4 here, :1958-1960).  The reference slices the
+    batched pair output with the literal bounds 0:20 / 20:40 / 40:60 -- the branch is only defined for a batch of 20, and this
+    restatement keeps the literals.  Reached only by a direct call: model_predictions always passes n_bodies = 4 (:1004).
+    (t <= 400 branch: no scalar_for_gradient.)"""
+    B = x_t.shape[0]
+    assert B == 20, "the reference's 3-body branch hard-codes batch 20 (model/diffusion_1d.py:1958-1960)"
+    xb = x_t.reshape(B, x_t.shape[1], 3, x_t.shape[2] // 3)
+    body = [xb[:, :, i, :] for i in range(3)]
+    x_in = torch.cat([torch.cat([body[0], body[1]], dim=2), torch.cat([body[0], body[2]], dim=2), torch.cat([body[1], body[2]], dim=2)], dim=0)
+    tt = torch.full((x_in.shape[0],), t, dtype=torch.long)
+    nc = d.model(x_in, tt)
+    nc = nc.reshape(nc.shape[0], nc.shape[1], 2, nc.shape[2] // 2)
+    tu = torch.full((B,), t, dtype=torch.long)
+    nu = [d.model_unconditioned(body[i].contiguous(), tu) for i in range(3)]
+    n1 = nc[0:20, :, 0, :] + nc[20:40, :, 0, :] - nu[0]
+    n2 = nc[0:20, :, 1, :] + nc[40:60, :, 0, :] - nu[1]
+    n3 = nc[20:40, :, 1, :] + nc[40:60, :, 1, :] - nu[2]
+    return torch.cat([n1, n2, n3], dim=2)
+
+
 def compose_inside_eps(d, x, t, *, compose_mode, n_composed, compose_start_step, single_model_step,
                        compose_n_bodies):
     """The "inside" branch of model_predictions, model/diffusion_1d.py:959-1001: one U-Net call

@@ -224,6 +224,15 @@ def test_multibody_steps_golden(gold_dir, device, diff_mb):
     od = O.Diffusion1D(O.synth_state_dict(O.unet1d_param_shapes(24, 8), 0), image_size=20, conditioned_steps=4,
                        sd_uncond=O.synth_state_dict(O.unet1d_param_shapes(24, 4), 1))
     assert rel(diff_mb.gradient(x.to(device), 123, 4), O.gradient_4body(od, x, 123)) < TOL_STEP
+    # the 3-body branch (:1927-1982) against the reference's own output at its one defined batch size, 20 (oracle/make_golden_r6.py),
+    # and at another batch against the first rows of the same computation (rows are independent)
+    g3 = np.load(os.path.join(gold_dir, "gradient3_1d_r6.npz"))
+    gen = torch.Generator().manual_seed(606)
+    for t in (311, 0):
+        x3 = torch.randn((20, 24, 12), generator=gen)
+        e3 = diff_mb.gradient(x3.to(device), t, 3)
+        assert rel(e3, g3[f"t{t}.eps"]) < TOL_STEP, t
+        assert torch.equal(diff_mb.gradient(x3[:7].contiguous().to(device), t, 3), e3[:7])
 
 
 def test_step_identities(device, diff8):

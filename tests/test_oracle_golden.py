@@ -154,6 +154,19 @@ def test_guided_steps(gold_dir, sd8):
     assert rel(out, g[f"{tag}.t{t}.out"]) < TOL
 
 
+def test_gradient_three_bodies_golden(gold_dir, sd8, sd4):
+    """The 3-body branch of gradient() (model/diffusion_1d.py:1927-1982) against the reference's own output (batch 20, the only
+    batch its literal slices are defined for; inputs regenerated from seed 606 as oracle/make_golden_r6.py draws them)."""
+    g = np.load(os.path.join(gold_dir, "gradient3_1d_r6.npz"))
+    od = O.Diffusion1D(sd8, image_size=20, conditioned_steps=4, sd_uncond=sd4)
+    gen = torch.Generator().manual_seed(606)
+    for t in (311, 0):
+        x = torch.randn((20, 24, 12), generator=gen)
+        with torch.no_grad():
+            eps = O.gradient_3body(od, x, t)
+        assert float((eps - torch.from_numpy(g[f"t{t}.eps"])).abs().max()) == 0.0, t
+
+
 def test_multibody_steps(gold_dir, sd8, sd4):
     g = np.load(os.path.join(gold_dir, "steps_1d.npz"))
     d = O.Diffusion1D(sd8, image_size=20, conditioned_steps=4, sd_uncond=sd4)
