@@ -232,7 +232,7 @@ class TemporalUnet1D(nn.Module):
         rerun()
         if bool(torch.isfinite(result()).all()):
             warnings.warn("cindm_amd: the first result after loading these weights was not finite on the split-fp16 kernels (an activation left "
-                          "fp16's exponent range on the caller's data); the model now runs on the exact fp32-MFMA kernels, about 2x slower "
+                          "fp16's exponent range on the caller's data); the model now runs on the exact fp32-MFMA kernels, about 3x slower "
                           "(get_option('range_fallback') == 3)", RuntimeWarning)
             return True
         with torch.cuda.device(device):

@@ -86,18 +86,20 @@ int  cindm_unet1d_set_sinusoid_table(cindm_unet1d* h, const float* table_host, i
  * GEMM kernels.  Synchronises `stream`. */
 int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
 
-/* Kernel-path selection for this handle (before *_finalize; changing an option un-finalizes the handle).  Every
- * alternative path computes the same function (the parity suite runs all of them); defaults are the fast path.
- * Keys: "mfma_f32" (1 = exact fp32 MFMA kernels instead of the split-fp16 ones), "local_gn", "attn_site",
- * "wide_qkv", "level0", "level1", "ups_last", "ups_tail", "h3_resample", "site_pack", "dconv", "dconv_pair",
- * "attn_head", "l2_prefetch", "auto_range" (1 = a checkpoint whose conv / projection weights leave the split-fp16 window
- * 2^-12 <= max|w| <= 2^15 runs on the fp32 kernels; "range_fallback" then reads 1), "fuse_update" (plain single-model
- * steps -- DDPM and DDIM loops -- apply the update inside the last U-Net kernel), "fuse_gather" (time composition of two-body
- * states: the first U-Net kernel reads the state's windows in place, no gather launch), "dconv2", "dresample", "pingpong" (the
- * sample loops keep t / step index / epochs in two slots advanced by the step's update), "ws_alias", "level_occ2" (bits: which
- * level kernels run two workgroups per CU above 320 rows), "stress", "taps" (1 = block outputs that live
- * only inside a level kernel are also stored for cindm_unet1d_tap; off on the sampling path),
- * "dbg"/"dbg3"/"dbg4" (timing ablations, wrong results).  No reference counterpart (PyTorch picks its own kernels). */
+/* Kernel-path selection for this handle (before *_finalize; changing an option un-finalizes the handle, except the run-time options
+ * "no_exchange", "recover", "tune").  Every alternative path computes the same function (the parity suite runs all of them); defaults
+ * are the fast path.  Keys (round 6: 24; DESIGN.md section 4.6 lists what was removed and why):
+ *   "mfma_f32" (1 = exact fp32 MFMA kernels instead of the split-fp16 ones), "local_gn", "attn_site", "attn_head" (0 / 1 / 2),
+ *   "level0" (master switch of the level kernels), "level1" (0 / 1 / 2 samples per workgroup), "ups_last", "ups_tail", "dconv", "dconv2",
+ *   "dresample", "l2_prefetch" (launches touch their successor's weights), "ws_alias", "pingpong" (the sample loops keep t / step index /
+ *   epochs in two slots advanced by the step's update), "fuse_update" (plain single-model steps apply the update inside the last U-Net
+ *   kernel), "fuse_gather" (time composition of two-body states: the first U-Net kernel reads the state's windows in place),
+ *   "taps" (1 = block outputs that live only inside a level kernel are also stored for cindm_unet1d_tap; off on the sampling path),
+ *   "auto_range" (1 = the range rule: a checkpoint outside the split-fp16 window runs on the fp32 kernels), "range_fallback" (read-only:
+ *   1 a weight left the window 2^-12 <= max|w| <= 2^15, 2 the calibration batch overflowed, 3 the caller's own batch did --
+ *   cindm_unet1d_range_escalate), "no_exchange", "recover", "stress", "tune" (same-box A/B word: bit 0 = round 5's L2 warm-up placement,
+ *   bit 1 = round 5's plain output stores), "dbg" (timing ablations / forced time-outs: wrong results).
+ * No reference counterpart (PyTorch picks its own kernels). */
 int  cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value);
 int  cindm_unet1d_get_option(const cindm_unet1d* h, const char* key, int32_t* value);
 
@@ -352,8 +354,9 @@ int  cindm_unet2d_set_sinusoid_table(cindm_unet2d* h, const float* table, int64_
  * :205-208) evaluated for every timestep into a device table. */
 /* Kernel-path selection, as cindm_unet1d_set_option.  Keys: "mfma_f32", "la_site", "conv_ws" (1 = persistent
  * wave-specialised 3x3 kernel, 0 = per-tile kernel, 2 / 3 = only the plain-source / GroupNorm-on-load convolutions on
- * it), "tail_h3" (ResnetBlock tails with a res_conv GEMM on the split-fp16 products), "ws_alias" (block-internal
- * temporaries share workspace), "auto_range", "dbg2"/"dbg3". */
+ * it), "ws_nosplit" (0 / 1 / 2: where that kernel splits K over its matrix waves), "tail_h3" (ResnetBlock tails with a res_conv GEMM
+ * on the split-fp16 products), "ws_alias" (block-internal temporaries share workspace), "la_wpi" / "la_nsplit" (workgroups per image of
+ * the LinearAttention kernels), "stress", "auto_range", "range_fallback" (read-only), "dbg2". */
 int  cindm_unet2d_set_option(cindm_unet2d* h, const char* key, int32_t value);
 int  cindm_unet2d_get_option(const cindm_unet2d* h, const char* key, int32_t* value);
 int  cindm_unet2d_finalize(cindm_unet2d* h, void* stream);
@@ -441,7 +444,9 @@ int  cindm_forceunet_set_param(cindm_forceunet* h, const char* key, const float*
  * forward 3x3 convolutions, "h3_bwd" = 0 the input-gradient ones, on the exact fp32 MFMA kernel instead of the
  * split-fp16 one (both paths meet the 2e-5 parity bound); "auto_range" = 0 skips the calibration forward of the range
  * rule; "range_fallback" (read-only) = 1 when that forward switched the handle to the fp32 convolutions; "stress" > 0:
- * pseudo-random delays before the producer -> consumer hand-overs of the persistent convolution kernel (race tests). */
+ * pseudo-random delays before the producer -> consumer hand-overs of the persistent convolution kernel (race tests);
+ * "la_fused" (0 = LinearAttention sites layer by layer), "gn_bwd_fused" (0 / 1 / 2: the GroupNorm + SiLU derivative), "ws_nosplit",
+ * and the run-time options "no_exchange", "recover", "dbg". */
 int  cindm_forceunet_set_option(cindm_forceunet* h, const char* key, int32_t value);
 int  cindm_forceunet_get_option(const cindm_forceunet* h, const char* key, int32_t* value);
 /* folds weight standardisation, packs forward and backward-data fragments, runs the range rule's calibration forward */
