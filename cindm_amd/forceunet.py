@@ -95,12 +95,24 @@ class ForceUnet(nn.Module):
         in-kernel exchange timed out (foreign load on the device); 0 in normal operation."""
         return int(_ffi.lib().cindm_forceunet_recovered(self._h)) + self._py_recovered
 
+    # True (default): every gradient call reads the handle's exchange flag before its result is handed back -- a stream synchronise
+    # and a 4-byte device-to-host copy per call, which serialises a Python-driven guided loop on the host.  False: asynchronous calls
+    # (as TemporalUnet1D.forward(check=False)); the caller reads ``cindm_forceunet_status`` / ``poll_status()`` before trusting results.
+    check_exchange = True
+
+    def poll_status(self, device=None):
+        """Reads and clears the exchange flag (synchronises the current stream): 0 = clean, 1 = an exchange timed out since the last
+        read (the gradients computed since then contain NaN)."""
+        dev = device if device is not None else next(self.parameters()).device
+        with torch.cuda.device(dev):
+            return int(_ffi.lib().cindm_forceunet_status(self._h, _ffi.current_stream(dev)))
+
     def _checked(self, call, device):
         """Runs ``call()`` (one library gradient call on the current stream) and hands its result back only after the handle's
         exchange flag has been read: a timed-out exchange (NaN gradients) is re-run once with ``no_exchange`` = 1 -- or raised,
         with ``recover`` = 0.  Skipped under stream capture (a capture cannot synchronise; the chain entry points check)."""
         out = call()
-        if torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing() or not self.check_exchange:
             return out
         L = _ffi.lib()
         st = L.cindm_forceunet_status(self._h, _ffi.current_stream(device))

@@ -486,7 +486,10 @@ int  cindm_airfoil_design_grad(cindm_forceunet* h, const float* x, int64_t B, in
  * with design_guidance = "standard-alpha"; p_sample's guided tail model/diffusion_2d.py:806-845): per reverse step
  * g = cindm_airfoil_design_grad(x_t); x_{t-1} = p_sample(x_t) (as cindm_ddpm2d_sample); x_{t-1} -= eta[t] * g, with eta a
  * device table of `timesteps` floats (coeff_ratio * betas.flip(0)).  grad: a device buffer shaped like x; ws as
- * cindm_ddpm2d_sample, ws_force as cindm_airfoil_design_grad.  One hipGraph per call, replayed once per timestep. */
+ * cindm_ddpm2d_sample, ws_force as cindm_airfoil_design_grad.  One hipGraph per call, replayed once per timestep.
+ * SYNCHRONISES `stream` before it returns, with use_graph = 0 as well (since round 5): the chain's exchange flag is read at its end and a
+ * timed-out chain is re-run once from the x_T kept in `ws` (round 6: a slice of the caller's workspace -- nothing is allocated); an eager
+ * chain therefore cannot be enqueued asynchronously or captured by the caller.  The error word is cleared when it is read. */
 int  cindm_ddpm2d_sample_force(cindm_ddpm1d* sched, cindm_unet2d* u, cindm_forceunet* f, float* x, int64_t B, int32_t nb,
                                int32_t use_average_share, const float* noise_state_steps,
                                const float* noise_boundary_steps, uint64_t seed, int64_t sample_offset,
