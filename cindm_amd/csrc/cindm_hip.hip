@@ -112,6 +112,7 @@ struct cindm_unet1d {
     const int* ep() const { return epoch_dev + epoch_slot; }
     const void* seen_ws = nullptr; int64_t seen_rows = 0;   // workspace whose exchange regions have been cleared
     int generation = 0;                    // bumped by every (re)pack: captured graphs that embed this handle's pointers check it
+    std::atomic<int> in_chain{0};          // 1 while a sampling chain runs on this handle (run_chain_with_recovery mutates its plan switches: one chain at a time)
     bool force_f32 = false;                // calibration forward overflowed on the split-fp16 kernels: fp32 MFMA kernels in use
     int force_reason = 0;                  // what "range_fallback" reads then: 2 = the synthetic calibration batch, 3 = the caller's own batch (cindm_unet1d_range_escalate)
     bool epoch_prebumped = false;          // the sample loop's counter kernel has already advanced the epoch for the next forward
@@ -2426,6 +2427,18 @@ struct ChainInFlight {
 template <typename Body>
 static int run_chain_with_recovery(cindm_ddpm1d* h, cindm_unet1d* pair, cindm_unet1d* uncond, float* x, float* xT, size_t n_floats,
                                    hipStream_t stream, Body body) {
+    // one chain at a time per U-Net handle: the recovery and the up-front demotion below flip the handle's plan switches (no_xchg_force, the
+    // cached graph) without a lock -- concurrent chains need their own handles, and a second one on the same handle is an error, not a race
+    struct Busy {
+        cindm_unet1d* a; cindm_unet1d* b; bool ok;
+        Busy(cindm_unet1d* a_, cindm_unet1d* b_) : a(a_), b(b_ && b_ != a_ ? b_ : nullptr), ok(true) {
+            if (a->in_chain.exchange(1)) { ok = false; a = nullptr; b = nullptr; return; }
+            if (b && b->in_chain.exchange(1)) { ok = false; a->in_chain.store(0); a = nullptr; b = nullptr; }
+        }
+        ~Busy() { if (a) a->in_chain.store(0); if (b) b->in_chain.store(0); }
+    } busy(pair, uncond);
+    if (!busy.ok) return fail("this U-Net handle is already inside a sampling chain on another thread: concurrent chains need their own handles "
+                              "(cindm_unet1d_create per chain; the weights can be shared by loading the same state dict)");
     ChainInFlight inflight;
     h->last_chain_recovered = 0; h->last_chain_crowded = 0; h->last_chain_in_flight = inflight.prev + 1;
     h->last_chain_range = std::max(pair->O("range_fallback"), uncond ? uncond->O("range_fallback") : 0);

@@ -637,11 +637,14 @@ def test_second_chain_on_a_device_goes_exchange_free_up_front(device):
     late chain bit-equal to what `no_exchange` computes by itself), last_chain_info() says which was which and the Python face
     warns once."""
     import threading
+    import time
     import warnings
     models = [build_unet(device)[0] for _ in range(2)]
     diffs = [cindm_amd.GaussianDiffusion1D(m, image_size=24, conditioned_steps=0, timesteps=1000, sampling_timesteps=1000).to(device) for m in models]
     kw = dict(batch_size=64, n_composed=0, compose_n_bodies=2, seed=4, t_stop=940)
+    long_kw = dict(kw, t_stop=0)                            # chain 0 of the concurrent pair: 1000 steps (~0.3 s) -- the overlap is FORCED
     fast = diffs[0].sample(**kw).clone()                     # alone on the device: the fast plan
+    fast_long = diffs[0].sample(**long_kw).clone()
     models[1].exchange_free(True)
     slow = diffs[1].sample(**kw).clone()
     models[1].exchange_free(False)
@@ -654,7 +657,9 @@ def test_second_chain_on_a_device_goes_exchange_free_up_front(device):
         try:
             with torch.cuda.stream(torch.cuda.Stream(device=device)):
                 gate.wait()
-                out[i] = diffs[i].sample(**kw).clone()
+                if i == 1:
+                    time.sleep(0.05)                        # chain 0 (0.3 s) is in flight by now and for long after
+                out[i] = diffs[i].sample(**(long_kw if i == 0 else kw)).clone()
                 infos[i] = diffs[i].last_chain_info()
         except Exception as e:          # noqa: BLE001
             errs.append(e)
@@ -668,11 +673,30 @@ def test_second_chain_on_a_device_goes_exchange_free_up_front(device):
     assert all(m.recovered == 0 for m in models), "a time-out fired: the registry did not demote the second chain"
     assert not any(i["recovered"] for i in infos)
     crowded = [i["exchange_free_up_front"] for i in infos]
-    if any(crowded):                     # the chains overlapped (the usual case: a chain is 60 x 330 us)
-        assert sum(crowded) == 1 and max(i["chains_in_flight"] for i in infos) == 2
-        assert any("ONE chain per device" in str(x.message) for x in w)
-    for i in range(2):
-        assert torch.equal(out[i], slow if crowded[i] else fast)
+    assert crowded == [False, True], crowded                 # (round 5's version accepted "no overlap" silently)
+    assert infos[1]["chains_in_flight"] == 2
+    assert any("ONE chain per device" in str(x.message) for x in w)
+    assert torch.equal(out[0], fast_long) and torch.equal(out[1], slow)
+    # ... and ONE handle cannot be inside two chains at once: the second caller gets an error, not a race on the handle's plan switches
+    errs2, done = [], []
+
+    def run_same(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                if i == 1:
+                    time.sleep(0.05)
+                done.append(diffs[0].sample(**(long_kw if i == 0 else kw)))
+        except cindm_amd.CindmError as e:
+            errs2.append(str(e))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        th = [threading.Thread(target=run_same, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    assert len(done) == 1 and len(errs2) == 1 and "already inside a sampling chain" in errs2[0], (len(done), errs2)
+    assert torch.equal(done[0], fast_long)
+    assert torch.equal(diffs[0].sample(**kw), fast)         # the handle is free again
 
 
 def test_unet2d_round5_paths_agree_at_full_occupancy(device):
