@@ -1151,11 +1151,34 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     __syncthreads();
     PH(3);
     uint32_t* tw = reinterpret_cast<uint32_t*>(Tile);
+    float yq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int r = rq + 8 * q;
+        yq[q] = ((Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n])) + bias;
+    }
+    if (a.pf.wt) {
+        // fp32 rows as 16-byte write-through stores: the lane quad transposes 4 x 4 blocks (rows 4 g .. 4 g + 3 of its four columns), lane j
+        // stores row q = 4 g + j (as dconv2_kernel's epilogue; a 4-byte sc1 store is one fabric write each)
+        static_assert(NQ == 6 || NQ == 12, "6 or 12 rows per thread");
+        const int j = lane & 3;
+        const size_t c4 = (size_t)(gn & ~3);
+#pragma unroll
+        for (int g = 0; g < (NQ + 3) / 4; ++g) {
+            float t4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t4[e] = 4 * g + e < NQ ? yq[(4 * g + e) < NQ ? 4 * g + e : 0] : 0.f;
+            quad_transpose4(t4, lane);
+            const int q = 4 * g + j;
+            const int r = rq + 8 * q, sm = r & 15, pos = r >> 4;
+            if (q < NQ && sm < ns) st_out4(a.out_f32, (size_t)((b0 + sm) * LOUT + pos) * a.ldo + c4, make_float4(t4[0], t4[1], t4[2], t4[3]), 1);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int r = rq + 8 * q, sm = r & 15, pos = r >> 4;
-        const float y = ((Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n])) + bias;
-        if (sm < ns) st_out(a.out_f32, (size_t)((b0 + sm) * LOUT + pos) * a.ldo + gn, y, a.pf.wt);
+        const float y = yq[q];
+        if (!a.pf.wt && sm < ns) st_out(a.out_f32, (size_t)((b0 + sm) * LOUT + pos) * a.ldo + gn, y, 0);
         const _Float16 hi = (_Float16)y;
         const _Float16 lo = (_Float16)((y - (float)hi) * H3_SCALE);
         const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
