@@ -475,6 +475,15 @@ struct Dconv2Args {
     int tune;                                             // experiment switches for same-box A/B runs (option "tune"; 0 = the shipped choice)
 };
 
+// (experiment builds -DCINDM_KPROF, library variant "kprof": the phase clocks of dconv2_kernel go INSIDE phase A's K loop -- marks 2 + 2j /
+// 3 + 2j = k-step j staged / multiplied, single-source instances only -- and the marks of the later phases are off)
+#ifdef CINDM_KPROF
+#define PHK(i) PH(i)
+#define PHX(i) do { } while (0)
+#else
+#define PHK(i) do { } while (0)
+#define PHX(i) PH(i)
+#endif
 template <int L, int KPW0, int KPW1, bool RES, int KPWB>
 __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     constexpr int T = 5;
@@ -720,11 +729,17 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     constexpr std::false_type NO{};
     constexpr std::integral_constant<bool, RES> RIDE_A{};
     // ---- phase A K loop; its last k-step requests phase B's first stage of weights instead of nothing ------------------
+    // (Round 6 put clocks INSIDE this loop, -DCINDM_KPROF: a k-step's multiplication takes 0.60 - 0.72 us = its 80 KB per CU at the stream's
+    // rate; its staging 0.16 us from planes and 0.36 us from fp32 rows -- the split into hi / lo is ~170 VALU instructions per lane.  Staging
+    // one to three k-steps AHEAD of the multiplication, or all of them in front of the loop, was built: bitwise equal, 324.7 vs 324.9 us per
+    // step with one k-step of lead, slower with three, and 12 - 175 spilled registers with all of them up front.  Not kept.)
     if constexpr (KPW1 == 0) {
 #pragma unroll
-        for (int j = 0; j < KPW0 - 1; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A, SLOT0); }
+        for (int j = 0; j < KPW0 - 1; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); PHK(2 + 2 * j); kstep(wbase, j, j + 1, YES, RIDE_A, SLOT0); PHK(3 + 2 * j); }
         store_raw(g0.f32, g0.slot, KPW0 - 1, raw0[KPW0 - 1]);
+        PHK(2 + 2 * (KPW0 - 1));
         kstep(wbase, KPW0 - 1, 0, NO, RIDE_A, SLOT0);
+        PHK(3 + 2 * (KPW0 - 1));
     } else {
 #pragma unroll
         for (int j = 0; j < KPW0; ++j) { store_raw(g0.f32, g0.slot, j, raw0[j]); kstep(wbase, j, j + 1, YES, RIDE_A, SLOT0); }
@@ -733,7 +748,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         store_raw(g1.f32, g1.slot, KPW1 - 1, raw1[KPW1 - 1]);
         kstep(wbase, KPW1 - 1, 0, NO, RIDE_A, SLOT0);
     }
-    PH(2);                                    // 2 = phase A's K loop done (staging waits + MFMAs)
+    PHX(2);                                    // 2 = phase A's K loop done (staging waits + MFMAs)
     // (phase B's first stage of weights is requested further down, where this wave would otherwise idle: requested HERE, the
     // 20 KB per wave sat in front of the epilogue's first LDS writes in the issue queue -- the cross-wave reduction of phase A
     // measured 1.5 us in the replayed step against 0.5 us for the same code in phase B)
@@ -799,7 +814,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
                 }
             }
             stress_delay(a.stress, 2u);
-            PH(PHB);
+            PHX(PHB);
             // the partner's granules of BOTH samples in one sweep (one loop per sample was two serial round trips)
             unsigned long long gq[NSAMP][2];
             {
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
                 mean[js] = m;
                 rstd[js] = (rstd[js] + M2p) + cnt * (d0 * d0 + d1 * d1);
             }
-            PH(PHB + 1);
+            PHX(PHB + 1);
         }
         after_xchg();                             // (requests that must not sit in front of the exchange's poll in the return queue)
         const float cnt_all = a.gw == 64 ? 2.f * cnt : cnt;
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     float v[6], y[6];
     stress_delay(a.stress, 3u);
     reduce_to(accM, accL, bias_a, v);
-    PH(3);                                    // 3 = cross-wave reduction of phase A (LDS round trip + barrier)
+    PHX(3);                                    // 3 = cross-wave reduction of phase A (LDS round trip + barrier)
     gn_mish(v, a.xchg_a, gam_a, bet_a, y, std::integral_constant<int, 4>{}, [&]() {});      // 4, 5 = GroupNorm statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += tbv;
@@ -881,13 +896,13 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rsrc, off, 0, 16);     // aux 16 = sc1: write-through
         };
         for (int i = tid; i < 384; i += 256) store_item(i);
-        PH(6);                                // 6 = Mish, time bias, planes through LDS, write-through stores issued
+        PHX(6);                                // 6 = Mish, time bias, planes through LDS, write-through stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
         stress_delay(a.stress, 6u);
         __syncthreads();
         if (tid == 0 && !(a.dbg == 9 && (nt & 1)))
             __hip_atomic_store(a.flags + 2 * ((size_t)mt * a.NT + nt), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        PH(7);                                // 7 = stores drained, flag raised
+        PHX(7);                                // 7 = stores drained, flag raised
         // phase B's first stage of weights: in flight during the hand-over (flag poll, y0 fetch)
         issue_b();
         if (a.tune & 1) l2_prefetch(a.pf, pfr);       // A/B: round 5's placement of the next launch's warm-up
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     // r = Wr x + br stays in registers (Red is free again: the barrier above)
     float r2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (RES) { reduce_to(accRM, accRL, bias2, r2); __syncthreads(); }
-    PH(8);                                    // 8 = the riding 1x1's reduction (RES)
+    PHX(8);                                    // 8 = the riding 1x1's reduction (RES)
 
     // ---- hand-over: this wave's k-steps of y0 (k-step ks = the 32 channels of producer nt = ks) -----------------------
     // The fetch runs through a ring of YB k-steps of staging registers (24 VGPRs each): with all KPWB k-steps in registers
@@ -941,7 +956,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
         // MI355X_MICROARCH.md -- but nothing else would stop the compiler from hoisting the raw-buffer loads above the relaxed
         // atomic loads of the spin).
         asm volatile("" ::: "memory");
-        PH(9);                                // 9 = the flags of this wave's producers seen
+        PHX(9);                                // 9 = the flags of this wave's producers seen
 #pragma unroll
         for (int j = 0; j < YB; ++j) fetch_y0(j, rawb[j]);
         __builtin_amdgcn_sched_barrier(0);
@@ -967,7 +982,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     if constexpr (KPWB > 2) kb_step(std::integral_constant<int, 2>{});
     if constexpr (KPWB > 3) kb_step(std::integral_constant<int, 3>{});
     static_assert(KPWB <= 4, "phase B: at most four k-steps per wave");
-    PH(10);                                   // 10 = phase B's K loop done (y0 fetch waits + MFMAs)
+    PHX(10);                                   // 10 = phase B's K loop done (y0 fetch waits + MFMAs)
     // the NEXT launch's L2 warm-up (kernels.h Pf), round 6: issued HERE, a few microseconds before this launch ends.  Through round 5 it
     // was issued behind the publish, i.e. in front of phase B's 1.3 MB per XCD of weights and 1.6 MB of y0: the touched lines did not
     // survive in the 4 MB L2 (n-tiles with and without warm-up streamed equally fast; the option was a net loss)
@@ -976,7 +991,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     // ---- phase B epilogue: out = Mish(GN(.)) + (x | r) -------------------------------------------------------------------
     stress_delay(a.stress, 8u);
     reduce_to(accM, accL, bias_b, v);
-    PH(11);                                   // 11 = cross-wave reduction of phase B
+    PHX(11);                                   // 11 = cross-wave reduction of phase B
     gn_mish(v, a.xchg_b, gam_b, bet_b, y, std::integral_constant<int, 12>{}, [&]() {});     // 12, 13 = statistics / pair exchange
 #pragma unroll
     for (int q = 0; q < 6; ++q) y[q] += RES ? r2[q] : rs[q];
@@ -1011,7 +1026,7 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
             st_out4(a.out_planes, pl * a.out_pstride + ((size_t)mt * a.NT + nt) * 192 + within, t4, a.pf.wt);
         }
     }
-    PH(14);                                   // 14 = Mish, residual, fp32 + planes stores issued
+    PHX(14);                                   // 14 = Mish, residual, fp32 + planes stores issued
     l2_prefetch_done(a.pf, pfr);
     PH_FLUSH(a.ph);
 }

@@ -23,7 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-assert os.environ.get("CINDM_LIB_VARIANT") in ("prof", "abl1", "abl2", "abl3"), "run with CINDM_LIB_VARIANT=prof (the production library has no phase clocks)"
+assert os.environ.get("CINDM_LIB_VARIANT") in ("prof", "abl1", "abl2", "abl3", "kprof"), "run with CINDM_LIB_VARIANT=prof (the production library has no phase clocks)"
 import bench                                 # noqa: E402
 from cindm_amd import _ffi                   # noqa: E402
 
@@ -45,6 +45,10 @@ PHASES = {
     "ups_last": ["entry"] + [f"after barrier {k}" for k in range(1, 12)] + ["final stores (+ fused DDPM update)"],
     "ups_tail128": ["entry"] + [f"after barrier {k}" for k in range(1, 9)] + ["final stores"],
 }
+
+
+if os.environ.get("CINDM_LIB_VARIANT", "").startswith("kprof"):      # the experiment build with the clocks inside phase A's K loop (kernels_dconv.h, CINDM_KPROF)
+    PHASES["dconv2"] = ["entry", "prologue loads issued"] + [x for j in range(4) for x in (f"k-step {j} staged (tile wait, LDS write)", f"k-step {j} multiplied (5 taps)")]
 
 
 def kind_of(name):
