@@ -221,7 +221,7 @@ static const OptDef kUnet1dOpts[] = {
     {"taps", 0, "CINDM_TAPS"},         // 1: the level kernels also store the block outputs that only cindm_unet1d_tap reads
     {"recover", 1, nullptr},                   // run-time: 0 = a chain whose exchange timed out is an error instead of an exchange-free re-run
     {"no_exchange", 0, "CINDM_NO_EXCHANGE"},   // 1: only kernels without an in-launch exchange between workgroups (run-time option: does not un-finalize)
-    {"tune", 0, "CINDM_TUNE"},         // same-box A/B switches (run-time; 0 = the shipped choices): bit 0 = round 5's L2 warm-up placement and regions, bit 1 = round 5's plain output stores
+    {"tune", 0, "CINDM_TUNE"},         // same-box A/B switches (run-time; 0 = the shipped choices): bit 0 = round 5's L2 warm-up placement, regions and issuers, bit 1 = round 5's plain output stores, bits 2 + i = launch i of the forward issues no warm-up (tools/pf_mask_scan.py)
     {"stress", 0, "CINDM_STRESS"},     // > 0 (a seed): pseudo-random pauses before the in-kernel hand-overs (dconv pair exchange, attention heads)
     {"auto_range", 1, "CINDM_AUTO_RANGE"}, // per-layer fall-back to the fp32 MFMA kernels when weights leave the fp16-safe window
     {"range_fallback", 0, nullptr},    // (read-only) 1 after finalize when a weight left the split-fp16 window: fp32 kernels in use
@@ -655,11 +655,18 @@ struct Emitter {
     // (h->pf_table, one entry per launch in order) tells launch i what launch i + 1 will stream
     int pf_idx = 0;
     std::vector<cindm_unet1d::WReg>* pf_out = nullptr;
+    // `issue` false: this launch streams what it registers but touches nothing for its successor.  Round 6 measured every launch of the
+    // headline step with its touches off (tools/pf_mask_scan.py, one process): the three attn1d_head launches pay 1.2 - 1.5 us for them
+    // (they end on a spin + a short projection: nothing hides the touches) and their successors gain nothing -- a C = 512 dconv2
+    // launch streams at the L2-hot rate either way, its 16 workgroups per n-tile warm each other --: -0.9 / -1.0 / -0.9 us per step
+    // without; downs.3.1 (in front of the first of them): -0.5 us.  Every other launch's touches are worth 0 ... +1.0 us per step.
+    bool pf_issue = true;
     void pf_step(Pf& pf, const cindm_unet1d::WReg& mine) {
         std::memset(&pf, 0, sizeof(pf));
         if (pf_out) pf_out->push_back(mine);
         const auto& tab = h->pf_table;
-        if (!dry && !pf_out && h->O("l2_prefetch") && !tab.empty()) {
+        // (experiment: bits 2.. of `tune` = launches of the forward that issue NO touches, bit 2 + i = launch i)
+        if (!dry && !pf_out && h->O("l2_prefetch") && !tab.empty() && (pf_issue || (h->O("tune") & 1)) && !(((h->O("tune") >> 2) >> (pf_idx % 24)) & 1)) {
             const cindm_unet1d::WReg& nx = tab[(size_t)(pf_idx + 1) % tab.size()];
             for (int k = 0; k < PF_REGIONS; ++k) {
                 pf.base[k] = reinterpret_cast<const char*>(h->blob) + nx.off[k];
@@ -971,7 +978,9 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
                            r.off[1] = w1.off * 4; r.bytes[1] = (unsigned)t1; r.stride[1] = (unsigned)t1;
                          }
         else { r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)std::min(w0.sz * 4, (size_t)2 << 20); }
+        E.pf_issue = p != "downs.3.1";              // (see Emitter::pf_issue)
         Pf pf; E.pf_step(pf, r);
+        E.pf_issue = true;
         if (E.dry) { E.drop(y0); return out; }
         Dconv2Args d;
         std::memset(&d, 0, sizeof(d));
@@ -1184,7 +1193,9 @@ static Ten emit_attn(Emitter& E, const std::string& p, const Ten& x, const float
         E.need_epoch();
         ++E.launches;
         Pf pfs;
+        E.pf_issue = false;                        // (see Emitter::pf_issue)
         E.pf_all(pfs, {&site->second, &h->packed.at(p + ".fn.fn.to_out#site")}, {});
+        E.pf_issue = true;
         if (!E.dry) {
             AttnHeadArgs s;
             std::memset(&s, 0, sizeof(s));

@@ -98,7 +98,7 @@ int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
  *   "auto_range" (1 = the range rule: a checkpoint outside the split-fp16 window runs on the fp32 kernels), "range_fallback" (read-only:
  *   1 a weight left the window 2^-12 <= max|w| <= 2^15, 2 the calibration batch overflowed, 3 the caller's own batch did --
  *   cindm_unet1d_range_escalate), "no_exchange", "recover", "stress", "tune" (same-box A/B word: bit 0 = round 5's L2 warm-up placement,
- *   bit 1 = round 5's plain output stores), "dbg" (timing ablations / forced time-outs: wrong results).
+ *   regions and issuers, bit 1 = round 5's plain output stores, bit 2 + i = launch i of the forward issues no warm-up), "dbg" (timing ablations / forced time-outs: wrong results).
  * No reference counterpart (PyTorch picks its own kernels). */
 int  cindm_unet1d_set_option(cindm_unet1d* h, const char* key, int32_t value);
 int  cindm_unet1d_get_option(const cindm_unet1d* h, const char* key, int32_t* value);

@@ -103,7 +103,7 @@ def test_guided_chain_fused_equals_loop(device, force):
                                     coeff_ratio=0.05).to(device)
     B, nb = 2, 2
     fn = cindm_amd.ForceObjective(m, B, nb, 6, p_min=-37.7, p_max=57.6)
-    tape = _tape(31, B, nb, 21, 64, 64, 1000)
+    tape = _tape(31, B, nb, 21, 64, 64, 1000, t_min=995)
     shape = (B, nb, 21, 64, 64)
     kw = dict(design_fn=fn, design_guidance="standard-alpha", noise=tape, t_stop=995, device=device)
     loop = d.p_sample_loop(shape, fused=False, **kw)
@@ -279,7 +279,7 @@ def test_guided_chain_golden(gold_dir, device, force, fused):
                                     coeff_ratio=float(g["coeff_ratio"])).to(device)
     B, nb = 1, 2
     fn = cindm_amd.ForceObjective(m, B, nb, 6, p_min=-37.7, p_max=57.6)
-    tape = _tape(int(g["tape_seed"]), B, nb, 21, 64, 64, 1000)
+    tape = _tape(int(g["tape_seed"]), B, nb, 21, 64, 64, 1000, t_min=int(min(g["ckpt_t"])))
     for t, ref in zip(g["ckpt_t"], g["ckpt"]):
         out = d.p_sample_loop((B, nb, 21, 64, 64), design_fn=fn, design_guidance="standard-alpha", noise=tape, t_stop=int(t),
                               device=device, fused=fused)
@@ -389,7 +389,7 @@ def test_surrogate_exchange_timeout_is_recovered(device):
     d = cindm_amd.GaussianDiffusion(u, image_size=64, frames=6, cond_frames=2, timesteps=1000, sampling_timesteps=1000, loss_type="l2",
                                     coeff_ratio=0.05).to(device)
     B, nb = 1, 2
-    tape = _tape(31, B, nb, 21, 64, 64, 1000)
+    tape = _tape(31, B, nb, 21, 64, 64, 1000, t_min=997)
     kw = dict(design_guidance="standard-alpha", noise=tape, t_stop=997, device=device, fused=True)
     want = d.p_sample_loop((B, nb, 21, 64, 64), design_fn=cindm_amd.ForceObjective(ref, B, nb, 6, p_min=-37.7, p_max=57.6), **kw)
     before = m.recovered

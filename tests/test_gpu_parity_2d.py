@@ -142,12 +142,14 @@ def test_step2d_sum_share_vs_oracle(device, unet2d):
 
 
 # ------------------------------------------------------------------ whole chains
-def _tape(seed, B, nb, C, H, W, T):
+def _tape(seed, B, nb, C, H, W, T, t_min=1):
+    """Explicit noise for a T-step chain, drawn in the chain's order; `t_min`: the draws of steps below it are skipped (zeros) -- for chains
+    that stop at t_stop >= t_min the tape is the same, without 1000 steps of host random numbers."""
     g = torch.Generator().manual_seed(seed)
     init = (torch.randn((B, 1, C - 3, H, W), generator=g), torch.randn((B, nb, 3, H, W), generator=g))
     ss = torch.zeros((T, B, 1, C - 3, H, W))
     sb = torch.zeros((T, B, nb, 3, H, W))
-    for t in range(T - 1, 0, -1):
+    for t in range(T - 1, max(t_min, 1) - 1, -1):
         ss[t] = torch.randn((B, 1, C - 3, H, W), generator=g)
         sb[t] = torch.randn((B, nb, 3, H, W), generator=g)
     return cindm_amd.NoiseTape2D(init, ss, sb)
@@ -196,7 +198,7 @@ def test_guided_chain2d_vs_oracle_short(device, unet2d, diff2d):
     """design_fn guidance over the first 6 steps against the oracle with the same tape."""
     _, sd = unet2d
     od = O.Diffusion2D(sd, image_size=64, frames=6)
-    tape = _tape(77, 1, 2, 21, 64, 64, 1000)
+    tape = _tape(77, 1, 2, 21, 64, 64, 1000, t_min=994)
     steps = {t: (tape.step_state[t], tape.step_boundary[t]) for t in range(1, 1000)}
     ref = O.p_sample_loop_2d(od, (1, 2, 21, 64, 64), tape.init, steps, design_grad, "standard-alpha", t_stop=994)
     out = diff2d.sample(batch_size=1, num_boundaries=2, design_fn=design_grad, design_guidance="standard-alpha",

@@ -778,7 +778,7 @@ def test_checkpoint_to_eval_simu_on_the_device(device, tmp_path):
     assert tr.step == 11
     gd = gd.to(device)
     from test_gpu_parity_2d import _tape as tape2d
-    t2 = tape2d(91, 1, 2, 21, 64, 64, 1000)
+    t2 = tape2d(91, 1, 2, 21, 64, 64, 1000, t_min=996)
     out2 = gd.sample(batch_size=1, num_boundaries=2, noise=t2, t_stop=996)
     od2 = O.Diffusion2D(sd2, image_size=64, frames=6)
     steps = {t: (t2.step_state[t], t2.step_boundary[t]) for t in range(1, 1000)}
