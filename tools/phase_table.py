@@ -88,6 +88,9 @@ def table(names, rec, out):
         tot_span += span
         if gap == gap:
             tot_gap += gap
+        if os.environ.get("PHASE_RAW") == kind_of(name):      # every stamp as its median distance from the entry stamp (marks that are not in program order)
+            out.write(f"\n#{s:2d} {name}: stamps relative to entry (us, median): " + " ".join(
+                f"[{i}] {np.median((r[:, :, i] - r[:, :, 0])[u & (r[:, :, i] != 0)]) * TICK_US:.2f}" for i in range(1, NST) if (u & (r[:, :, i] != 0)).any()) + "\n")
         labels = PHASES.get(kind_of(name), [])
         crit_wg = int(np.argmax(np.where(u, last, 0).max(axis=1)))
         out.write(f"\n#{s:2d} {name}: {int(wg_used.sum())} workgroups x {int(u[0].sum())} waves | span {span:6.2f} us | gap before {gap:5.2f} us | entry skew {skew:5.2f} us\n")
