@@ -459,19 +459,13 @@ def test_builtin_objective_chain_equals_autograd_path(device, diff8):
     assert torch.equal(a, b) and torch.equal(a[4:], lo)
 
 
-def test_builtin_objective_paper_configuration(device, unet8, diff8):
+def test_builtin_objective_paper_configuration(device, gold_dir, unet8, diff8):
     """The shape scripts_paper/1D/cindm.sh runs (Table 2): 4 bodies, 3 windows (cs = 10), mean-inside, "L2" objective with a
-    time-consistency term, initial-state overwrite, standard-recurrence-N -- two reverse steps against the oracle."""
-    _, sd = unet8
-    od = O.Diffusion1D(sd, image_size=24, conditioned_steps=0)
-    obj = cindm_amd.PointObjective([0.3, -0.2], 1, coef=0.2, time_consistency_coef=0.2, design_fn_mode="L2")
-    g = torch.Generator().manual_seed(33)
-    B, Lt, F = 2, 44, 16
-    iso = torch.randn((B, 4, F), generator=g) * 0.2
-    tape = O.NoiseTape.make(44, (B, Lt, F), 1000, recur=2)
-    kw = dict(n_composed=2, compose_start_step=10, compose_n_bodies=4, compose_mode="mean-inside",
-              design_guidance="standard-recurrence-2", initial_state_overwrite=iso)
-    ref = O.p_sample_loop(od, (B, 24, F), None, tape, design_fn=obj, t_stop=998, **kw)
+    time-consistency term, initial-state overwrite, standard-recurrence-N -- two reverse steps against the oracle.  The oracle's output
+    is a fixture (20 s of host autograd; test_oracle_golden.py::test_paper_config_fixture_is_the_oracles_output re-derives it in the CPU suite)."""
+    from test_oracle_golden import paper_config_inputs
+    _, obj, iso, tape, kw, (B, Lt, F) = paper_config_inputs()
+    ref = np.load(os.path.join(gold_dir, "oracle_paper_config_r6.npz"))["ref"]
     out = diff8.sample(batch_size=B, design_fn=obj, noise=cindm_amd.NoiseTape(tape.init, tape.step, tape.recur), t_stop=998,
                        **{**kw, "initial_state_overwrite": iso.to(device)})
     assert out.shape == (B, Lt, F)
