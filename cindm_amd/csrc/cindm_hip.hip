@@ -213,7 +213,7 @@ static const OptDef kUnet1dOpts[] = {
     {"dconv", 1, "CINDM_DCONV"},       // deep-level k=5 convolutions on dconv_kernel (LDS-resident activation planes)
     {"ws_alias", 1, "CINDM_WS_ALIAS"}, // sampling path (taps = 0): dead intermediates' workspace blocks are recycled: 0 never, 1 above 320 rows, 2 always
     {"pingpong", 1, "CINDM_PINGPONG"}, // plain sample loops: step counter / epochs in two slots advanced by the step's update (no step_counter_kernel launch)
-    {"dresample", 1, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel (0: conv_gemm_h3_kernel<3 | 4>)
+    {"dresample", 2, "CINDM_DRESAMPLE"},   // the resampling convolutions between the deep levels on dresample_kernel: 2 = 16 columns per workgroup, 1 = 32 (0: conv_gemm_h3_kernel<3 | 4>)
     {"dconv2", 1, "CINDM_DCONV2"},     // a whole deep-level ResidualTemporalBlock per launch (dconv2_kernel: in-launch all-gather between its convolutions)
     {"l2_prefetch", 1, "CINDM_L2_PREFETCH"},   // launches touch the next launch's weights (L2 warm-up)
     {"fuse_gather", 1, nullptr},       // time composition of two-body states: level0_down_kernel reads the state's windows in place (no compose_gather_kernel launch)
@@ -1349,11 +1349,19 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
             d.x = x.p; d.ld = x.ld; d.W = reinterpret_cast<const uint4*>(E.W(w)); d.bias = E.B(w); d.nch = w.CinP / 128;
             d.Bp = Bp; d.N = x.C; d.NT = NT; d.out_f32 = out.p; d.ldo = out.ld; d.out_planes = out.pl; d.out_pstride = out.pst;
             d.ph = E.ph_next(std::string("dresample<") + (up ? "up" : "down") + "> " + p);
-            const dim3 grid((unsigned)NT, (unsigned)tiles);
+            // "dresample" = 2 (default): 16 columns per workgroup where 32 would leave CUs idle (2 NT x tiles = 256 workgroups at 256 rows:
+            // 320.2 -> 317.2 us per step; at 768 rows the 32-column grid is 384 workgroups already and the split costs 2 us); 1: always 32
+            const bool half = h->O("dresample") >= 2 && NT % 8 == 0 && NT * tiles < 256;
+            const dim3 grid((unsigned)(half ? 2 * NT : NT), (unsigned)tiles);
             E.prof_begin(up ? 3 : 2, 2.0 * Bp * Lout * x.C * (double)x.C * (up ? 2.0 : 3.0));
             if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }
-            if (up) KLAUNCH(E, (dresample_kernel<true, 2>), grid, dim3(256), 0, d);
-            else KLAUNCH(E, (dresample_kernel<false, 2>), grid, dim3(256), 0, d);
+            if (half) {
+                if (up) KLAUNCH(E, (dresample_kernel<true, 2, 2>), grid, dim3(256), 0, d);
+                else KLAUNCH(E, (dresample_kernel<false, 2, 2>), grid, dim3(256), 0, d);
+            } else {
+                if (up) KLAUNCH(E, (dresample_kernel<true, 2, 1>), grid, dim3(256), 0, d);
+                else KLAUNCH(E, (dresample_kernel<false, 2, 1>), grid, dim3(256), 0, d);
+            }
             E.prof_end();
             hipError_t e = hipGetLastError();
             if (e != hipSuccess && E.err == hipSuccess) E.err = e;

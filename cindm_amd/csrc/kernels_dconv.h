@@ -1052,20 +1052,25 @@ struct DresArgs {
     PhaseBuf ph;
 };
 
-template <bool UP, int KPW>
+// NH: column split of an n-tile over workgroups -- 1: the workgroup owns all 32 columns (grid NT x tiles = 128 workgroups at 256 rows);
+// 2 (round 6): 16 columns, workgroup x = (n-tile x % NT, half x / NT), 256 workgroups: both halves of an n-tile land on the XCD the tile's
+// weights are warmed for, each reads half of the tile's fragments (98 -> 49 KB) and the same activation tile (98 KB).
+template <bool UP, int KPW, int NH>
 __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     constexpr int T = UP ? 4 : 3, LIN = UP ? 3 : 6, LOUT = UP ? 6 : 3, S = 16;
-    constexpr int RIN = LIN * S, ROUT = LOUT * S, NBLK = LOUT, NQ = ROUT / 8;
-    constexpr int KST = 4 * KPW, TP = 20;
+    constexpr int TNW = TN / NH, NBW = 2 / NH, RQN = 256 / TNW, LDW = TNW + 1;      // columns, 16-column blocks, row groups of the epilogue, Red pitch
+    constexpr int RIN = LIN * S, ROUT = LOUT * S, NBLK = LOUT, NQ = ROUT / RQN;
+    static_assert(NH == 1 || NH == 2, "32 or 16 columns per workgroup");
+    constexpr int KST = 4 * KPW, TP = TNW / 2 + 4;      // TP: words per row and plane in Tile (two columns per word, padded)
     __shared__ uint4 Img[2][KST * 4 * RIN];
-    __shared__ float Red[4][ROUT * LDR];
+    __shared__ float Red[4][ROUT * LDW];
     __shared__ uint4 Tile[2 * ROUT * 5];
     PH_DECL;
     PH(0);                                    // phase clocks (profiling builds): 0 entry, 1 loads issued, 2 K loop, 3 reduce, 4 stores issued
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int nt = NH == 1 ? (int)blockIdx.x : (int)blockIdx.x % a.NT, nbh = NH == 1 ? 0 : (int)blockIdx.x / a.NT, mt = blockIdx.y;
     const int b0 = mt * S, ns = min(S, a.Bp - b0);
-    const int n = tid & 31, rq = tid >> 5, gn = nt * TN + n;
+    const int n = tid & (TNW - 1), rq = tid / TNW, gn = nt * TN + nbh * TNW + n;
 
     // staging: item = (input row, k-quarter); row = position * 16 + sample; a row's 32 channels are one 128-byte line
     constexpr int NIT = RIN * 4 / 64;
@@ -1085,12 +1090,12 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
             const float4* p4 = reinterpret_cast<const float4*>(ibase[i] + (4 * j + w) * 32);
             raw[j][i][0] = p4[0]; raw[j][i][1] = p4[1];
         }
-    half8 breg[T][2][2];
+    half8 breg[T][NBW][2];
     const uint4* wbase = a.W + (size_t)nt * a.nch * (T * 4) * 256 + tid;
     auto load_b_tap = [&](int ch, int tap) {
         const uint4* wp = wbase + ((size_t)ch * (T * 4) + tap * 4) * 256;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) breg[tap][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[q * 256]);
+        for (int q = 0; q < 2 * NBW; ++q) breg[tap][q >> 1][q & 1] = __builtin_bit_cast(half8, wp[(NH == 1 ? q : 2 * nbh + q) * 256]);
     };
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) load_b_tap(0, tap);
@@ -1101,11 +1106,11 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     PH(1);
 
-    f32x4 accM[NBLK][2], accL[NBLK][2];
+    f32x4 accM[NBLK][NBW], accL[NBLK][NBW];
 #pragma unroll
     for (int i = 0; i < NBLK; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < NBW; ++j) { accM[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accL[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     auto kstep = [&](int j, int chn, auto pf) {
         constexpr bool PF = decltype(pf)::value;
@@ -1136,12 +1141,12 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
                 const int p = UP ? num / 2 : num;
                 if (num < 0 || p >= LIN) continue;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < NBW; ++nb) {
                     accM[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][0], accM[lo][nb], 0, 0, 0);
                     accL[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[p], breg[tap][nb][1], accL[lo][nb], 0, 0, 0);
                 }
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NBW; ++nb)
                     accL[lo][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[p], breg[tap][nb][0], accL[lo][nb], 0, 0, 0);
             }
             if constexpr (PF) { load_b_tap(chn, tap); __builtin_amdgcn_sched_barrier(0); }      // pinned behind the tap's last use
@@ -1155,27 +1160,26 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     PH(2);
     l2_prefetch_late(a.pf, pfr);
 
-    // cross-wave K reduction; thread (n, rq) ends with column n of rows rq + 8 q (row = position * 16 + sample)
+    // cross-wave K reduction; thread (n, rq) ends with column n of rows rq + RQN q (row = position * 16 + sample)
 #pragma unroll
     for (int mb = 0; mb < NBLK; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
-                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDR + nb * 16 + (lane & 15)] = accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV;
+                Red[w][(mb * 16 + (lane >> 4) * 4 + rg) * LDW + nb * 16 + (lane & 15)] = accM[mb][nb][rg] + accL[mb][nb][rg] * H3_INV;
     __syncthreads();
     PH(3);
     uint32_t* tw = reinterpret_cast<uint32_t*>(Tile);
     float yq[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int r = rq + 8 * q;
-        yq[q] = ((Red[0][r * LDR + n] + Red[1][r * LDR + n]) + (Red[2][r * LDR + n] + Red[3][r * LDR + n])) + bias;
+        const int r = rq + RQN * q;
+        yq[q] = ((Red[0][r * LDW + n] + Red[1][r * LDW + n]) + (Red[2][r * LDW + n] + Red[3][r * LDW + n])) + bias;
     }
     if (a.pf.wt) {
         // fp32 rows as 16-byte write-through stores: the lane quad transposes 4 x 4 blocks (rows 4 g .. 4 g + 3 of its four columns), lane j
         // stores row q = 4 g + j (as dconv2_kernel's epilogue; a 4-byte sc1 store is one fabric write each)
-        static_assert(NQ == 6 || NQ == 12, "6 or 12 rows per thread");
         const int j = lane & 3;
         const size_t c4 = (size_t)(gn & ~3);
 #pragma unroll
@@ -1185,13 +1189,13 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
             for (int e = 0; e < 4; ++e) t4[e] = 4 * g + e < NQ ? yq[(4 * g + e) < NQ ? 4 * g + e : 0] : 0.f;
             quad_transpose4(t4, lane);
             const int q = 4 * g + j;
-            const int r = rq + 8 * q, sm = r & 15, pos = r >> 4;
+            const int r = rq + RQN * q, sm = r & 15, pos = r >> 4;
             if (q < NQ && sm < ns) st_out4(a.out_f32, (size_t)((b0 + sm) * LOUT + pos) * a.ldo + c4, make_float4(t4[0], t4[1], t4[2], t4[3]), 1);
         }
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int r = rq + 8 * q, sm = r & 15, pos = r >> 4;
+        const int r = rq + RQN * q, sm = r & 15, pos = r >> 4;
         const float y = yq[q];
         if (!a.pf.wt && sm < ns) st_out(a.out_f32, (size_t)((b0 + sm) * LOUT + pos) * a.ldo + gn, y, 0);
         const _Float16 hi = (_Float16)y;
@@ -1206,15 +1210,16 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
         __syncthreads();
         // the next layer's tiles: down -> one tile of 3 positions x 16 samples (rows as here); up -> two tiles of 6 positions x
         // 8 samples (tile 2 mt + (sample >> 3), row position * 8 + (sample & 7)); item = (plane, k-quarter, row) = 16 bytes
-        for (int i = tid; i < 2 * 4 * ROUT; i += 256) {
-            const int pl = i / (4 * ROUT), within = i - pl * 4 * ROUT, kq = within / ROUT, r = within - kq * ROUT;
+        constexpr int KQW = 4 / NH;              // k-quarters (8 channels = one 16-byte item) of this workgroup's columns
+        for (int i = tid; i < 2 * KQW * ROUT; i += 256) {
+            const int pl = i / (KQW * ROUT), within = i - pl * KQW * ROUT, kq = within / ROUT, r = within - kq * ROUT;
             const uint4 t4 = *reinterpret_cast<const uint4*>(tw + pl * ROUT * TP + r * TP + kq * 4);
             size_t dst;
-            if constexpr (!UP) dst = ((size_t)mt * a.NT + nt) * 192 + kq * 48 + r;
+            if constexpr (!UP) dst = ((size_t)mt * a.NT + nt) * 192 + (nbh * KQW + kq) * 48 + r;
             else {
                 const int sm = r & 15, pos = r >> 4, tile = 2 * mt + (sm >> 3);
                 if (tile * 8 >= a.Bp) continue;                  // (a ragged batch: the second 8-sample tile does not exist)
-                dst = ((size_t)tile * a.NT + nt) * 192 + kq * 48 + pos * 8 + (sm & 7);
+                dst = ((size_t)tile * a.NT + nt) * 192 + (nbh * KQW + kq) * 48 + pos * 8 + (sm & 7);
             }
             st_out4(a.out_planes, pl * a.out_pstride + dst, t4, a.pf.wt);
         }

@@ -91,7 +91,7 @@ int  cindm_unet1d_finalize(cindm_unet1d* h, void* stream);
  * are the fast path.  Keys (round 6: 24; DESIGN.md section 4.6 lists what was removed and why):
  *   "mfma_f32" (1 = exact fp32 MFMA kernels instead of the split-fp16 ones), "local_gn", "attn_site", "attn_head" (0 / 1 / 2),
  *   "level0" (master switch of the level kernels), "level1" (0 / 1 / 2 samples per workgroup), "ups_last", "ups_tail", "dconv", "dconv2",
- *   "dresample", "l2_prefetch" (launches touch their successor's weights), "ws_alias", "pingpong" (the sample loops keep t / step index /
+ *   "dresample" (0 / 1 / 2: general kernel / 32 / 16-or-32 columns per workgroup), "l2_prefetch" (launches touch their successor's weights), "ws_alias", "pingpong" (the sample loops keep t / step index /
  *   epochs in two slots advanced by the step's update), "fuse_update" (plain single-model steps apply the update inside the last U-Net
  *   kernel), "fuse_gather" (time composition of two-body states: the first U-Net kernel reads the state's windows in place),
  *   "taps" (1 = block outputs that live only inside a level kernel are also stored for cindm_unet1d_tap; off on the sampling path),

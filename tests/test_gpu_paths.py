@@ -32,6 +32,7 @@ PATHS_1D = [
     {"pingpong": 0},                      # step counter / exchange epochs advanced by step_counter_kernel (one more launch per step)
     {"dconv2": 0},                        # deep-level blocks as two dconv_kernel launches (no in-launch all-gather)
     {"dresample": 0},                     # deep-level resampling convolutions on conv_gemm_h3_kernel<3 | 4>
+    {"dresample": 1},                     # ... on dresample_kernel with 32 columns per workgroup at every batch size (default: 16 below 512 rows)
     {"dconv": 0},                         # deep levels on conv_gemm_h3_kernel
     {"attn_head": 0},                     # deep attention sites on attn1d_site_h3_kernel
     {"attn_head": 2},                     # ... all of them on attn1d_head_kernel
