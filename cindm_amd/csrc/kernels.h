@@ -2550,7 +2550,14 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
             xin[q] = *reinterpret_cast<const float4*>(src);
         }
     }
-    float pvr[14];                                                       // requested now, written to LDS after the zero fill
+    // (round 6) the LDS zero fill HERE, while the scalar load of t is on its way: the parameter loads below need t for the time-bias row and
+    // the wave stalls in front of them until it arrives (in-order issue) -- behind them the zero fill was 0.5 us in front of the first barrier
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = tid; i < 2 * ROWS1 * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_sched_barrier(0);
+    float pvr[14];                                                       // requested now, written to LDS after the noise generation
     if (tid < CB) {
         const float* src[8] = {a.bc[0], a.gam[0], a.bet[0], a.bc[1], a.gam[1], a.bet[1], a.tb0 + (size_t)t_now * a.tb_ld, a.br0};
 #pragma unroll
@@ -2569,9 +2576,24 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     // wave w takes slots 32 w ..), parked in R -- free until block 1's output goes there -- and picked up by wave 0 after barrier 4.
     // At the kernel's tail (one wave, after the last barrier) Philox + Box-Muller were 2.5 us of a 3 us phase (phase clocks, round 4).
     const int tu_z = a.fuse_upd ? step_scalar(a.upd.t_ptr, a.upd.t_imm) : 0;
-    StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};      // the step's schedule values (scalar loads; DDIM: its table row)
-    if (a.fuse_upd) sc = plain_step_coefs(a.upd, tu_z);
-    const bool gen_z = a.fuse_upd && plain_step_draws(a.upd, sc, tu_z);
+    StepCoefs sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};      // the step's schedule values (DDIM: its table row, scalar loads)
+    // DDPM: the five schedule values of step t are VECTOR loads of wave 0, consumed where the update is applied.  As scalar loads at this
+    // point (through round 6) they sat behind the scalar load of t -- two serial round trips to memory, lines nobody has read for 32 steps --
+    // and `sigma = expf(.)` waited for them HERE, in front of the noise generation, the LDS zero fill and the first barrier (a barrier waits
+    // lgkmcnt(0): scalar loads included): this phase measured 4.2 - 4.6 us with the update fused against 2.7 - 3.0 us without
+    // (3.9 us now; same-box with the zero fill moved up as well: 313.7 -> 311.9 us per step).
+    const bool sc_vec = a.fuse_upd && !a.upd.ddim_tab;
+    float scv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.fuse_upd && !sc_vec) sc = plain_step_coefs(a.upd, tu_z);
+    if (sc_vec && w == 0) {
+        const ComposeArgs& u = a.upd;
+        const float* tab[5] = {u.objective == 2 ? u.sqrt_ac : u.sqrt_recip, u.objective == 2 ? u.sqrt_1mac : u.sqrt_recipm1, u.coef1, u.coef2, u.logvar};
+#pragma unroll
+        for (int i = 0; i < 5; ++i)         // (buffer loads: a uniform address would be turned back into a scalar load)
+            scv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tab[i]), 0, 0x7ffffff0u, 0x00020000), (unsigned)tu_z * 4u, 0, 0));
+    }
+    const bool gen_z = a.fuse_upd && (sc_vec ? (a.upd.add_noise && tu_z > 0) : plain_step_draws(a.upd, sc, tu_z));
     if (gen_z && lane < 32) {
         const ComposeArgs& u = a.upd;
         const int s = 32 * w + lane, nt = s >> 6, ln = s & 63, n = nt * 16 + (ln & 15), q4 = (ln >> 4) * 4;
@@ -2589,9 +2611,6 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
             reinterpret_cast<float4*>(R)[s] = z;
         }
     }
-    for (int i = tid; i < 2 * ROWS1 * XPB / 16; i += 256) reinterpret_cast<float4*>(&XI[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < 4 * ROWS1 * QPB / 16; i += 256) reinterpret_cast<float4*>(&Q[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < 4 * ROWS2 * PPB / 16; i += 256) reinterpret_cast<float4*>(&P[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < CB) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) PVB[i][tid] = pvr[i];
@@ -2822,6 +2841,10 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         // layer ago and their noise (zq) was generated at the top of the kernel, so the update adds a few FMAs to this tail.
         const ComposeArgs& u = a.upd;
         const int tu = tu_z;
+        if (sc_vec) {                        // plain_step_coefs' expressions on the vector-loaded values
+            sc.cx = scv[0]; sc.co = scv[1]; sc.k1 = scv[2]; sc.k2 = scv[3];
+            sc.sigma = (u.add_noise && tu > 0) ? expf(0.5f * scv[4]) : 0.f;
+        }
         f32x4 e[1][2];
         lvlm_conv<1, 2, 1, 2, PPB, 8>(ring, reinterpret_cast<const float4*>(a.Wf), P[0][0], P[0][1], 16, 1, 2, ROWS2 - 1, lane, e);
         const float4 bf = *reinterpret_cast<const float4*>(&PV[13][lq * 4]);
