@@ -2585,14 +2585,21 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
     const bool sc_vec = a.fuse_upd && !a.upd.ddim_tab;
     float scv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (a.fuse_upd && !sc_vec) sc = plain_step_coefs(a.upd, tu_z);
-    if (sc_vec && w == 0) {
+    {   // EVERY wave issues exactly five loads, whatever the launch does (no update fused / DDIM: five reads of the final weights' first word):
+        // behind a branch with an unknown number of requests the compiler waits for every OLDER load with a count that covers these too
         const ComposeArgs& u = a.upd;
         const float* tab[5] = {u.objective == 2 ? u.sqrt_ac : u.sqrt_recip, u.objective == 2 ? u.sqrt_1mac : u.sqrt_recipm1, u.coef1, u.coef2, u.logvar};
 #pragma unroll
         for (int i = 0; i < 5; ++i)         // (buffer loads: a uniform address would be turned back into a scalar load)
             scv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tab[i]), 0, 0x7ffffff0u, 0x00020000), (unsigned)tu_z * 4u, 0, 0));
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc_vec ? tab[i] : a.Wf), 0, 0x7ffffff0u, 0x00020000), sc_vec ? (unsigned)tu_z * 4u : 0u, 0, 0));
     }
+    // (seed, sample offset) of the sample loops: SCALAR loads, requested here with t.  As `u.dyn ? u.dyn[0] : u.seed` inside the noise
+    // block they were vector loads waited for with vmcnt(0) -- i.e. behind the 160 KB of weight fragments, the input rows and the
+    // parameter vectors requested above: the noise generation started when ALL of those had arrived (tools/isa_audit.py).
+    typedef const unsigned long long __attribute__((address_space(4))) cindm_cu64;
+    const uint64_t dseed = (a.fuse_upd && a.upd.dyn) ? (uint64_t)*(cindm_cu64*)(const void*)a.upd.dyn : a.upd.seed;
+    const int64_t dsoff = (a.fuse_upd && a.upd.dyn) ? (int64_t)*(cindm_cu64*)(const void*)(a.upd.dyn + 1) : a.upd.sample_off;
     const bool gen_z = a.fuse_upd && (sc_vec ? (a.upd.add_noise && tu_z > 0) : plain_step_draws(a.upd, sc, tu_z));
     if (gen_z && lane < 32) {
         const ComposeArgs& u = a.upd;
@@ -2602,8 +2609,6 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
             // (explicit tapes are indexed by t in the DDPM loop and by the step index in the DDIM loop)
             if (u.noise) z = *reinterpret_cast<const float4*>(u.noise + (size_t)(u.ddim_tab ? sc.sidx : tu_z) * u.noise_t_stride + ((size_t)b * L2 + n) * a.F + q4);
             else {
-                const uint64_t dseed = u.dyn ? (uint64_t)u.dyn[0] : u.seed;
-                const int64_t dsoff = u.dyn ? (int64_t)u.dyn[1] : u.sample_off;
                 float z4[4];
                 counter_normal4(dseed, (uint64_t)(dsoff + b), (uint32_t)tu_z, (uint32_t)((n * a.F + q4) >> 2), z4);
                 z = make_float4(z4[0], z4[1], z4[2], z4[3]);
@@ -2842,6 +2847,10 @@ __global__ __launch_bounds__(256) void ups_last_kernel(const UpsLastArgs a) {
         const ComposeArgs& u = a.upd;
         const int tu = tu_z;
         if (sc_vec) {                        // plain_step_coefs' expressions on the vector-loaded values
+            // (the empty asm pins the values' first use HERE: left alone the compiler evaluates expf(.) right behind the loads, i.e. waits for
+            // them -- and for every older request of the wave -- at the top of the kernel)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(scv[i]));
             sc.cx = scv[0]; sc.co = scv[1]; sc.k1 = scv[2]; sc.k2 = scv[3];
             sc.sigma = (u.add_noise && tu > 0) ? expf(0.5f * scv[4]) : 0.f;
         }
