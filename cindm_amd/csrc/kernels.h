@@ -1384,6 +1384,9 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
     constexpr int RPP = 64 / LPR;
     constexpr int NPASS = (RW + RPP - 1) / RPP;
     const int lrow = lane / LPR, lcol = lane % LPR;
+    PfRegs pfr;
+    l2_prefetch_early(a.pf, pfr);          // (the A/B path only -- `tune` bit 0 --, in front of every other request)
+    __builtin_amdgcn_sched_barrier(0);
     float4 xr[NPASS][CH];
     bool okr[NPASS];
 #pragma unroll
@@ -1402,16 +1405,20 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
 #pragma unroll
     for (int s = 0; s < 6; ++s) tile[s] = (s >> 1) * 8 + 2 * w + (s & 1);
     // weight ring: PF k32-steps in flight, [tile][plane]
+    // (round 6, as attn1d_head_kernel) half of the ring in front of the LayerNorm, the rest between its passes: requests issue in order against
+    // the L1 path's back-pressure, and with all of them in front the LayerNorm's VALU work started when the last one was issued
     float4 wr[PF][6][2];
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
+    auto load_ring = [&](int p) {
 #pragma unroll
         for (int s = 0; s < 6; ++s)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
                 wr[p][s][pl] = (p < K32) ? Wq4[(((size_t)tile[s] * K32 + p) * 2 + pl) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    PfRegs pfr;
-    l2_prefetch_early(a.pf, pfr);
+    };
+    constexpr int PFRONT = (PF + 1) / 2;
+#pragma unroll
+    for (int p = 0; p < PFRONT; ++p) load_ring(p);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- LayerNorm (as in attn1d_site_kernel), result split into the two fp16 planes ----
     {
@@ -1451,6 +1458,13 @@ __global__ __launch_bounds__(256) void attn1d_site_h3_kernel(const AttnSiteArgs 
                     *reinterpret_cast<half4v*>(&Yp[1][off]) = lo;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PFRONT + r < PF) load_ring(PFRONT + r);
+            if (r == NPASS - 1) {
+#pragma unroll
+                for (int p = PFRONT + NPASS; p < PF; ++p) load_ring(p);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();

@@ -1281,6 +1281,9 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
     int tile[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) tile[s] = (s >> 1) * 8 + 2 * hd + (s & 1);
+    PfRegs pfr;
+    l2_prefetch_early(a.pf, pfr);          // (the A/B path only -- `tune` bit 0; in front of everything: see below)
+    __builtin_amdgcn_sched_barrier(0);
     // ---- the group's rows first (round 4): they come from the previous launch, i.e. from memory, and the LayerNorm needs them
     // before anything else -- requested behind the 56 KB of weight fragments per wave they arrived behind them (loads return
     // in order): the LayerNorm phase measured 3 us in the replayed step ----
@@ -1302,28 +1305,25 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
 #pragma unroll
     for (int m = 0; m < CH; ++m) gv[m] = *reinterpret_cast<const float4*>(a.g + 4 * (lcol + LPR * m));
     // this wave's k32 steps of the head's six tiles: everything in flight at once (KPW * 12 KiB per wave)
+    // (round 6) ... in two halves: the first in front of the LayerNorm (it is on its way while the rows are), the rest k-step by k-step BETWEEN
+    // the LayerNorm's passes: a wave issues in order and 48 requests take ~2 us to issue against the back-pressure of the L1 path -- with all
+    // of them in front, the LayerNorm's 1.6 us of VALU work started when the last one was issued.
     float4 wr[KPW][6][2];
-#pragma unroll
-    for (int j = 0; j < KPW; ++j)
+    auto load_wq = [&](int j) {
 #pragma unroll
         for (int s = 0; s < 6; ++s)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
                 wr[j][s][pl] = Wq4[(((size_t)tile[s] * K32 + (4 * j + w)) * 2 + pl) * 64 + lane];
-    // output-projection fragments of this wave's tiles (rows hd * C/4 + ..): CT4 tiles per workgroup, CT4 / 4 per wave
-    constexpr int TPW = CT4 / 4;
-    static_assert(CT4 % 4 == 0, "output tiles split evenly over the waves");
-    const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
-    float4 wo[TPW][4][2];
+    };
+    constexpr int KFRONT = (KPW + 1) / 2;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                wo[t][k][pl] = Wo4[(((size_t)(hd * CT4 + w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane];
-    PfRegs pfr;
-    l2_prefetch_early(a.pf, pfr);
+    for (int j = 0; j < KFRONT; ++j) load_wq(j);
+    // (round 6) NOTHING else is requested in front of the LayerNorm: with the 16 output-projection fragments and the A/B path's conditional
+    // touches here the wave had 74+ requests outstanding -- more than vmcnt can count -- behind a region with an unknown number of loads, and
+    // the LayerNorm's wait for the group's rows (the OLDEST requests) was a vmcnt(0): it started when the last weight fragment had arrived
+    // (tools/isa_audit.py).  58 requests now, the rows' wait is exact, the LayerNorm runs while the q | k | v fragments stream in.
+    __builtin_amdgcn_sched_barrier(0);
     PH(1);
 
     // ---- LayerNorm of the group's positions -> split-fp16 planes (as attn1d_site_h3_kernel) ----
@@ -1364,8 +1364,29 @@ __global__ __launch_bounds__(256) void attn1d_head_kernel(const AttnHeadArgs a) 
                     *reinterpret_cast<half4v*>(&Yp[1][off]) = lo;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (KFRONT + r < KPW) load_wq(KFRONT + r);
+            if (r == NPASS - 1) {
+#pragma unroll
+                for (int j = KFRONT + NPASS; j < KPW; ++j) load_wq(j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // output-projection fragments of this wave's tiles (rows hd * C/4 + ..): CT4 tiles per workgroup, CT4 / 4 per wave
+    constexpr int TPW = CT4 / 4;
+    static_assert(CT4 % 4 == 0, "output tiles split evenly over the waves");
+    const float4* Wo4 = reinterpret_cast<const float4*>(a.Wo);
+    float4 wo[TPW][4][2];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                wo[t][k][pl] = Wo4[(((size_t)(hd * CT4 + w * TPW + t) * 4 + k) * 2 + pl) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     PH(2);
 
