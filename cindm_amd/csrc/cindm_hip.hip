@@ -105,7 +105,8 @@ struct cindm_unet1d {
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
-    struct WReg { size_t off[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; };      // byte offsets into blob
+    struct WReg { size_t off[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS];
+                  unsigned xmask[PF_REGIONS]; unsigned nrep[PF_REGIONS]; unsigned rstride[PF_REGIONS]; };      // byte offsets into blob; pieces: kernels.h Pf
     std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag, [2] prefetch sink, [8] second epoch slot
     int epoch_slot = 0;                    // which epoch slot (0 / 8) the forward being emitted reads (ping-pong sample loop)
@@ -671,6 +672,7 @@ struct Emitter {
             for (int k = 0; k < PF_REGIONS; ++k) {
                 pf.base[k] = reinterpret_cast<const char*>(h->blob) + nx.off[k];
                 pf.bytes[k] = nx.bytes[k]; pf.stride[k] = nx.stride[k];
+                pf.xmask[k] = nx.xmask[k]; pf.nrep[k] = nx.nrep[k]; pf.rstride[k] = nx.rstride[k];
             }
             pf.sink = h->epoch_dev + 2;
             pf.late = (h->O("tune") & 1) ? 0 : 1;      // round 6: touches a few microseconds before the launch ends (tune bit 0: round 5's, at its head)
@@ -968,9 +970,15 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
     {   // L2 warm-up registration: both convolutions' weights, tiled by n-tile
         cindm_unet1d::WReg r{};
         const size_t t0 = w0.sz * 4 / (size_t)NT, t1 = w1.sz * 4 / (size_t)NT;
-        if (NT % 8 == 0 && !(h->O("tune") & 1)) {
-            // round 6: conv A's fragments only, n-tiles x AND x + 8 of XCD x (through round 5: tile x of conv A and of conv B -- half of a
-            // 512-channel layer's tiles were never warmed, and conv B's lines were touched a whole launch phase before their use)
+        if (NT % 4 == 0 && tiles % 2 == 0 && !(h->O("tune") & 1)) {
+            // round 6, with dconv2_kernel's workgroup mapping: XCD x streams the n-tiles (x & 3) + 4 k -- conv A's fragments of those, as
+            // NT / 4 pieces of one region
+            r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
+            r.xmask[0] = 3; r.nrep[0] = (unsigned)(NT / 4); r.rstride[0] = (unsigned)(4 * t0);
+        }
+        else if (NT % 8 == 0 && !(h->O("tune") & 1)) {
+            // (identity mapping: an odd number of m-tiles) conv A's fragments, n-tiles x AND x + 8 of XCD x (through round 5: tile x of conv A
+            // and of conv B -- half of a 512-channel layer's tiles were never warmed, and conv B's lines were touched a whole phase early)
             r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
             if (NT >= 16) { r.off[1] = w0.off * 4 + 8 * t0; r.bytes[1] = (unsigned)t0; r.stride[1] = (unsigned)t0; }
         }

@@ -143,7 +143,8 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 // outputs written through: conv A's tiles x and x + 8 are the two regions of a dconv2 successor; adding conv B's tiles (touched a
 // whole phase before their use) cost 1.2 us per step again, adding the riding 1x1's changed nothing.  Two it stays.)
 constexpr int PF_REGIONS = 2;
-struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt; };      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
+struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt;
+            unsigned xmask[PF_REGIONS]; unsigned nrep[PF_REGIONS]; unsigned rstride[PF_REGIONS]; };      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
 struct PfRegs { unsigned v[PF_REGIONS][2]; };
 // (Every caller is a 256-thread kernel.  Round 4: the block size is a CONSTANT here.  `blockDim.x` is a 16-bit VECTOR-memory load
 // from the dispatch packet: its use made hipcc wait `vmcnt(0)` in the middle of this function -- vector loads return in order, so
@@ -156,15 +157,21 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
     const int nshare = (int)((gridDim.x * gridDim.y * gridDim.z + 7) >> 3);
 #pragma unroll
     for (int k = 0; k < PF_REGIONS; ++k) {
-        const int lines = (int)(p.bytes[k] >> 7);
+        // a region = nrep pieces of `bytes` each, `rstride` apart (0 / 1 piece: one range), at base + (xcd & xmask) * stride
+        // (xmask 0 = 7).  Pieces: the n-tiles (x & 3) + 4 k that an XCD streams under dconv2_kernel's workgroup mapping.
+        const int lpp = (int)(p.bytes[k] >> 7), nrep = p.nrep[k] ? (int)p.nrep[k] : 1;
+        const int lines = lpp * nrep;
         const int per = (lines + nshare - 1) / nshare;
-        const char* base = p.base[k] + (size_t)xcd * p.stride[k];
+        const char* base = p.base[k] + (size_t)(xcd & (p.xmask[k] ? (int)p.xmask[k] : 7)) * p.stride[k];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int li = (int)threadIdx.x + BLOCK * i;
             const int line = rank * per + li;
             r.v[k][i] = 0u;
-            if (li < per && line < lines) r.v[k][i] = *reinterpret_cast<const unsigned*>(base + ((size_t)line << 7));
+            if (li < per && line < lines) {
+                const int piece = nrep > 1 ? line / lpp : 0, within = line - piece * lpp;
+                r.v[k][i] = *reinterpret_cast<const unsigned*>(base + (size_t)piece * p.rstride[k] + ((size_t)within << 7));
+            }
         }
     }
 }
