@@ -970,11 +970,17 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
     {   // L2 warm-up registration: both convolutions' weights, tiled by n-tile
         cindm_unet1d::WReg r{};
         const size_t t0 = w0.sz * 4 / (size_t)NT, t1 = w1.sz * 4 / (size_t)NT;
-        if (NT % 4 == 0 && tiles % 2 == 0 && !(h->O("tune") & 1)) {
+        // dconv2_kernel's workgroup mapping: a column of NT workgroups spreads over XS XCDs, 4 workgroups on each (NT = 16: XS = 4, NT = 8:
+        // XS = 2 -- scanned, same process: config 2 316.6 us per step with the identity mapping, 309.4 with XS = 4 / 4, 307.3 with 4 / 2, 307.7
+        // with 2 / 2, 312.6 with 4 / 8; config 3 799.8 / 779.6 / 774.9); a coarser spread where the number of m-tiles does not divide
+        int XS = NT / 4;
+        while (XS >= 1 && XS < 8 && tiles % (8 / XS) != 0) XS *= 2;
+        const bool remap = (XS == 2 || XS == 4) && NT % XS == 0 && tiles % (8 / XS) == 0;
+        if (remap && !(h->O("tune") & 1)) {
             // round 6, with dconv2_kernel's workgroup mapping: XCD x streams the n-tiles (x & 3) + 4 k -- conv A's fragments of those, as
             // NT / 4 pieces of one region
             r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
-            r.xmask[0] = 3; r.nrep[0] = (unsigned)(NT / 4); r.rstride[0] = (unsigned)(4 * t0);
+            r.xmask[0] = (unsigned)(XS - 1); r.nrep[0] = (unsigned)(NT / XS); r.rstride[0] = (unsigned)(XS * t0);
         }
         else if (NT % 8 == 0 && !(h->O("tune") & 1)) {
             // (identity mapping: an odd number of m-tiles) conv A's fragments, n-tiles x AND x + 8 of XCD x (through round 5: tile x of conv A
@@ -1010,6 +1016,7 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
         d.xchg_a = xa; d.xchg_b = xb; d.epoch = h->ep(); d.err_flag = h->epoch_dev + 1;
         d.stress = h->O("stress"); d.dbg = h->O("dbg") >= 30 ? h->O("dbg") - 30 : 0;
         d.tune = h->O("tune");
+        d.xs = remap ? XS : 0;
         d.ph = E.ph_next("dconv2<" + std::to_string(L) + "," + std::to_string(k0) + "," + std::to_string(k1) + "," + (identity ? "false" : "true") + "," +
                          std::to_string(kb) + "> " + p);
         const dim3 grid((unsigned)NT, (unsigned)tiles);

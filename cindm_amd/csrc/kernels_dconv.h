@@ -473,6 +473,7 @@ struct Dconv2Args {
     Pf pf; int stress; int dbg;
     PhaseBuf ph;                                          // phase clocks (profiling builds; kernels.h)
     int tune;                                             // experiment switches for same-box A/B runs (option "tune"; 0 = the shipped choice)
+    int xs;                                               // XCDs a column of workgroups spreads over (0: identity mapping)
 };
 
 // (experiment builds -DCINDM_KPROF, library variant "kprof": the phase clocks of dconv2_kernel go INSIDE phase A's K loop -- marks 2 + 2j /
@@ -506,17 +507,18 @@ __global__ __launch_bounds__(256) void dconv2_kernel(const Dconv2Args a) {
     const unsigned tag = (unsigned)uniform_word(a.epoch);
     const int err_seen = uniform_word(a.err_flag);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // Workgroup -> (n-tile, m-tile), round 6: XCD x (= block index % 8, observed) hosts the n-tiles (x & 3) + 4 k of the m-tiles of parity
-    // x >> 2, instead of n-tile(s) x (, x + 8) of EVERY m-tile.  A column's y0 and activation tile are then fetched by 4 XCDs, NT / 4
-    // workgroups each, instead of by 8 XCDs with NT / 8 each: the second and later workgroups of an XCD find the lines in its L2 (sc1 loads
-    // are L2-served) and half as many bytes cross the fabric -- phase B's K loop, bound by that fetch, 3.96 -> 3.64 us at C = 512.  The
-    // pair-exchange partners nt ^ 1 stay on DIFFERENT XCDs: on the same one the exchange took 1.6 us instead of 0.65 (the first form tried,
-    // n-tiles 4 (x & 3) + k: +15 us per step).  A bijection of the grid when NT % 4 == 0 and the number of m-tiles is even; identity otherwise.
+    // Workgroup -> (n-tile, m-tile), round 6: a column's NT workgroups spread over XS = a.xs XCDs (block index % 8 = XCD, observed), NT / XS = 4
+    // on each -- XCD x hosts the n-tiles (x % XS) + XS k of the m-tiles congruent to x / XS modulo 8 / XS -- instead of over all 8 with n-tile(s)
+    // x (, x + 8) of EVERY m-tile.  A column's y0 and activation tile are then fetched by XS XCDs whose second and later workgroups find the
+    // lines in the XCD's L2 (sc1 loads are L2-served): fewer bytes cross the fabric -- phase B's K loop, bound by that fetch, 3.96 -> 3.64 us
+    // at C = 512.  The pair-exchange partners nt ^ 1 stay on DIFFERENT XCDs: on the same one the exchange took 1.6 us instead of 0.65 (the
+    // first form tried, n-tiles 4 (x & 3) + k: +15 us per step).  The host picks XS (a bijection of the grid needs NT % XS == 0 and the
+    // number of m-tiles % (8 / XS) == 0; 0 = identity) and registers the warm-up pieces to match (emit_rtb_dconv2).
     int nt = blockIdx.x, mt = blockIdx.y;
 #ifndef CINDM_NO_XCD_REMAP
-    if ((gridDim.x & 3) == 0 && (gridDim.y & 1) == 0) {
-        const int bl = blockIdx.x + gridDim.x * blockIdx.y, xcd = bl & 7, sl = bl >> 3, q4 = gridDim.x >> 2;
-        nt = (sl % q4) * 4 + (xcd & 3); mt = (xcd >> 2) + 2 * (sl / q4);
+    if (a.xs > 0) {
+        const int XS = a.xs, bl = blockIdx.x + gridDim.x * blockIdx.y, xcd = bl & 7, sl = bl >> 3, q4 = gridDim.x / XS;
+        nt = (sl % q4) * XS + (xcd & (XS - 1)); mt = (xcd / XS) + (8 / XS) * (sl / q4);
     }
 #endif
     const int b0 = mt * S;
