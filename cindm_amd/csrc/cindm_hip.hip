@@ -672,10 +672,10 @@ struct Emitter {
             for (int k = 0; k < PF_REGIONS; ++k) {
                 pf.base[k] = reinterpret_cast<const char*>(h->blob) + nx.off[k];
                 pf.bytes[k] = nx.bytes[k]; pf.stride[k] = nx.stride[k];
-                pf.xmask[k] = nx.xmask[k]; pf.nrep[k] = nx.nrep[k]; pf.rstride[k] = nx.rstride[k];
             }
             pf.sink = h->epoch_dev + 2;
-            pf.late = (h->O("tune") & 1) ? 0 : 1;      // round 6: touches a few microseconds before the launch ends (tune bit 0: round 5's, at its head)
+            pf.late = ((h->O("tune") & 1) ? 0 : 1) | (int)((nx.xmask[0] & 15u) << 8) | (int)((nx.nrep[0] & 255u) << 16);      // (+ region 0's piece layout: kernels.h Pf)
+            // (bit 0, round 6: touches a few microseconds before the launch ends; tune bit 0: round 5's, at its head)
         }
         if (!dry && !pf_out) pf.wt = (h->O("tune") & 2) ? 0 : 1;        // round 6: the launch's outputs are written through (kernels.h st_out; tune bit 1: round 5's plain stores)
         ++pf_idx;
@@ -1355,8 +1355,20 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
         const int Bp = (int)E.rows, NT = x.C / 32, tiles = (Bp + 15) / 16;
         E.planes(out);
         ++E.launches;
+        // workgroup mapping (kernels_dconv.h): a column's 2 NT (NT) workgroups on XS XCDs; n-tile idx % NT of XCD x: idx = x % XS (mod XS)
+        const bool half = h->O("dresample") >= 2 && NT % 8 == 0 && NT * tiles < 256;
+        // (2 XCDs per column: 305.0 -> 303.7 us per step, config 3 768.0 -> 764.7; 4: 304.7 / 768.2)
+        int XS = 2;
+        while (XS >= 1 && XS < 8 && tiles % (8 / XS) != 0) XS *= 2;
+        if (!(XS == 2 || XS == 4) || (half ? 2 * NT : NT) % XS != 0 || (h->O("tune") & 1)) XS = 0;
         Pf pf;
-        E.pf_tiled(pf, w, NT);
+        if (XS) {
+            cindm_unet1d::WReg r{};
+            const size_t t0 = w.sz * 4 / (size_t)NT;
+            r.off[0] = w.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
+            r.xmask[0] = (unsigned)(XS - 1); r.nrep[0] = (unsigned)(NT / XS); r.rstride[0] = (unsigned)(XS * t0);
+            E.pf_step(pf, r);
+        } else E.pf_tiled(pf, w, NT);
         if (!E.dry) {
             DresArgs d;
             std::memset(&d, 0, sizeof(d));
@@ -1366,7 +1378,7 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
             d.ph = E.ph_next(std::string("dresample<") + (up ? "up" : "down") + "> " + p);
             // "dresample" = 2 (default): 16 columns per workgroup where 32 would leave CUs idle (2 NT x tiles = 256 workgroups at 256 rows:
             // 320.2 -> 317.2 us per step; at 768 rows the 32-column grid is 384 workgroups already and the split costs 2 us); 1: always 32
-            const bool half = h->O("dresample") >= 2 && NT % 8 == 0 && NT * tiles < 256;
+            d.xs = XS;
             const dim3 grid((unsigned)(half ? 2 * NT : NT), (unsigned)tiles);
             E.prof_begin(up ? 3 : 2, 2.0 * Bp * Lout * x.C * (double)x.C * (up ? 2.0 : 3.0));
             if (E.prof) { E.prof->back().gx = grid.x; E.prof->back().gy = grid.y; E.prof->back().nstage = d.nch; }

@@ -143,8 +143,11 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 // outputs written through: conv A's tiles x and x + 8 are the two regions of a dconv2 successor; adding conv B's tiles (touched a
 // whole phase before their use) cost 1.2 us per step again, adding the riding 1x1's changed nothing.  Two it stays.)
 constexpr int PF_REGIONS = 2;
-struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt;
-            unsigned xmask[PF_REGIONS]; unsigned nrep[PF_REGIONS]; unsigned rstride[PF_REGIONS]; };      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
+struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt; };
+// (`late` also carries region 0's piece layout: bits 8-11 xmask, bits 16-23 nrep -- see l2_prefetch.  The struct keeps the size it had through
+// round 5 ON PURPOSE: with three more words per region in it, i.e. in every kernel's argument block, the two-chains-on-one-device test failed on
+// four of six fresh boxes -- one sample of the demoted chain off by 2e-5 -- and passed again without them; the cause is not understood)
+__device__ __forceinline__ bool pf_late(const Pf& p) { return (p.late & 1) != 0; }      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
 struct PfRegs { unsigned v[PF_REGIONS][2]; };
 // (Every caller is a 256-thread kernel.  Round 4: the block size is a CONSTANT here.  `blockDim.x` is a 16-bit VECTOR-memory load
 // from the dispatch packet: its use made hipcc wait `vmcnt(0)` in the middle of this function -- vector loads return in order, so
@@ -157,12 +160,14 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
     const int nshare = (int)((gridDim.x * gridDim.y * gridDim.z + 7) >> 3);
 #pragma unroll
     for (int k = 0; k < PF_REGIONS; ++k) {
-        // a region = nrep pieces of `bytes` each, `rstride` apart (0 / 1 piece: one range), at base + (xcd & xmask) * stride
-        // (xmask 0 = 7).  Pieces: the n-tiles (x & 3) + 4 k that an XCD streams under dconv2_kernel's workgroup mapping.
-        const int lpp = (int)(p.bytes[k] >> 7), nrep = p.nrep[k] ? (int)p.nrep[k] : 1;
+        // region 0 may be nrep PIECES of `bytes` each, (xmask + 1) * stride apart, at base + (xcd & xmask) * stride: the n-tiles
+        // (x % XS) + XS k that an XCD streams under dconv2_kernel's / dresample_kernel's workgroup mapping (xmask = XS - 1)
+        const int xmask = k == 0 ? (p.late >> 8) & 15 : 0, nrep = (k == 0 && ((p.late >> 16) & 255)) ? (p.late >> 16) & 255 : 1;
+        const int lpp = (int)(p.bytes[k] >> 7);
         const int lines = lpp * nrep;
         const int per = (lines + nshare - 1) / nshare;
-        const char* base = p.base[k] + (size_t)(xcd & (p.xmask[k] ? (int)p.xmask[k] : 7)) * p.stride[k];
+        const char* base = p.base[k] + (size_t)(xmask ? (xcd & xmask) : xcd) * p.stride[k];
+        const size_t rstride = (size_t)(xmask + 1) * p.stride[k];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int li = (int)threadIdx.x + BLOCK * i;
@@ -170,7 +175,7 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
             r.v[k][i] = 0u;
             if (li < per && line < lines) {
                 const int piece = nrep > 1 ? line / lpp : 0, within = line - piece * lpp;
-                r.v[k][i] = *reinterpret_cast<const unsigned*>(base + (size_t)piece * p.rstride[k] + ((size_t)within << 7));
+                r.v[k][i] = *reinterpret_cast<const unsigned*>(base + (size_t)piece * rstride + ((size_t)within << 7));
             }
         }
     }
@@ -180,12 +185,12 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
 __device__ __forceinline__ void l2_prefetch_early(const Pf& p, PfRegs& r) {
 #pragma unroll
     for (int k = 0; k < PF_REGIONS; ++k) r.v[k][0] = r.v[k][1] = 0u;
-    if (!p.late) l2_prefetch(p, r);
+    if (!pf_late(p)) l2_prefetch(p, r);
 }
 // The late point of a kernel = right behind its LAST load request where there is one (vector loads return in order: a request that
 // is issued behind the touches waits for them, ~1 - 1.5 us from the Infinity Cache -- placed in front of a LayerNorm gain load they cost
 // level0_down 1.6 us), else behind its last K loop.
-__device__ __forceinline__ void l2_prefetch_late(const Pf& p, PfRegs& r) { if (p.late) l2_prefetch(p, r); }
+__device__ __forceinline__ void l2_prefetch_late(const Pf& p, PfRegs& r) { if (pf_late(p)) l2_prefetch(p, r); }
 __device__ __forceinline__ void l2_prefetch_done(const Pf& p, const PfRegs& r) {
     unsigned x = 0u;
 #pragma unroll

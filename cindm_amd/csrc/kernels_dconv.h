@@ -1064,6 +1064,7 @@ struct DresArgs {
     uint4* out_planes; size_t out_pstride;
     Pf pf;
     PhaseBuf ph;
+    int xs;                                      // XCDs a column of workgroups spreads over (0: identity mapping)
 };
 
 // NH: column split of an n-tile over workgroups -- 1: the workgroup owns all 32 columns (grid NT x tiles = 128 workgroups at 256 rows);
@@ -1082,7 +1083,13 @@ __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     PH_DECL;
     PH(0);                                    // phase clocks (profiling builds): 0 entry, 1 loads issued, 2 K loop, 3 reduce, 4 stores issued
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nt = NH == 1 ? (int)blockIdx.x : (int)blockIdx.x % a.NT, nbh = NH == 1 ? 0 : (int)blockIdx.x / a.NT, mt = blockIdx.y;
+    // (round 6, as dconv2_kernel) a column's workgroups spread over a.xs XCDs instead of all 8: its activation tile crosses the fabric a.xs times
+    int bx = blockIdx.x, mt = blockIdx.y;
+    if (a.xs > 0) {
+        const int XS = a.xs, bl = blockIdx.x + gridDim.x * blockIdx.y, xcd = bl & 7, sl = bl >> 3, q4 = gridDim.x / XS;
+        bx = (sl % q4) * XS + (xcd & (XS - 1)); mt = (xcd / XS) + (8 / XS) * (sl / q4);
+    }
+    const int nt = NH == 1 ? bx : bx % a.NT, nbh = NH == 1 ? 0 : bx / a.NT;
     const int b0 = mt * S, ns = min(S, a.Bp - b0);
     const int n = tid & (TNW - 1), rq = tid / TNW, gn = nt * TN + nbh * TNW + n;
 
