@@ -16,7 +16,7 @@ VARIANT = os.environ.get("CINDM_LIB_VARIANT", "")
 # question "what bounds the K loops": 1 = no MFMAs, 2 = every stage re-reads stage 0's weight fragments (L2-hot), 3 = both)
 _VARIANTS = {"": [], "prof": ["-DCINDM_PHASE_PROF"], "abl1": ["-DCINDM_PHASE_PROF", "-DCINDM_ABL=1"],
              "abl2": ["-DCINDM_PHASE_PROF", "-DCINDM_ABL=2"], "abl3": ["-DCINDM_PHASE_PROF", "-DCINDM_ABL=3"],
-             "kprof": ["-DCINDM_PHASE_PROF", "-DCINDM_KPROF"], "exp0": ["-DCINDM_NO_XCD_REMAP"]}
+             "kprof": ["-DCINDM_PHASE_PROF", "-DCINDM_KPROF"]}
 if VARIANT not in _VARIANTS:
     raise RuntimeError(f"unknown CINDM_LIB_VARIANT {VARIANT!r} (one of {sorted(_VARIANTS)})")
 EXTRA_FLAGS = _VARIANTS[VARIANT]
