@@ -591,3 +591,11 @@ def test_isa_handover_order_of_the_built_kernels(tmp_path):
     assert a.returncode == 0, a.stdout
     lines = [ln for ln in a.stdout.splitlines() if "dconv2_kernel" in ln]
     assert len(lines) >= 7 and all(" OK " in ln for ln in lines), a.stdout
+
+
+def test_graft_entry_build_checks_the_current_abi():
+    """__graft_entry__.build() compares the library's ABI word with the Python face's, not with a literal (round 6 bumped the ABI to 4 and a
+    literal 3 in build() would have failed the driver's build check)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "cindm_abi_version() == _ffi.ABI_VERSION" in src and not re.search(r"ABI_VERSION\s*==\s*\d", src)
