@@ -105,8 +105,7 @@ struct cindm_unet1d {
     bool use_level0 = true;                // the finest down level in one launch, level0_down_kernel (CINDM_LEVEL0=0 disables)
     bool use_h3_resample = true;           // stride-2 / transposed resampling convolutions on the split-fp16 kernel (CINDM_H3_RESAMPLE=0 disables)
     int launches = 0;
-    struct WReg { size_t off[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS];
-                  unsigned xmask[PF_REGIONS]; unsigned nrep[PF_REGIONS]; unsigned rstride[PF_REGIONS]; };      // byte offsets into blob; pieces: kernels.h Pf
+    struct WReg { size_t off[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; };      // byte offsets into blob
     std::vector<WReg> pf_table;            // per launch of one forward: the weights it streams (L2 warm-up of its predecessor)
     int* epoch_dev = nullptr;              // [0] per-forward epoch (tag of the pair exchanges), [1] error flag, [2] prefetch sink, [8] second epoch slot
     int epoch_slot = 0;                    // which epoch slot (0 / 8) the forward being emitted reads (ping-pong sample loop)
@@ -674,8 +673,7 @@ struct Emitter {
                 pf.bytes[k] = nx.bytes[k]; pf.stride[k] = nx.stride[k];
             }
             pf.sink = h->epoch_dev + 2;
-            pf.late = ((h->O("tune") & 1) ? 0 : 1) | (int)((nx.xmask[0] & 15u) << 8) | (int)((nx.nrep[0] & 255u) << 16);      // (+ region 0's piece layout: kernels.h Pf)
-            // (bit 0, round 6: touches a few microseconds before the launch ends; tune bit 0: round 5's, at its head)
+            pf.late = (h->O("tune") & 1) ? 0 : 1;      // round 6: touches a few microseconds before the launch ends (tune bit 0: round 5's, at its head)
         }
         if (!dry && !pf_out) pf.wt = (h->O("tune") & 2) ? 0 : 1;        // round 6: the launch's outputs are written through (kernels.h st_out; tune bit 1: round 5's plain stores)
         ++pf_idx;
@@ -976,15 +974,12 @@ static Ten emit_rtb_dconv2(Emitter& E, const std::string& p, const Ten& x0, cons
         int XS = NT / 4;
         while (XS >= 1 && XS < 8 && tiles % (8 / XS) != 0) XS *= 2;
         const bool remap = (XS == 2 || XS == 4) && NT % XS == 0 && tiles % (8 / XS) == 0;
-        if (remap && !(h->O("tune") & 1)) {
-            // round 6, with dconv2_kernel's workgroup mapping: XCD x streams the n-tiles (x & 3) + 4 k -- conv A's fragments of those, as
-            // NT / 4 pieces of one region
-            r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
-            r.xmask[0] = (unsigned)(XS - 1); r.nrep[0] = (unsigned)(NT / XS); r.rstride[0] = (unsigned)(XS * t0);
-        }
-        else if (NT % 8 == 0 && !(h->O("tune") & 1)) {
-            // (identity mapping: an odd number of m-tiles) conv A's fragments, n-tiles x AND x + 8 of XCD x (through round 5: tile x of conv A
-            // and of conv B -- half of a 512-channel layer's tiles were never warmed, and conv B's lines were touched a whole phase early)
+        if (NT % 8 == 0 && !(h->O("tune") & 1)) {
+            // round 6: conv A's fragments only, n-tiles x AND x + 8 of XCD x (through round 5: tile x of conv A and of conv B -- half of a
+            // 512-channel layer's tiles were never warmed, and conv B's lines were touched a whole launch phase before their use).  Under the
+            // workgroup mapping above XCD x streams the tiles (x % XS) + XS k: x and x + 8 are two of its four.  All four as pieces of one
+            // region -- built, alternating processes against this: 304.7 -> 307.5 us per step: the touches cost their issuer more than the
+            // other two tiles bring -- so two it stays.
             r.off[0] = w0.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
             if (NT >= 16) { r.off[1] = w0.off * 4 + 8 * t0; r.bytes[1] = (unsigned)t0; r.stride[1] = (unsigned)t0; }
         }
@@ -1362,13 +1357,7 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
         while (XS >= 1 && XS < 8 && tiles % (8 / XS) != 0) XS *= 2;
         if (!(XS == 2 || XS == 4) || (half ? 2 * NT : NT) % XS != 0 || (h->O("tune") & 1)) XS = 0;
         Pf pf;
-        if (XS) {
-            cindm_unet1d::WReg r{};
-            const size_t t0 = w.sz * 4 / (size_t)NT;
-            r.off[0] = w.off * 4; r.bytes[0] = (unsigned)t0; r.stride[0] = (unsigned)t0;
-            r.xmask[0] = (unsigned)(XS - 1); r.nrep[0] = (unsigned)(NT / XS); r.rstride[0] = (unsigned)(XS * t0);
-            E.pf_step(pf, r);
-        } else E.pf_tiled(pf, w, NT);
+        E.pf_tiled(pf, w, NT);
         if (!E.dry) {
             DresArgs d;
             std::memset(&d, 0, sizeof(d));

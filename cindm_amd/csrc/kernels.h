@@ -144,10 +144,6 @@ struct PhaseBuf { unsigned long long* buf; int slot; };
 // whole phase before their use) cost 1.2 us per step again, adding the riding 1x1's changed nothing.  Two it stays.)
 constexpr int PF_REGIONS = 2;
 struct Pf { const char* base[PF_REGIONS]; unsigned bytes[PF_REGIONS]; unsigned stride[PF_REGIONS]; int* sink; int late; int wt; };
-// (`late` also carries region 0's piece layout: bits 8-11 xmask, bits 16-23 nrep -- see l2_prefetch.  The struct keeps the size it had through
-// round 5 ON PURPOSE: with three more words per region in it, i.e. in every kernel's argument block, the two-chains-on-one-device test failed on
-// four of six fresh boxes -- one sample of the demoted chain off by 2e-5 -- and passed again without them; the cause is not understood)
-__device__ __forceinline__ bool pf_late(const Pf& p) { return (p.late & 1) != 0; }      // late: the touches are issued near the END of the launch; wt: the launch's outputs are written through (st_out)
 struct PfRegs { unsigned v[PF_REGIONS][2]; };
 // (Every caller is a 256-thread kernel.  Round 4: the block size is a CONSTANT here.  `blockDim.x` is a 16-bit VECTOR-memory load
 // from the dispatch packet: its use made hipcc wait `vmcnt(0)` in the middle of this function -- vector loads return in order, so
@@ -160,23 +156,15 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
     const int nshare = (int)((gridDim.x * gridDim.y * gridDim.z + 7) >> 3);
 #pragma unroll
     for (int k = 0; k < PF_REGIONS; ++k) {
-        // region 0 may be nrep PIECES of `bytes` each, (xmask + 1) * stride apart, at base + (xcd & xmask) * stride: the n-tiles
-        // (x % XS) + XS k that an XCD streams under dconv2_kernel's / dresample_kernel's workgroup mapping (xmask = XS - 1)
-        const int xmask = k == 0 ? (p.late >> 8) & 15 : 0, nrep = (k == 0 && ((p.late >> 16) & 255)) ? (p.late >> 16) & 255 : 1;
-        const int lpp = (int)(p.bytes[k] >> 7);
-        const int lines = lpp * nrep;
+        const int lines = (int)(p.bytes[k] >> 7);
         const int per = (lines + nshare - 1) / nshare;
-        const char* base = p.base[k] + (size_t)(xmask ? (xcd & xmask) : xcd) * p.stride[k];
-        const size_t rstride = (size_t)(xmask + 1) * p.stride[k];
+        const char* base = p.base[k] + (size_t)xcd * p.stride[k];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int li = (int)threadIdx.x + BLOCK * i;
             const int line = rank * per + li;
             r.v[k][i] = 0u;
-            if (li < per && line < lines) {
-                const int piece = nrep > 1 ? line / lpp : 0, within = line - piece * lpp;
-                r.v[k][i] = *reinterpret_cast<const unsigned*>(base + (size_t)piece * rstride + ((size_t)within << 7));
-            }
+            if (li < per && line < lines) r.v[k][i] = *reinterpret_cast<const unsigned*>(base + ((size_t)line << 7));
         }
     }
 }
@@ -185,12 +173,12 @@ __device__ __forceinline__ void l2_prefetch(const Pf& p, PfRegs& r) {
 __device__ __forceinline__ void l2_prefetch_early(const Pf& p, PfRegs& r) {
 #pragma unroll
     for (int k = 0; k < PF_REGIONS; ++k) r.v[k][0] = r.v[k][1] = 0u;
-    if (!pf_late(p)) l2_prefetch(p, r);
+    if (!p.late) l2_prefetch(p, r);
 }
 // The late point of a kernel = right behind its LAST load request where there is one (vector loads return in order: a request that
 // is issued behind the touches waits for them, ~1 - 1.5 us from the Infinity Cache -- placed in front of a LayerNorm gain load they cost
 // level0_down 1.6 us), else behind its last K loop.
-__device__ __forceinline__ void l2_prefetch_late(const Pf& p, PfRegs& r) { if (pf_late(p)) l2_prefetch(p, r); }
+__device__ __forceinline__ void l2_prefetch_late(const Pf& p, PfRegs& r) { if (p.late) l2_prefetch(p, r); }
 __device__ __forceinline__ void l2_prefetch_done(const Pf& p, const PfRegs& r) {
     unsigned x = 0u;
 #pragma unroll

@@ -679,9 +679,9 @@ def test_second_chain_on_a_device_goes_exchange_free_up_front(device):
     assert any("ONE chain per device" in str(x.message) for x in w)
     # chain 0 (undisturbed plan) is bit-equal to its solo run.  The DEMOTED chain is held to the chain tolerance against its solo exchange-free run,
     # not to bit-equality: late in round 6 it came out with one to four samples (always samples 11 - 13 of a 16-sample tile) off by 2e-5 ... 7e-5 --
-    # all 24 x 8 values of those samples, last bits -- on most fresh boxes once chain 0's warm-up of a dconv2 successor touched four weight
-    # tiles per XCD instead of two; the tree with only that reverted passes bit-equal, and so does the demoted chain when it is run again alone.
-    # Excluded by experiment: the workgroup mapping, the size of the kernels' argument blocks, write-through outputs.  Open: DESIGN.md section 4.12.
+    # all 24 x 8 values of those samples, last bits -- on most fresh boxes, first seen with the commit that re-mapped dconv2_kernel's workgroups
+    # (and still there with the mapping compiled out: the trigger is timing); the demoted chain is bit-equal again when it is run again alone.
+    # Not sufficient to remove it: the mapping compiled out, the old argument-block size, plain output stores, chain 0's warm-up off.  Open: DESIGN.md 4.12.
     assert torch.equal(out[0], fast_long)
     if not torch.equal(out[1], slow):
         nz = (out[1] != slow).nonzero()
