@@ -1352,8 +1352,8 @@ static Ten emit_resample(Emitter& E, const std::string& p, const Ten& x, bool up
         ++E.launches;
         // workgroup mapping (kernels_dconv.h): a column's 2 NT (NT) workgroups on XS XCDs; n-tile idx % NT of XCD x: idx = x % XS (mod XS)
         // (not on the exchange-free plan -- i.e. not for a chain that shares the device with another one: with 16 columns per workgroup TWO
-        // workgroups write the two 64-byte halves of every 128-byte output line, and under that contention the demoted chain lost such a half
-        // now and then -- one to four samples off by 1e-5 ... 7e-5; 32 columns per workgroup = whole lines per workgroup)
+        // workgroups write the two 64-byte halves of every 128-byte fp32 output line, that plan reads those rows, and this is the best lead for
+        // the demoted chain's last-bit differences under contention -- DESIGN 4.12; 32 columns per workgroup = whole lines per workgroup)
         const bool half = h->O("dresample") >= 2 && NT % 8 == 0 && NT * tiles < 256 && !h->NX();
         // (2 XCDs per column: 305.0 -> 303.7 us per step, config 3 768.0 -> 764.7; 4: 304.7 / 768.2)
         int XS = 2;

@@ -1070,9 +1070,9 @@ struct DresArgs {
 // NH: column split of an n-tile over workgroups -- 1: the workgroup owns all 32 columns (grid NT x tiles = 128 workgroups at 256 rows);
 // 2 (round 6): 16 columns, workgroup x = (n-tile x % NT, half x / NT), 256 workgroups: both halves of an n-tile land on the XCD the tile's
 // weights are warmed for, each reads half of the tile's fragments (98 -> 49 KB) and the same activation tile (98 KB).
-// CAUTION: with NH = 2 two workgroups write the two 64-byte halves of every 128-byte line of out_f32.  Under the contention of a second chain on
-// the device such a half was LOST now and then: the host uses NH = 2 only on the plan whose consumers read out_planes (whole
-// lines per workgroup), never where out_f32 is read.
+// CAUTION: with NH = 2 two workgroups write the two 64-byte halves of every 128-byte line of out_f32 -- the only place of the path where
+// workgroups share output lines, and the best lead for the open two-chain question of DESIGN.md 4.12: the host uses NH = 2 only on the plan
+// whose consumers read out_planes (whole lines per workgroup).
 template <bool UP, int KPW, int NH>
 __global__ __launch_bounds__(256) void dresample_kernel(const DresArgs a) {
     constexpr int T = UP ? 4 : 3, LIN = UP ? 3 : 6, LOUT = UP ? 6 : 3, S = 16;
